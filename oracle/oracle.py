@@ -1,0 +1,193 @@
+"""ctypes wrapper around oracle/bp_oracle.c (the CPU restatement of the ship-ice env.step() path).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (benchpush_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libbp_oracle.so")
+MAXV = 24
+OBS_SHAPE = (4, 150, 150)
+INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scaled_collision_reward", "dist_reward",
+             "trial_success", "boundary_violated", "yaw_violated", "total_ke", "total_impulse", "n_post_solve",
+             "n_contact_pts", "n_first_contact"]
+
+
+class OrcParams(C.Structure):
+    _fields_ = [("dt", C.c_double), ("steps", C.c_int), ("iterations", C.c_int), ("persistence", C.c_int),
+                ("settle_steps", C.c_int), ("brute_force", C.c_int), ("damping_pow", C.c_double),
+                ("bias_coef", C.c_double), ("slop", C.c_double), ("target_speed", C.c_double),
+                ("max_yaw_rate", C.c_double), ("map_w", C.c_double), ("map_h", C.c_double), ("goal_y", C.c_double),
+                ("m_to_pix", C.c_double), ("density", C.c_double), ("poly_radius", C.c_double),
+                ("elasticity", C.c_double), ("friction", C.c_double), ("beta", C.c_double),
+                ("boundary_penalty", C.c_double), ("terminal_reward", C.c_double), ("local_w", C.c_double),
+                ("local_h", C.c_double), ("vshift", C.c_double), ("obs_range", C.c_double)]
+
+
+def build(force=False):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "bp_oracle.c")):
+        subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.POINTER(OrcParams)]
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_reset.restype = C.c_int
+        L.orc_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p,
+                                C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_step.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
+        L.orc_observe.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_num_shapes.restype = C.c_int
+        L.orc_num_shapes.argtypes = [C.c_void_p]
+        for name in ("orc_get_bodies", "orc_get_mass", "orc_get_stats", "orc_get_info"):
+            getattr(L, name).argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_world_polys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_get_local_polys.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.orc_poly_area.restype = C.c_double
+        L.orc_poly_area.argtypes = [C.c_int, C.c_void_p]
+        L.orc_poly_centroid.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_convex_hull.restype = C.c_int
+        L.orc_convex_hull.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_collide.restype = C.c_int
+        L.orc_collide.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OracleShipIce:
+    """Single-env oracle with the reference's reset()/step() shape (ship_ice_env.py:223-355)."""
+
+    def __init__(self, params, ship_vertices, head, tail, brute_force=False):
+        self.L = lib()
+        p = OrcParams()
+        for k, v in params.items():
+            setattr(p, k, v)
+        p.brute_force = int(brute_force)
+        self.params = dict(params)
+        self.h = self.L.orc_create(C.byref(p))
+        self.ship_vertices = np.ascontiguousarray(ship_vertices, np.float64)
+        self.head = np.ascontiguousarray(head, np.float64)
+        self.tail = np.ascontiguousarray(tail, np.float64)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def reset(self, trial, start=None, observe=True):
+        obs_list = trial["obstacles"]
+        counts = np.array([len(o["vertices"]) for o in obs_list], np.int32)
+        verts = np.ascontiguousarray(np.concatenate([np.asarray(o["vertices"], np.float64) for o in obs_list])
+                                     if len(obs_list) else np.zeros((0, 2)), np.float64)
+        centres = np.ascontiguousarray([o["centre"] for o in obs_list], np.float64).reshape(-1, 2)
+        st = np.ascontiguousarray(trial["ship_state"] if start is None else start, np.float64)
+        self.nf = self.L.orc_reset(self.h, len(obs_list), _p(verts), _p(counts), _p(centres),
+                                   len(self.ship_vertices), _p(self.ship_vertices), _p(self.head), _p(self.tail), _p(st))
+        obs = None
+        if observe:
+            obs = np.zeros(OBS_SHAPE, np.uint8)
+            self.L.orc_observe(self.h, _p(obs))
+        return obs, self.info()
+
+    def step(self, action, observe=True):
+        obs = np.zeros(OBS_SHAPE, np.uint8) if observe else None
+        r = C.c_double()
+        t = C.c_int()
+        info = np.zeros(len(INFO_KEYS), np.float64)
+        self.L.orc_step(self.h, float(action), _p(obs) if observe else None, C.byref(r), C.byref(t), _p(info))
+        return obs, r.value, bool(t.value), dict(zip(INFO_KEYS, info.tolist()))
+
+    def info(self):
+        info = np.zeros(len(INFO_KEYS), np.float64)
+        self.L.orc_get_info(self.h, _p(info))
+        return dict(zip(INFO_KEYS, info.tolist()))
+
+    def bodies(self):
+        n = self.L.orc_num_shapes(self.h)
+        out = np.zeros((n, 9), np.float64)
+        self.L.orc_get_bodies(self.h, _p(out))
+        return out
+
+    def mass(self):
+        n = self.L.orc_num_shapes(self.h)
+        out = np.zeros((n, 5), np.float64)
+        self.L.orc_get_mass(self.h, _p(out))
+        return out
+
+    def world_polys(self):
+        n = self.L.orc_num_shapes(self.h)
+        out = np.zeros((n, MAXV, 2), np.float64)
+        cnt = np.zeros(n, np.int32)
+        self.L.orc_get_world_polys(self.h, _p(out), _p(cnt))
+        return out, cnt
+
+    def local_polys(self):
+        n = self.L.orc_num_shapes(self.h)
+        v = np.zeros((n, MAXV, 2), np.float64)
+        nn = np.zeros((n, MAXV, 2), np.float64)
+        self.L.orc_get_local_polys(self.h, _p(v), _p(nn))
+        return v, nn
+
+    def stats(self):
+        out = np.zeros(8, np.int64)
+        self.L.orc_get_stats(self.h, _p(out))
+        return dict(zip(["substeps", "pairs_bb", "narrow", "arb_sum", "arb_max", "moving_sum", "hot_sum", "narb"], out.tolist()))
+
+
+def sincos(x):
+    s, c = C.c_double(), C.c_double()
+    lib().orc_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def poly_area(v):
+    v = np.ascontiguousarray(v, np.float64)
+    return lib().orc_poly_area(len(v), _p(v))
+
+
+def poly_centroid(v):
+    v = np.ascontiguousarray(v, np.float64)
+    out = np.zeros(2)
+    lib().orc_poly_centroid(len(v), _p(v), _p(out))
+    return out
+
+
+def convex_hull(v):
+    v = np.ascontiguousarray(v, np.float64)
+    out = np.zeros((len(v), 2))
+    n = lib().orc_convex_hull(len(v), _p(v), _p(out))
+    return out[:n]
+
+
+def collide(a, ra, b, rb):
+    a = np.ascontiguousarray(a, np.float64)
+    b = np.ascontiguousarray(b, np.float64)
+    n = np.zeros(2)
+    p1 = np.zeros((2, 2))
+    p2 = np.zeros((2, 2))
+    h = np.zeros(2, np.uint32)
+    c = lib().orc_collide(len(a), _p(a), ra, len(b), _p(b), rb, _p(n), _p(p1), _p(p2), _p(h))
+    return c, n, p1[:c], p2[:c], h[:c]
