@@ -1,0 +1,96 @@
+"""ctypes binding of libbenchpush_hip.so (C ABI: include/benchpush_amd.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable, loading / bp_create raise.
+"""
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+MAXV = 20
+MAX_SHIP_VERTS = 32
+INFO_COUNT = 16
+INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scaled_collision_reward", "dist_reward",
+             "trial_success", "boundary_violated", "yaw_violated", "total_ke", "total_impulse", "n_post_solve",
+             "n_contact_pts", "n_first_contact"]
+ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
+EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_reset", "bp_step", "bp_step_physics",
+           "bp_observe", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
+           "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_last_error"]
+
+
+class BpConfig(C.Structure):
+    _fields_ = [("dt", C.c_double), ("steps", C.c_int32), ("iterations", C.c_int32), ("persistence", C.c_int32),
+                ("settle_steps", C.c_int32), ("damping_pow", C.c_double), ("bias_coef", C.c_double), ("slop", C.c_double),
+                ("target_speed", C.c_double), ("max_yaw_rate", C.c_double), ("map_w", C.c_double), ("map_h", C.c_double),
+                ("goal_y", C.c_double), ("m_to_pix", C.c_double), ("density", C.c_double), ("poly_radius", C.c_double),
+                ("elasticity", C.c_double), ("friction", C.c_double), ("beta", C.c_double),
+                ("boundary_penalty", C.c_double), ("terminal_reward", C.c_double), ("local_w", C.c_double),
+                ("local_h", C.c_double), ("vshift", C.c_double), ("obs_range", C.c_double),
+                ("num_ship_verts", C.c_int32), ("_pad", C.c_int32),
+                ("ship_verts", (C.c_double * 2) * MAX_SHIP_VERTS), ("ship_head", C.c_double * 2),
+                ("ship_tail", C.c_double * 2)]
+
+
+class BpError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it has not been built (python -m benchpush_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BpError("libbenchpush_hip.so not found at %s -- build it with `python -m benchpush_amd.build` "
+                      "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.bp_abi_version.restype = C.c_int32
+    L.bp_create.argtypes = [C.POINTER(BpConfig), C.c_int32, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.bp_destroy.argtypes = [vp]
+    L.bp_load_scenarios.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    L.bp_reset.argtypes = [vp, vp, vp, vp, vp]
+    L.bp_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.bp_step_physics.argtypes = [vp, vp, vp, vp, vp, vp, vp]
+    L.bp_observe.argtypes = [vp, vp, vp, vp]
+    L.bp_get_world_polys.argtypes = [vp, vp, vp, vp]
+    L.bp_get_body_state.argtypes = [vp, vp, vp]
+    L.bp_get_low_dim_obs.argtypes = [vp, vp, vp]
+    for n in ("bp_nb_cap", "bp_obs_height", "bp_obs_width"):
+        getattr(L, n).argtypes = [vp]
+        getattr(L, n).restype = C.c_int32
+    L.bp_get_num_bodies.argtypes = [vp, vp]
+    L.bp_check_errors.argtypes = [vp, vp]
+    L.bp_kernel_time_ms.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.bp_enable_timing.argtypes = [vp, C.c_int32]
+    L.bp_last_error.argtypes = [vp]
+    L.bp_last_error.restype = C.c_char_p
+    L.bp_debug_trace.argtypes = [vp, vp, C.c_int32]
+    _lib = L
+    return L
+
+
+def check(L, h, rc, what):
+    if rc != 0:
+        msg = L.bp_last_error(h).decode() if h else ""
+        raise BpError("%s failed: %s (%d) %s" % (what, ERRORS.get(rc, "?"), rc, msg))
+
+
+def make_config(params, ship_vertices, head, tail):
+    cfg = BpConfig()
+    for k, v in params.items():
+        setattr(cfg, k, v)
+    sv = [list(map(float, v)) for v in ship_vertices]
+    if len(sv) > MAX_SHIP_VERTS:
+        raise ValueError("too many ship vertices")
+    cfg.num_ship_verts = len(sv)
+    for i, (x, y) in enumerate(sv):
+        cfg.ship_verts[i][0] = x
+        cfg.ship_verts[i][1] = y
+    cfg.ship_head[0], cfg.ship_head[1] = float(head[0]), float(head[1])
+    cfg.ship_tail[0], cfg.ship_tail[1] = float(tail[0]), float(tail[1])
+    return cfg

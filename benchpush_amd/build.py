@@ -1,0 +1,40 @@
+"""In-tree build of libbenchpush_hip.so (gfx950 only) with hipcc.  The .so is git-ignored but travels with gpurun."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libbenchpush_hip.so")
+SOURCES = ["bp_capi.hip"]
+HEADERS = ["bp_device.hpp", "bp_physics.hpp", "bp_kernels.hpp", "bp_host_geom.hpp", os.path.join("..", "..", "include", "benchpush_amd.h")]
+# -ffp-contract=off / -fno-fast-math: the physics must round exactly like the binary64 reference arithmetic.
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17",
+               "-Wno-unused-value"]
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build_hip(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

@@ -1,0 +1,449 @@
+// libbenchpush_hip.so: C ABI (include/benchpush_amd.h) over the gfx950 kernels.  No torch types, no CPU fallback:
+// every entry point fails with BP_ENODEVICE / BP_EHIP when the GPU path cannot run.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bp_host_geom.hpp"
+#include "bp_kernels.hpp"
+
+struct bp_handle {
+    bp_config cfg;
+    int num_envs = 0;
+    long long env_offset = 0;
+    int device = 0;
+    int nbcap = 0;
+    int num_trials = 0;
+    bool loaded = false, was_reset = false;
+    DevParams P;
+    DevPtrs D;
+    std::vector<void *> allocs;
+    size_t lds_bytes = 0;
+    std::string err;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev; // triples: start, mid, stop
+    size_t ev_used = 0;
+};
+
+static int fail(bp_handle *h, int code, const std::string &msg)
+{
+    if (h) h->err = msg;
+    return code;
+}
+#define HIPCHK(h, call)                                                                                       \
+    do {                                                                                                      \
+        hipError_t _e = (call);                                                                               \
+        if (_e != hipSuccess) return fail((h), BP_EHIP, std::string(#call) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+template <typename T>
+static int dalloc(bp_handle *h, T **p, size_t n, int fill_byte = 0)
+{
+    void *q = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes);
+    if (e != hipSuccess) return fail(h, BP_ENOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemset(q, fill_byte, bytes);
+    if (e != hipSuccess) return fail(h, BP_EHIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return BP_OK;
+}
+
+static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
+static size_t lds_bytes_for(int nbcap)
+{
+    return sizeof(d2) * nbcap * 3 + sizeof(d2) * 32 * 4 + sizeof(d2) * 128 + sizeof(unsigned) * nbcap +
+           sizeof(unsigned short) * nbcap + sizeof(unsigned short) * mvcap_for(nbcap) + (size_t)nbcap + 64;
+}
+
+extern "C" {
+
+int32_t bp_abi_version(void) { return BP_ABI_VERSION; }
+
+const char *bp_last_error(const bp_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int32_t device, bp_handle **out)
+{
+    if (!cfg || !out || num_envs <= 0) return BP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BP_ENODEVICE;
+    if (cfg->damping_pow != 0.0) return BP_EINVAL;          // only the reference's damping: 0 is supported
+    if (cfg->num_ship_verts < 3 || cfg->num_ship_verts > BP_MAX_SHIP_VERTS) return BP_EINVAL;
+    if (cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
+    bp_handle *h = new bp_handle();
+    h->cfg = *cfg;
+    h->num_envs = num_envs;
+    h->env_offset = env_id_offset;
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return BP_ENODEVICE; }
+    memset(&h->D, 0, sizeof(h->D));
+    DevParams &P = h->P;
+    memset(&P, 0, sizeof(P));
+    P.dt_sub = cfg->dt / cfg->steps;
+    P.steps = cfg->steps; P.iterations = cfg->iterations; P.persistence = cfg->persistence; P.settle_steps = cfg->settle_steps;
+    P.damping_pow = cfg->damping_pow; P.bias_coef = cfg->bias_coef; P.slop = cfg->slop;
+    P.target_speed = cfg->target_speed; P.max_yaw_rate = cfg->max_yaw_rate;
+    P.map_w = cfg->map_w; P.map_h = cfg->map_h; P.goal_y = cfg->goal_y; P.m_to_pix = cfg->m_to_pix;
+    P.poly_radius = cfg->poly_radius;
+    P.arb_e = cfg->elasticity * cfg->elasticity;
+    P.arb_u = cfg->friction * cfg->friction;
+    P.beta = cfg->beta; P.boundary_penalty = cfg->boundary_penalty; P.terminal_reward = cfg->terminal_reward;
+    P.local_w = cfg->local_w; P.local_h = cfg->local_h; P.vshift = cfg->vshift; P.obs_range = cfg->obs_range;
+    P.skin = 0.25;
+    P.num_envs = num_envs; P.env_offset = env_id_offset;
+    P.num_ship_verts = cfg->num_ship_verts;
+    memcpy(P.ship_verts, cfg->ship_verts, sizeof(P.ship_verts));
+    memcpy(P.ship_head, cfg->ship_head, sizeof(P.ship_head));
+    memcpy(P.ship_tail, cfg->ship_tail, sizeof(P.ship_tail));
+    // OccupancyGrid.__init__ (occupancy_map.py:11-35) with grid cell 1/m_to_pix
+    const double grid = 1.0 / cfg->m_to_pix;
+    P.grid_w = (int)(cfg->map_w / grid);
+    P.grid_h = (int)(cfg->map_h / grid);
+    P.obs_h = (int)(cfg->local_h * cfg->m_to_pix);
+    P.obs_w = (int)(cfg->local_w * cfg->m_to_pix);
+    *out = h;
+    return BP_OK;
+}
+
+int bp_destroy(bp_handle *h)
+{
+    if (!h) return BP_EINVAL;
+    hipSetDevice(h->device);
+    for (void *p : h->allocs) hipFree(p);
+    for (hipEvent_t e : h->ev) hipEventDestroy(e);
+    delete h;
+    return BP_OK;
+}
+
+int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const double *verts, const int32_t *counts,
+                      const double *centres, const double *starts, const int32_t *nfloes)
+{
+    if (!h || T <= 0 || F < 0 || V <= 0 || !starts || !nfloes) return BP_EINVAL;
+    if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    using namespace bpgeom;
+    std::vector<std::vector<Shape>> trials(T);
+    int maxnb = 1;
+    for (int t = 0; t < T; t++) {
+        std::vector<Shape> &bodies = trials[t];
+        Shape ship;
+        build_ship(h->cfg.ship_verts, h->cfg.num_ship_verts, starts[3 * t], starts[3 * t + 1], starts[3 * t + 2], ship);
+        if ((int)ship.verts.size() > BP_MAXV) return fail(h, BP_EINVAL, "ship hull exceeds BP_MAXV");
+        bodies.push_back(ship);
+        if (nfloes[t] > F) return fail(h, BP_EINVAL, "nfloes > F");
+        for (int f = 0; f < nfloes[t]; f++) {
+            const int n = counts[(size_t)t * F + f];
+            if (n < 3) continue;
+            if (n > V) return fail(h, BP_EINVAL, "vertex count > V");
+            Shape s;
+            if (!build_floe(verts + ((size_t)t * F + f) * V * 2, n, centres[((size_t)t * F + f) * 2],
+                            centres[((size_t)t * F + f) * 2 + 1], h->cfg.density, h->cfg.poly_radius, s))
+                continue;
+            if ((int)s.verts.size() > BP_MAXV) return fail(h, BP_EINVAL, "floe hull exceeds BP_MAXV");
+            bodies.push_back(s);
+        }
+        if ((int)bodies.size() > maxnb) maxnb = (int)bodies.size();
+    }
+    if (maxnb > 60000) return fail(h, BP_EINVAL, "too many bodies");
+    const int nbcap = (maxnb + 7) / 8 * 8;
+    h->nbcap = nbcap;
+    h->num_trials = T;
+    h->P.nbcap = nbcap;
+    h->P.mvcap = mvcap_for(nbcap);
+    h->P.num_trials = T;
+    h->lds_bytes = lds_bytes_for(nbcap);
+    if (h->lds_bytes > 160 * 1024) return fail(h, BP_EINVAL, "nb_cap too large for LDS");
+
+    // host SoA
+    std::vector<int> h_nb(T), h_nv((size_t)T * nbcap, 0);
+    std::vector<d2> h_lv((size_t)T * nbcap * BP_MAXV), h_ln((size_t)T * nbcap * BP_MAXV);
+    std::vector<double4> h_mass((size_t)T * nbcap), h_pose((size_t)T * nbcap);
+    memset(h_lv.data(), 0, h_lv.size() * sizeof(d2));
+    memset(h_ln.data(), 0, h_ln.size() * sizeof(d2));
+    memset(h_mass.data(), 0, h_mass.size() * sizeof(double4));
+    memset(h_pose.data(), 0, h_pose.size() * sizeof(double4));
+    for (int t = 0; t < T; t++) {
+        h_nb[t] = (int)trials[t].size();
+        for (int b = 0; b < (int)trials[t].size(); b++) {
+            const Shape &s = trials[t][b];
+            const size_t o = (size_t)t * nbcap + b;
+            h_nv[o] = (int)s.verts.size();
+            for (int i = 0; i < (int)s.verts.size(); i++) {
+                h_lv[o * BP_MAXV + i].x = s.verts[i].x; h_lv[o * BP_MAXV + i].y = s.verts[i].y;
+                h_ln[o * BP_MAXV + i].x = s.normals[i].x; h_ln[o * BP_MAXV + i].y = s.normals[i].y;
+            }
+            h_mass[o].x = s.m_inv; h_mass[o].y = s.i_inv; h_mass[o].z = s.cog.x; h_mass[o].w = s.cog.y;
+            h_pose[o].x = s.p.x; h_pose[o].y = s.p.y; h_pose[o].z = s.angle; h_pose[o].w = 0.0;
+        }
+    }
+    DevPtrs &D = h->D;
+    int rc;
+    int *d_nb, *d_nv; d2 *d_lv, *d_ln; double4 *d_mass, *d_pose;
+    if ((rc = dalloc(h, &d_nb, T))) return rc;
+    if ((rc = dalloc(h, &d_nv, (size_t)T * nbcap))) return rc;
+    if ((rc = dalloc(h, &d_lv, (size_t)T * nbcap * BP_MAXV))) return rc;
+    if ((rc = dalloc(h, &d_ln, (size_t)T * nbcap * BP_MAXV))) return rc;
+    if ((rc = dalloc(h, &d_mass, (size_t)T * nbcap))) return rc;
+    if ((rc = dalloc(h, &d_pose, (size_t)T * nbcap))) return rc;
+    HIPCHK(h, hipMemcpy(d_nb, h_nb.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_nv, h_nv.data(), sizeof(int) * h_nv.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_lv, h_lv.data(), sizeof(d2) * h_lv.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_ln, h_ln.data(), sizeof(d2) * h_ln.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_mass, h_mass.data(), sizeof(double4) * h_mass.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_pose, h_pose.data(), sizeof(double4) * h_pose.size(), hipMemcpyHostToDevice));
+    D.sc_nb = d_nb; D.sc_nv = d_nv; D.sc_lv = d_lv; D.sc_ln = d_ln; D.sc_mass = d_mass; D.sc_pose = d_pose;
+
+    const size_t E = (size_t)h->num_envs, EB = E * nbcap;
+    if ((rc = dalloc(h, &D.e_trial, E))) return rc;
+    if ((rc = dalloc(h, &D.e_episode, E, 0xFF))) return rc; // -1
+    if ((rc = dalloc(h, &D.e_nb, E))) return rc;
+    if ((rc = dalloc(h, &D.e_err, E))) return rc;
+    if ((rc = dalloc(h, &D.e_stamp, E))) return rc;
+    if ((rc = dalloc(h, &D.e_currdt, E))) return rc;
+    if ((rc = dalloc(h, &D.e_total_work, E))) return rc;
+    if ((rc = dalloc(h, &D.e_ke, E))) return rc;
+    if ((rc = dalloc(h, &D.e_imp, E))) return rc;
+    if ((rc = dalloc(h, &D.e_cnt, E * 4))) return rc;
+    if ((rc = dalloc(h, &D.pxy, EB))) return rc;
+    if ((rc = dalloc(h, &D.ang, EB))) return rc;
+    if ((rc = dalloc(h, &D.rot, EB))) return rc;
+    if ((rc = dalloc(h, &D.velv, EB))) return rc;
+    if ((rc = dalloc(h, &D.velw, EB))) return rc;
+    if ((rc = dalloc(h, &D.velb, EB))) return rc;
+    if ((rc = dalloc(h, &D.wv, EB * BP_MAXV))) return rc;
+    if ((rc = dalloc(h, &D.wn, EB * BP_MAXV))) return rc;
+    if ((rc = dalloc(h, &D.pv, EB * BP_MAXV))) return rc;
+    if ((rc = dalloc(h, &D.bb, EB))) return rc;
+    if ((rc = dalloc(h, &D.fat, EB))) return rc;
+    if ((rc = dalloc(h, &D.adj, EB * BP_KADJ))) return rc;
+    if ((rc = dalloc(h, &D.adjn, EB))) return rc;
+    if ((rc = dalloc(h, &D.hint, EB * BP_KADJ))) return rc;
+    if ((rc = dalloc(h, &D.a_key, E * BP_ACAP, 0xFF))) return rc;
+    if ((rc = dalloc(h, &D.a_stamp, E * BP_ACAP))) return rc;
+    if ((rc = dalloc(h, &D.a_sc, E * BP_ACAP))) return rc;
+    if ((rc = dalloc(h, &D.a_h0, E * BP_ACAP))) return rc;
+    if ((rc = dalloc(h, &D.a_h1, E * BP_ACAP))) return rc;
+    if ((rc = dalloc(h, &D.a_d, E * BP_ACAP * 14))) return rc;
+    D.dbg = nullptr; D.dbg_env = -1;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    h->loaded = true;
+    return BP_OK;
+}
+
+static int launch(bp_handle *h, int mode, const double *actions, const unsigned char *mask, unsigned char *obs, double *reward,
+                  unsigned char *term, unsigned char *trunc, double *info, hipStream_t st, bool physics, bool raster)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    if (h->timing) {
+        if (h->ev_used + 3 > h->ev.size()) {
+            for (int k = 0; k < 3; k++) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); h->ev.push_back(e); }
+        }
+        e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; e2 = h->ev[h->ev_used + 2];
+        h->ev_used += 3;
+        HIPCHK(h, hipEventRecord(e0, st));
+    }
+    if (physics) {
+        hipLaunchKernelGGL(k_physics, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mode, actions, mask, reward, term,
+                           trunc, info);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
+    if (raster && obs) {
+        hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS), 0, st, h->P, h->D, mask, obs);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (h->timing) HIPCHK(h, hipEventRecord(e2, st));
+    return BP_OK;
+}
+
+int bp_reset(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, double *info, void *stream)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "bp_load_scenarios has not been called");
+    HIPCHK(h, hipSetDevice(h->device));
+    const bool save = h->timing;
+    h->timing = false; // resets are not part of the per-step kernel timing
+    const int rc = launch(h, MODE_RESET, nullptr, env_mask, obs, nullptr, nullptr, nullptr, info, (hipStream_t)stream, true, true);
+    h->timing = save;
+    if (rc == BP_OK) h->was_reset = true;
+    return rc;
+}
+
+int bp_step(bp_handle *h, const double *actions, uint8_t *obs, double *reward, uint8_t *terminated, uint8_t *truncated,
+            double *info, void *stream)
+{
+    if (!h || !actions) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_step before bp_load_scenarios/bp_reset");
+    HIPCHK(h, hipSetDevice(h->device));
+    return launch(h, MODE_STEP, actions, nullptr, obs, reward, terminated, truncated, info, (hipStream_t)stream, true, true);
+}
+
+int bp_step_physics(bp_handle *h, const double *actions, double *reward, uint8_t *terminated, uint8_t *truncated, double *info,
+                    void *stream)
+{
+    if (!h || !actions) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_step_physics before bp_load_scenarios/bp_reset");
+    HIPCHK(h, hipSetDevice(h->device));
+    return launch(h, MODE_STEP, actions, nullptr, nullptr, reward, terminated, truncated, info, (hipStream_t)stream, true, false);
+}
+
+int bp_observe(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream)
+{
+    if (!h || !obs) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_observe before bp_load_scenarios/bp_reset");
+    HIPCHK(h, hipSetDevice(h->device));
+    return launch(h, MODE_STEP, nullptr, env_mask, obs, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, false, true);
+}
+
+__global__ void k_export_polys(const DevParams P, const DevPtrs D, double *out, int *counts)
+{
+    const int env = blockIdx.x;
+    const size_t eb = (size_t)env * P.nbcap;
+    const int nb = D.e_nb[env];
+    const int *nv = D.sc_nv + (size_t)D.e_trial[env] * P.nbcap;
+    for (int i = threadIdx.x; i < P.nbcap; i += blockDim.x) {
+        const int n = (i < nb) ? nv[i] : 0;
+        counts[eb + i] = n;
+        for (int q = 0; q < BP_MAXV; q++) {
+            const d2 v = (q < n) ? D.wv[(eb + i) * BP_MAXV + q] : mk2(0.0, 0.0);
+            out[((eb + i) * BP_MAXV + q) * 2] = v.x;
+            out[((eb + i) * BP_MAXV + q) * 2 + 1] = v.y;
+        }
+    }
+}
+__global__ void k_export_bodies(const DevParams P, const DevPtrs D, double *out)
+{
+    const int env = blockIdx.x;
+    const size_t eb = (size_t)env * P.nbcap;
+    const int nb = D.e_nb[env];
+    for (int i = threadIdx.x; i < P.nbcap; i += blockDim.x) {
+        double *o = out + (eb + i) * 9;
+        if (i < nb) {
+            o[0] = D.pxy[eb + i].x; o[1] = D.pxy[eb + i].y; o[2] = D.ang[eb + i];
+            o[3] = D.velv[eb + i].x; o[4] = D.velv[eb + i].y; o[5] = D.velw[eb + i].x;
+            o[6] = D.velb[eb + i].x; o[7] = D.velb[eb + i].y; o[8] = D.velw[eb + i].y;
+        } else {
+            for (int k = 0; k < 9; k++) o[k] = 0.0;
+        }
+    }
+}
+// generate_observation_low_dim (ship_ice_env.py:358-370): |centroid| of each floe's world polygon
+__global__ void k_export_lowdim(const DevParams P, const DevPtrs D, double *out)
+{
+    const int env = blockIdx.x;
+    const size_t eb = (size_t)env * P.nbcap;
+    const int nb = D.e_nb[env];
+    const int *nv = D.sc_nv + (size_t)D.e_trial[env] * P.nbcap;
+    for (int i = 1 + threadIdx.x; i < P.nbcap; i += blockDim.x) {
+        double *o = out + ((size_t)env * (P.nbcap - 1) + (i - 1)) * 2;
+        if (i < nb) {
+            const d2 c = poly_centroid_seq(D.wv + (eb + i) * BP_MAXV, nv[i]);
+            o[0] = __builtin_fabs(c.x); o[1] = __builtin_fabs(c.y);
+        } else { o[0] = 0.0; o[1] = 0.0; }
+    }
+}
+
+int bp_get_world_polys(bp_handle *h, double *out, int32_t *counts, void *stream)
+{
+    if (!h || !out || !counts) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_export_polys, dim3(h->num_envs), dim3(256), 0, (hipStream_t)stream, h->P, h->D, out, counts);
+    HIPCHK(h, hipGetLastError());
+    return BP_OK;
+}
+int bp_get_body_state(bp_handle *h, double *out, void *stream)
+{
+    if (!h || !out) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_export_bodies, dim3(h->num_envs), dim3(256), 0, (hipStream_t)stream, h->P, h->D, out);
+    HIPCHK(h, hipGetLastError());
+    return BP_OK;
+}
+int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream)
+{
+    if (!h || !out) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_export_lowdim, dim3(h->num_envs), dim3(256), 0, (hipStream_t)stream, h->P, h->D, out);
+    HIPCHK(h, hipGetLastError());
+    return BP_OK;
+}
+
+int32_t bp_nb_cap(const bp_handle *h) { return h ? h->nbcap : 0; }
+int32_t bp_obs_height(const bp_handle *h) { return h ? h->P.obs_h : 0; }
+int32_t bp_obs_width(const bp_handle *h) { return h ? h->P.obs_w : 0; }
+
+int bp_get_num_bodies(bp_handle *h, int32_t *out_host)
+{
+    if (!h || !out_host) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out_host, h->D.e_nb, sizeof(int) * h->num_envs, hipMemcpyDeviceToHost));
+    return BP_OK;
+}
+
+int bp_check_errors(bp_handle *h, int32_t *out_host)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    std::vector<int> e(h->num_envs);
+    HIPCHK(h, hipMemcpy(e.data(), h->D.e_err, sizeof(int) * h->num_envs, hipMemcpyDeviceToHost));
+    int any = 0;
+    for (int v : e) any |= v;
+    if (out_host) memcpy(out_host, e.data(), sizeof(int) * h->num_envs);
+    if (any) return fail(h, BP_ECAPACITY, "in-kernel capacity overflow, bits=" + std::to_string(any));
+    return BP_OK;
+}
+
+int bp_enable_timing(bp_handle *h, int32_t on)
+{
+    if (!h) return BP_EINVAL;
+    h->timing = on != 0;
+    h->ev_used = 0;
+    return BP_OK;
+}
+
+int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32_t *launches)
+{
+    if (!h) return BP_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    double p = 0, r = 0;
+    const int n = (int)(h->ev_used / 3);
+    for (int k = 0; k < n; k++) {
+        float a = 0, b = 0;
+        HIPCHK(h, hipEventElapsedTime(&a, h->ev[3 * k], h->ev[3 * k + 1]));
+        HIPCHK(h, hipEventElapsedTime(&b, h->ev[3 * k + 1], h->ev[3 * k + 2]));
+        p += a; r += b;
+    }
+    if (physics_ms) *physics_ms = n ? p / n : 0.0;
+    if (raster_ms) *raster_ms = n ? r / n : 0.0;
+    if (launches) *launches = n;
+    h->ev_used = 0;
+    return BP_OK;
+}
+
+// debug hook used by the parity tests: trace (x, y, angle) of every body of one env after each sub-step of the next
+// launches into a device buffer [substeps][nb_cap][3]; pass NULL to disable.
+int bp_debug_trace(bp_handle *h, double *dev_buf, int32_t env)
+{
+    if (!h) return BP_EINVAL;
+    h->D.dbg = dev_buf;
+    h->D.dbg_env = env;
+    return BP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,141 @@
+// Device-side data layout and small math helpers shared by the kernels of libbenchpush_hip.so.
+// gfx950 only: 64-wide wavefronts are assumed everywhere (one wavefront == one environment).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/benchpush_amd.h"
+
+#define BP_KADJ 24   // Verlet neighbour slots per body
+#define BP_ACAP 64   // arbiter (contact pair) slots per env: one per lane
+#define BP_WAVE 64
+
+typedef double2 d2;
+
+enum { ARB_FIRST = 0, ARB_NORMAL = 1, ARB_IGNORE = 2, ARB_CACHED = 3 };
+#define ARB_FREE_KEY 0xFFFFFFFFu
+
+struct DevParams {
+    double dt_sub;
+    int steps, iterations, persistence, settle_steps;
+    double damping_pow, bias_coef, slop, target_speed, max_yaw_rate, map_w, map_h, goal_y, m_to_pix;
+    double poly_radius, arb_e, arb_u, beta, boundary_penalty, terminal_reward, local_w, local_h, vshift, obs_range;
+    double skin;
+    int nbcap, mvcap, num_envs, num_trials, num_ship_verts;
+    long long env_offset;
+    double ship_verts[BP_MAX_SHIP_VERTS][2];
+    double ship_head[2], ship_tail[2];
+    int obs_h, obs_w, grid_h, grid_w;
+};
+
+// All device arrays of one handle.  "sc_" = scenario (per trial, read-only), others = per-env state.
+struct DevPtrs {
+    // scenarios [T][nbcap]...
+    const int *sc_nb;        // [T] bodies in trial (ship + kept floes)
+    const int *sc_nv;        // [T][nbcap] hull vertex count (0 = unused)
+    const d2 *sc_lv;         // [T][nbcap][MAXV] local hull vertices
+    const d2 *sc_ln;         // [T][nbcap][MAXV] local plane normals
+    const double4 *sc_mass;  // [T][nbcap] m_inv, i_inv, cog.x, cog.y
+    const double4 *sc_pose;  // [T][nbcap] x, y, angle, -
+    // env state
+    int *e_trial, *e_episode, *e_nb, *e_err;
+    unsigned *e_stamp;
+    double *e_currdt, *e_total_work, *e_ke, *e_imp;
+    unsigned *e_cnt;         // [E][4] n_post_solve, n_contact_pts, n_first_contact, -
+    d2 *pxy;                 // [E][nbcap] position of COG
+    double *ang;             // [E][nbcap]
+    d2 *rot;                 // [E][nbcap] cos, sin
+    d2 *velv, *velw, *velb;  // [E][nbcap] (vx,vy) (w,w_bias) (vbx,vby)
+    d2 *wv, *wn, *pv;        // [E][nbcap][MAXV] world verts / normals / previous-step world verts
+    double4 *bb, *fat;       // [E][nbcap] l,b,r,t
+    unsigned short *adj;     // [E][nbcap][KADJ]
+    unsigned char *adjn;     // [E][nbcap]
+    unsigned char *hint;     // [E][nbcap][KADJ]
+    // persisted arbiter slots [E][ACAP]
+    unsigned *a_key, *a_stamp, *a_sc, *a_h0, *a_h1;
+    double *a_d;             // [E][ACAP][14] jn0 jt0 jn1 jt1 nx ny r1x0 r1y0 r2x0 r2y0 r1x1 r1y1 r2x1 r2y1
+    // debug
+    double *dbg;             // optional [substeps][nbcap][3] pose trace of env dbg_env
+    int dbg_env;
+};
+
+__device__ __forceinline__ d2 mk2(double x, double y) { d2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ double vdot(d2 a, d2 b) { return a.x * b.x + a.y * b.y; }
+__device__ __forceinline__ double vcross(d2 a, d2 b) { return a.x * b.y - a.y * b.x; }
+__device__ __forceinline__ d2 vsub(d2 a, d2 b) { return mk2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ d2 vadd(d2 a, d2 b) { return mk2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ d2 vneg(d2 a) { return mk2(-a.x, -a.y); }
+__device__ __forceinline__ d2 vmul(d2 a, double s) { return mk2(a.x * s, a.y * s); }
+__device__ __forceinline__ d2 vperp(d2 a) { return mk2(-a.y, a.x); }
+__device__ __forceinline__ d2 vrotate(d2 a, d2 b) { return mk2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ double vlen(d2 a) { return __builtin_sqrt(vdot(a, a)); }
+__device__ __forceinline__ d2 vlerp(d2 a, d2 b, double t) { return vadd(vmul(a, 1.0 - t), vmul(b, t)); }
+__device__ __forceinline__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
+__device__ __forceinline__ double fclampd(double f, double lo, double hi) { return fmin(fmax(f, lo), hi); }
+
+#define BP_DBL_MIN 2.2250738585072014e-308
+#define BP_PI 3.14159265358979323846
+#define BP_INF (__builtin_inf())
+
+// Deterministic sin/cos: Cody-Waite reduction by pi/2 + fdlibm kernel polynomials.  Same operation order as the CPU
+// oracle so that results are bit-identical (stands in for libm's sin/cos inside Chipmunk's cpvforangle).
+__device__ __forceinline__ void bp_sincos(double x, double &sn, double &cs)
+{
+    const double invpio2 = 6.36619772367581382433e-01;
+    const double pio2_1 = 1.57079632673412561417e+00, pio2_1t = 6.07710050650619224932e-11;
+    const double pio2_2 = 6.07710050630396597660e-11, pio2_2t = 2.02226624879595063154e-21;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    double fn = __builtin_rint(x * invpio2);
+    double r = x - fn * pio2_1;
+    double w = fn * pio2_1t;
+    double y0 = r - w;
+    if (__builtin_fabs(y0) < __builtin_fabs(x) * 7.62939453125e-06) {
+        double t = r;
+        w = fn * pio2_2;
+        r = t - w;
+        w = fn * pio2_2t - ((t - r) - w);
+        y0 = r - w;
+    }
+    double y1 = (r - y0) - w;
+    int q = (int)((long long)fn & 3);
+    double z = y0 * y0;
+    double v = z * y0;
+    double rs = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
+    double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    double kc = 1.0 - (0.5 * z - (z * rc - y0 * y1));
+    if (q == 0) { sn = ks; cs = kc; }
+    else if (q == 1) { sn = kc; cs = -ks; }
+    else if (q == 2) { sn = -ks; cs = -kc; }
+    else { sn = -kc; cs = ks; }
+}
+
+// wave-wide helpers (64 lanes) ---------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
+__device__ __forceinline__ int popc_below(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
+
+// Butterfly arg-max over groups of `width` lanes (32 or 64): largest value, ties -> lowest index; `aux` rides along.
+__device__ __forceinline__ void group_argmax_first(double &v, int &idx, int &aux, int width)
+{
+    for (int off = width >> 1; off >= 1; off >>= 1) {
+        double ov = __shfl_xor(v, off);
+        int oi = __shfl_xor(idx, off);
+        int oa = __shfl_xor(aux, off);
+        bool take = (ov > v) || (ov == v && oi < idx);
+        if (take) { v = ov; idx = oi; aux = oa; }
+    }
+}
+__device__ __forceinline__ double group_min(double v, int width)
+{
+    for (int off = width >> 1; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double group_max(double v, int width)
+{
+    for (int off = width >> 1; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}

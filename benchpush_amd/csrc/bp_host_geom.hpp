@@ -1,0 +1,204 @@
+// Host-side body/shape construction for bp_load_scenarios (product code, C++).
+//
+// Follows what pymunk does when the reference builds its sim objects:
+//   create_polygon  benchpush/common/utils/sim_utils.py:136-153  (Poly(None, verts).center_of_gravity, recentre,
+//                   Poly(body, vs, radius=0.02), shape.density = 0.001)
+//   Ship.sim        benchpush/common/ship.py:77-98               (KINEMATIC body, Poly(radius=0.02))
+// i.e. Chipmunk2D 7.0.3's cpConvexHull (QuickHull, tol 0), cpCentroidForPoly, cpAreaForPoly (with radius),
+// cpMomentForPoly and cpBodyAccumulateMassFromShapes.  The hull's vertex ORDER is part of the contract: vertex
+// indices feed the contact ids and every per-vertex sum runs in this order.
+#pragma once
+#include <cmath>
+#include <cfloat>
+#include <utility>
+#include <vector>
+
+namespace bpgeom {
+
+struct P2 { double x, y; };
+static inline P2 sub(P2 a, P2 b) { return {a.x - b.x, a.y - b.y}; }
+static inline P2 add(P2 a, P2 b) { return {a.x + b.x, a.y + b.y}; }
+static inline double cross(P2 a, P2 b) { return a.x * b.y - a.y * b.x; }
+static inline double dot(P2 a, P2 b) { return a.x * b.x + a.y * b.y; }
+static inline double len(P2 a) { return std::sqrt(dot(a, a)); }
+
+// Splits pts[0..n) into those strictly left of a->b (moved to the front, farthest first) and the rest.
+static int hull_partition(P2 *pts, int n, P2 a, P2 b, double tol)
+{
+    if (n == 0) return 0;
+    double best = 0;
+    int pivot = 0;
+    const P2 d = sub(b, a);
+    const double vtol = tol * len(d);
+    int head = 0;
+    int tail = n - 1;
+    while (head <= tail) {
+        const double val = cross(sub(pts[head], a), d);
+        if (val > vtol) {
+            if (val > best) { best = val; pivot = head; }
+            ++head;
+        } else {
+            std::swap(pts[head], pts[tail]);
+            --tail;
+        }
+    }
+    if (pivot != 0) std::swap(pts[0], pts[pivot]);
+    return head;
+}
+
+static int hull_reduce(double tol, P2 *pts, int n, P2 a, P2 pivot, P2 b, P2 *out)
+{
+    if (n < 0) return 0;
+    if (n == 0) { out[0] = pivot; return 1; }
+    const int nl = hull_partition(pts, n, a, pivot, tol);
+    int k = hull_reduce(tol, pts + 1, nl - 1, a, pts[0], pivot, out);
+    out[k++] = pivot;
+    const int nr = hull_partition(pts + nl, n - nl, pivot, b, tol);
+    return k + hull_reduce(tol, pts + nl + 1, nr - 1, pivot, pts[nl], b, out + k);
+}
+
+// cpConvexHull(count, verts, result, NULL, 0.0)
+static std::vector<P2> convex_hull(const std::vector<P2> &in)
+{
+    const int n = (int)in.size();
+    std::vector<P2> work(in), out(n + 1);
+    int lo = 0, hi = 0;
+    P2 mn = in[0], mx = in[0];
+    for (int i = 1; i < n; ++i) {
+        const P2 v = in[i];
+        if (v.x < mn.x || (v.x == mn.x && v.y < mn.y)) { mn = v; lo = i; }
+        else if (v.x > mx.x || (v.x == mx.x && v.y > mx.y)) { mx = v; hi = i; }
+    }
+    if (lo == hi) { return std::vector<P2>{in[0]}; }
+    std::swap(work[0], work[lo]);
+    std::swap(work[1], work[hi == 0 ? lo : hi]);
+    const P2 a = work[0], b = work[1];
+    // result aliases the work buffer in Chipmunk (result == verts copy); emulate with the same in-place layout
+    std::vector<P2> buf(work);
+    int cnt = hull_reduce(0.0, buf.data() + 2, n - 2, a, b, a, buf.data() + 1) + 1;
+    buf.resize(cnt);
+    return buf;
+}
+
+static P2 centroid(const std::vector<P2> &v)
+{
+    const int n = (int)v.size();
+    double sum = 0.0;
+    P2 acc{0, 0};
+    for (int i = 0; i < n; ++i) {
+        const P2 p = v[i], q = v[(i + 1) % n];
+        const double c = cross(p, q);
+        sum += c;
+        const P2 s = add(p, q);
+        acc = add(acc, P2{s.x * c, s.y * c});
+    }
+    const double f = 1.0 / (3.0 * sum);
+    return {acc.x * f, acc.y * f};
+}
+
+static double area_with_radius(const std::vector<P2> &v, double r)
+{
+    const int n = (int)v.size();
+    double a2 = 0.0, per = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const P2 p = v[i], q = v[(i + 1) % n];
+        a2 += cross(p, q);
+        per += len(sub(p, q));
+    }
+    return r * (M_PI * std::fabs(r) + per) + a2 / 2.0;
+}
+
+static double moment_per_unit_mass(const std::vector<P2> &v, P2 off)
+{
+    const int n = (int)v.size();
+    double s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const P2 p = add(v[i], off), q = add(v[(i + 1) % n], off);
+        const double a = cross(q, p);
+        const double b = dot(p, p) + dot(p, q) + dot(q, q);
+        s1 += a * b;
+        s2 += a;
+    }
+    return (1.0 * s1) / (6.0 * s2);
+}
+
+// numpy shoelace of the raw polygon (geometry/polygon.py:25-29) used by the zero-area filter, ship_ice_env.py:206
+static double shoelace_area(const double *xy, int n)
+{
+    double d1 = 0.0, d2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int p = (i - 1 + n) % n;
+        d1 += xy[2 * i] * xy[2 * p + 1];
+        d2 += xy[2 * i + 1] * xy[2 * p];
+    }
+    return 0.5 * std::fabs(d1 - d2);
+}
+
+struct Shape {
+    std::vector<P2> verts;   // hull, body-local (COG recentred)
+    std::vector<P2> normals; // plane i: edge verts[i-1] -> verts[i]
+    double m_inv = 0, i_inv = 0;
+    P2 cog{0, 0};
+    P2 p{0, 0};              // world position of the centre of gravity
+    double angle = 0;
+};
+
+static void set_planes(Shape &s)
+{
+    const int n = (int)s.verts.size();
+    s.normals.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const P2 a = s.verts[(i - 1 + n) % n], b = s.verts[i];
+        const P2 e = sub(b, a);
+        const P2 rp{e.y, -e.x};
+        const double inv = 1.0 / (len(rp) + DBL_MIN);
+        s.normals[i] = {rp.x * inv, rp.y * inv};
+    }
+}
+
+// floe: returns false if dropped by the zero-area filter
+static bool build_floe(const double *raw_xy, int n, double cx, double cy, double density, double radius, Shape &out)
+{
+    if (shoelace_area(raw_xy, n) == 0.0) return false;
+    std::vector<P2> loc(n);
+    for (int i = 0; i < n; ++i) loc[i] = {raw_xy[2 * i] - cx, raw_xy[2 * i + 1] - cy};
+    const std::vector<P2> h0 = convex_hull(loc);
+    const P2 c0 = centroid(h0);
+    for (int i = 0; i < n; ++i) loc[i] = {loc[i].x - c0.x, loc[i].y - c0.y};
+    out.verts = convex_hull(loc);
+    set_planes(out);
+    const P2 sc = centroid(out.verts);
+    const double area = area_with_radius(out.verts, radius);
+    const double m = density * area;
+    const double ipm = moment_per_unit_mass(out.verts, P2{-sc.x, -sc.y});
+    // cpBodyAccumulateMassFromShapes with a single shape on an empty body
+    double bm = 0.0, bi = 0.0;
+    P2 bc{0, 0};
+    const double msum = bm + m;
+    const P2 dc = sub(bc, sc);
+    bi += m * ipm + dot(dc, dc) * (m * bm) / msum;
+    const double t = m / msum;
+    bc = P2{bc.x * (1.0 - t) + sc.x * t, bc.y * (1.0 - t) + sc.y * t};
+    bm = msum;
+    out.m_inv = 1.0 / bm;
+    out.i_inv = 1.0 / bi;
+    out.cog = bc;
+    out.angle = 0.0;
+    out.p = P2{(bc.x * 1.0 - bc.y * 0.0) + cx, (bc.x * 0.0 + bc.y * 1.0) + cy};
+    return true;
+}
+
+static void build_ship(const double (*sv)[2], int n, double x, double y, double theta, Shape &out)
+{
+    std::vector<P2> loc(n);
+    for (int i = 0; i < n; ++i) loc[i] = {sv[i][0], sv[i][1]};
+    out.verts = convex_hull(loc);
+    set_planes(out);
+    out.m_inv = 0.0;
+    out.i_inv = 0.0;
+    out.cog = {0, 0};
+    out.p = {x, y};
+    out.angle = theta;
+}
+
+} // namespace bpgeom

@@ -1,0 +1,575 @@
+// Kernels: k_physics (env.step()/reset() physics + work/reward) and k_observe (4x150x150 u8 raster).
+#pragma once
+#include "bp_physics.hpp"
+
+enum { MODE_STEP = 0, MODE_RESET = 1 };
+
+extern __shared__ double2 bp_smem[];
+
+// numpy restatements with sequential sums (geometry/polygon.py:25-41)
+__device__ __forceinline__ double poly_area_seq(const d2 *v, int n)
+{
+    double d1 = 0.0, d2_ = 0.0;
+    for (int i = 0; i < n; i++) {
+        const int p = (i - 1 + n) % n;
+        d1 += v[i].x * v[p].y;
+        d2_ += v[i].y * v[p].x;
+    }
+    return 0.5 * __builtin_fabs(d1 - d2_);
+}
+__device__ __forceinline__ d2 poly_centroid_seq(const d2 *v, int n)
+{
+    const double A = poly_area_seq(v, n);
+    double sx = 0.0, sy = 0.0;
+    for (int i = 0; i < n; i++) {
+        const int p = (i - 1 + n) % n;
+        const double u = v[i].x * v[p].y - v[p].x * v[i].y;
+        sx += (v[i].x + v[p].x) * u;
+        sy += (v[i].y + v[p].y) * u;
+    }
+    const double f = 1.0 / (6.0 * A);
+    return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
+}
+
+__global__ __launch_bounds__(64) void k_physics(const DevParams P, const DevPtrs D, const int mode, const double *__restrict__ actions,
+                                                const unsigned char *__restrict__ mask, double *__restrict__ reward,
+                                                unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
+                                                double *__restrict__ info)
+{
+    const int env = blockIdx.x;
+    const int lane = lane_id();
+    if (mode == MODE_RESET && mask != nullptr && mask[env] == 0) return;
+    const int nbcap = P.nbcap;
+
+    // ---- carve LDS ----
+    LdsCtx L;
+    {
+        char *p = (char *)bp_smem;
+        L.sv = (d2 *)p; p += sizeof(d2) * nbcap;
+        L.sw = (d2 *)p; p += sizeof(d2) * nbcap;
+        L.sb = (d2 *)p; p += sizeof(d2) * nbcap;
+        L.stAv = (d2 *)p; p += sizeof(d2) * 32;
+        L.stAn = (d2 *)p; p += sizeof(d2) * 32;
+        L.stBv = (d2 *)p; p += sizeof(d2) * 32;
+        L.stBn = (d2 *)p; p += sizeof(d2) * 32;
+        L.tf = (d2 *)p; p += sizeof(d2) * 128;
+        L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
+        L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
+        L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
+        L.lastlvl = (unsigned char *)p; p += nbcap;
+        L.rf = (unsigned char *)p; p += 64;
+    }
+
+    // ---- env context ----
+    const size_t eb = (size_t)env * nbcap;
+    int trial, episode;
+    if (mode == MODE_RESET) {
+        episode = D.e_episode[env] + 1; // first reset: -1 -> 0 (ship_ice_env.py:226-229)
+        trial = (int)(((long long)P.env_offset + env + episode) % P.num_trials);
+    } else {
+        episode = D.e_episode[env];
+        trial = D.e_trial[env];
+    }
+    const size_t tb = (size_t)trial * nbcap;
+    EnvCtx E;
+    E.nb = (mode == MODE_RESET) ? D.sc_nb[trial] : D.e_nb[env];
+    E.nv = D.sc_nv + tb;
+    E.lv = D.sc_lv + tb * BP_MAXV;
+    E.ln = D.sc_ln + tb * BP_MAXV;
+    E.mass = D.sc_mass + tb;
+    E.pxy = D.pxy + eb; E.rot = D.rot + eb; E.ang = D.ang + eb;
+    E.wv = D.wv + eb * BP_MAXV; E.wn = D.wn + eb * BP_MAXV; E.pv = D.pv + eb * BP_MAXV;
+    E.bb = D.bb + eb; E.fat = D.fat + eb;
+    E.adj = D.adj + eb * BP_KADJ; E.adjn = D.adjn + eb; E.hint = D.hint + eb * BP_KADJ;
+
+    ArbReg A;
+    SubState S;
+    S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
+    A.level = 0; A.rank = 0;
+    A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
+    A.nMass1 = A.tMass1 = A.bias1 = A.bounce1 = A.jBias1 = 0.0;
+    A.ma = A.ia = A.mb = A.ib = 0.0;
+
+    if (mode == MODE_RESET) {
+        // ---- new space + bodies from the trial (ship_ice_env.py:109-216) ----
+        for (int base = 0; base < nbcap; base += 64) {
+            const int i = base + lane;
+            if (i < nbcap) {
+                L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, 0.0); L.sb[i] = mk2(0.0, 0.0); L.mvs[i] = 0u;
+                if (i < E.nb) {
+                    const double4 ps = D.sc_pose[tb + i];
+                    double sn, cs;
+                    bp_sincos(ps.z, sn, cs);
+                    E.pxy[i] = mk2(ps.x, ps.y); E.ang[i] = ps.z; E.rot[i] = mk2(cs, sn);
+                    E.adjn[i] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        for (int g0 = 0; g0 < E.nb; g0 += 2) {
+            const int i = g0 + (lane >> 5);
+            const bool act = i < E.nb;
+            double4 t; t.x = 1; t.y = 0; t.z = 0; t.w = 0;
+            if (act) {
+                const d2 p = E.pxy[i], r = E.rot[i];
+                const double4 ms = E.mass[i];
+                t.x = r.x; t.y = r.y;
+                t.z = p.x - (ms.z * r.x - ms.w * r.y);
+                t.w = p.y - (ms.z * r.y + ms.w * r.x);
+            }
+            double4 nbb;
+            world_from_pose(P, E, act ? i : 0, act, lane & 31, t, nbb);
+            if (act && (lane & 31) == 0) {
+                E.bb[i] = nbb;
+                double4 nf;
+                nf.x = nbb.x - P.skin; nf.y = nbb.y - P.skin; nf.z = nbb.z + P.skin; nf.w = nbb.w + P.skin;
+                E.fat[i] = nf;
+            }
+        }
+        __syncthreads();
+        // neighbour lists for every body (all fat boxes are final here)
+        for (int i = 0; i < E.nb; i++) {
+            const double4 fi = E.fat[i];
+            int cnt = 0;
+            for (int base = 0; base < E.nb; base += 64) {
+                const int j = base + lane;
+                const bool ov = (j < E.nb) && (j != i) && bb_overlap(fi, E.fat[j]);
+                const unsigned long long m = ballot(ov);
+                const int pos = cnt + popc_below(m, lane);
+                if (ov && pos < BP_KADJ) { E.adj[i * BP_KADJ + pos] = (unsigned short)j; E.hint[i * BP_KADJ + pos] = 0; }
+                cnt += __popcll(m);
+            }
+            if (cnt > BP_KADJ) { S.err |= BP_ERR_ADJ_OVERFLOW; cnt = BP_KADJ; }
+            if (lane == 0) E.adjn[i] = (unsigned char)cnt;
+        }
+        A.key = ARB_FREE_KEY; A.stamp = 0; A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0;
+        A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0;
+        A.n = mk2(0, 0); A.r1_0 = A.r2_0 = A.r1_1 = A.r2_1 = mk2(0, 0);
+        // first sub-step of a new space: every shape is new to the broadphase, so every pair gets tested once
+        for (int base = 0; base < E.nb; base += 64) {
+            const int i = base + lane;
+            if (i < E.nb) L.mv[i] = (unsigned short)i;
+        }
+        S.stamp = 0; S.curr_dt = 0.0; S.nmv = E.nb;
+        S.total_ke = 0.0; S.total_imp = 0.0; S.n_post = S.n_contact = S.n_first = 0;
+        __syncthreads();
+    } else {
+        // ---- load persistent state ----
+        for (int base = 0; base < nbcap; base += 64) {
+            const int i = base + lane;
+            if (i < nbcap) {
+                const bool in = i < E.nb;
+                L.sv[i] = in ? D.velv[eb + i] : mk2(0.0, 0.0);
+                L.sw[i] = in ? D.velw[eb + i] : mk2(0.0, 0.0);
+                L.sb[i] = in ? D.velb[eb + i] : mk2(0.0, 0.0);
+                L.mvs[i] = 0u;
+            }
+        }
+        const size_t ab = (size_t)env * BP_ACAP + lane;
+        A.key = D.a_key[ab]; A.stamp = D.a_stamp[ab];
+        { const unsigned sc = D.a_sc[ab]; A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
+        A.h0 = D.a_h0[ab]; A.h1 = D.a_h1[ab];
+        const double *ad = D.a_d + ab * 14;
+        A.jn0 = ad[0]; A.jt0 = ad[1]; A.jn1 = ad[2]; A.jt1 = ad[3];
+        A.n = mk2(ad[4], ad[5]);
+        A.r1_0 = mk2(ad[6], ad[7]); A.r2_0 = mk2(ad[8], ad[9]); A.r1_1 = mk2(ad[10], ad[11]); A.r2_1 = mk2(ad[12], ad[13]);
+        if (A.key != ARB_FREE_KEY) {
+            const double4 m1 = E.mass[A.key >> 16], m2 = E.mass[A.key & 0xFFFFu];
+            A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+        }
+        S.stamp = D.e_stamp[env]; S.curr_dt = D.e_currdt[env];
+        S.total_ke = D.e_ke[env]; S.total_imp = D.e_imp[env];
+        S.n_post = D.e_cnt[env * 4 + 0]; S.n_contact = D.e_cnt[env * 4 + 1]; S.n_first = D.e_cnt[env * 4 + 2];
+        __syncthreads();
+        // ship control (ship_ice_env.py:265-274): set once per env step
+        if (lane == 0) {
+            const double act = actions[env] * P.max_yaw_rate;
+            const d2 r = E.rot[0];
+            L.sv[0] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
+            L.sw[0] = mk2(act, L.sw[0].y);
+        }
+        __syncthreads();
+        // moving list: every body with a non-zero velocity
+        int n = 0;
+        for (int base = 0; base < E.nb; base += 64) {
+            const int i = base + lane;
+            bool mvg = false;
+            if (i < E.nb) {
+                const d2 v = L.sv[i], w2 = L.sw[i], vb = L.sb[i];
+                mvg = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
+            }
+            const unsigned long long m = ballot(mvg);
+            if (mvg) { const int pos = n + popc_below(m, lane); if (pos < P.mvcap) L.mv[pos] = (unsigned short)i; }
+            n += __popcll(m);
+        }
+        if (n > P.mvcap) { S.err |= BP_ERR_ARB_OVERFLOW; n = P.mvcap; }
+        S.nmv = n;
+        __syncthreads();
+    }
+
+    const unsigned stamp_start = S.stamp;
+    const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
+    for (int it = 0; it < nsub; it++) {
+        substep(P, D, E, L, A, S, P.dt_sub, mode == MODE_STEP);
+        if (D.dbg != nullptr && env == D.dbg_env) {
+            for (int base = 0; base < E.nb; base += 64) {
+                const int i = base + lane;
+                if (i < E.nb) {
+                    double *o = D.dbg + ((size_t)it * nbcap + i) * 3;
+                    o[0] = E.pxy[i].x; o[1] = E.pxy[i].y; o[2] = E.ang[i];
+                }
+            }
+        }
+    }
+
+    // ---- end of step: work / reward / termination (ship_ice_env.py:291-345) or reset snapshot ----
+    double work = 0.0;
+    if (mode == MODE_STEP) {
+        for (int base = 0; base < E.nb; base += 64) {
+            const int i = base + lane;
+            const bool mvd = (i >= 1) && (i < E.nb) && (L.mvs[i] > stamp_start);
+            double contrib = 0.0;
+            if (mvd) {
+                const int n = E.nv[i];
+                d2 *prev = E.pv + (size_t)i * BP_MAXV;
+                const d2 *nowv = E.wv + (size_t)i * BP_MAXV;
+                const double area = poly_area_seq(prev, n);
+                const d2 ca = poly_centroid_seq(prev, n);
+                const d2 cb = poly_centroid_seq(nowv, n);
+                const double d = __builtin_sqrt((ca.x - cb.x) * (ca.x - cb.x) + (ca.y - cb.y) * (ca.y - cb.y));
+                contrib = d * area;
+                for (int q = 0; q < n; q++) prev[q] = nowv[q];
+            }
+            unsigned long long m = ballot(mvd);
+            while (m) { // ascending floe order, like the python loop
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                work += __shfl(contrib, l);
+            }
+        }
+    } else {
+        for (int base = 0; base < E.nb * BP_MAXV; base += 64) {
+            const int q = base + lane;
+            if (q < E.nb * BP_MAXV) E.pv[q] = E.wv[q];
+        }
+    }
+    __syncthreads();
+
+    // ---- write back persistent state ----
+    for (int base = 0; base < nbcap; base += 64) {
+        const int i = base + lane;
+        if (i < nbcap) { D.velv[eb + i] = L.sv[i]; D.velw[eb + i] = L.sw[i]; D.velb[eb + i] = L.sb[i]; }
+    }
+    {
+        const size_t ab = (size_t)env * BP_ACAP + lane;
+        D.a_key[ab] = A.key; D.a_stamp[ab] = A.stamp; D.a_sc[ab] = (unsigned)A.state | ((unsigned)A.count << 8);
+        D.a_h0[ab] = A.h0; D.a_h1[ab] = A.h1;
+        double *ad = D.a_d + ab * 14;
+        ad[0] = A.jn0; ad[1] = A.jt0; ad[2] = A.jn1; ad[3] = A.jt1; ad[4] = A.n.x; ad[5] = A.n.y;
+        ad[6] = A.r1_0.x; ad[7] = A.r1_0.y; ad[8] = A.r2_0.x; ad[9] = A.r2_0.y;
+        ad[10] = A.r1_1.x; ad[11] = A.r1_1.y; ad[12] = A.r2_1.x; ad[13] = A.r2_1.y;
+    }
+    const int err_any = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |
+                        (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
+                        (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
+    if (lane == 0) {
+        const d2 sp = E.pxy[0];
+        const double sa = E.ang[0];
+        D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
+        D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
+        D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
+        if (err_any) atomicOr(&D.e_err[env], err_any);
+        double total_work;
+        if (mode == MODE_RESET) {
+            D.e_trial[env] = trial; D.e_episode[env] = episode; D.e_nb[env] = E.nb;
+            total_work = 0.0;
+            D.e_total_work[env] = 0.0;
+            if (info) {
+                double *o = info + (size_t)env * BP_INFO_COUNT;
+                for (int k = 0; k < BP_INFO_COUNT; k++) o[k] = 0.0;
+                o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa;
+                o[BP_I_KE] = S.total_ke; o[BP_I_IMPULSE] = S.total_imp;
+                o[BP_I_NPOST] = (double)S.n_post; o[BP_I_NCONTACT] = (double)S.n_contact; o[BP_I_NFIRST] = (double)S.n_first;
+            }
+        } else {
+            total_work = D.e_total_work[env] + work;
+            D.e_total_work[env] = total_work;
+            int boundary_terminal = 0;
+            if (sp.x < 0.0 && __builtin_fabs(sp.x - 0.0) >= 0.0) boundary_terminal = 1;
+            if (sp.x > P.map_w && __builtin_fabs(sp.x - P.map_w) >= 0.0) boundary_terminal = 1;
+            int term = 0;
+            if (sp.y >= P.goal_y) term = 1;
+            else if (boundary_terminal) term = 1;
+            double dist_reward = 0.0;
+            if (sp.y < P.goal_y) {
+                const d2 r = E.rot[0];
+                dist_reward = 1.0 * (r.x * 0.0 + r.y * 1.0);
+            }
+            const double coll = -work;
+            double rwd = P.beta * coll + dist_reward;
+            if (S.yaw_violated) rwd += 0.0;
+            if (S.boundary_violated) rwd += P.boundary_penalty;
+            int success = 0;
+            if (term && !boundary_terminal) { rwd += P.terminal_reward; success = 1; }
+            if (reward) reward[env] = rwd;
+            if (terminated) terminated[env] = (unsigned char)term;
+            if (truncated) truncated[env] = 0;
+            if (info) {
+                double *o = info + (size_t)env * BP_INFO_COUNT;
+                o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa; o[BP_I_TOTAL_WORK] = total_work; o[BP_I_WORK] = work;
+                o[BP_I_COLL_REWARD] = coll; o[BP_I_SCALED_COLL] = coll * P.beta; o[BP_I_DIST_REWARD] = dist_reward;
+                o[BP_I_SUCCESS] = success; o[BP_I_BOUNDARY] = S.boundary_violated; o[BP_I_YAW] = S.yaw_violated;
+                o[BP_I_KE] = S.total_ke; o[BP_I_IMPULSE] = S.total_imp;
+                o[BP_I_NPOST] = (double)S.n_post; o[BP_I_NCONTACT] = (double)S.n_contact; o[BP_I_NFIRST] = (double)S.n_first;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_observe: egocentric observation, uint8 [4][H][W] per env (ship_ice_env.py:378-409 + occupancy_map.py).
+// One 256-thread workgroup per env.  Every output pixel is computed directly ("gather"): the 1000x300 global maps
+// of the reference are never materialised.
+//   ch0 footprint   free 0.5 / ship 1.0 / out-of-map 0     occupancy_map.py:300-337,379-410
+//   ch1 goal line   max(0, goal - i*0.04)/goal, OOB 1      occupancy_map.py:413-433,492-521
+//   ch2 heading     cv2.line head->tail 0.5, head pixel 1  occupancy_map.py:524-587
+//   ch3 occupancy   skimage.draw.polygon of floes within 12 m, 25 px/m   occupancy_map.py:37-65,112-140
+// ------------------------------------------------------------------------------------------------------------
+#define OBS_THREADS 256
+#define OBS_MAXCAND 512
+
+// skimage._shared.geometry.point_in_polygon restated (third-party, unpinned): non-zero = inside / edge / vertex.
+// GETX/GETY fetch polygon vertex i in raster coordinates.
+#define BP_PIP_BODY(GETX, GETY)                                                                  \
+    const double eps = 1e-12;                                                                    \
+    unsigned l_cross = 0, r_cross = 0;                                                           \
+    double x1 = GETX(n - 1) - x, y1 = GETY(n - 1) - y;                                           \
+    for (int i = 0; i < n; i++) {                                                                \
+        const double x0 = GETX(i) - x, y0 = GETY(i) - y;                                         \
+        if ((-eps < x0 && x0 < eps) && (-eps < y0 && y0 < eps)) return true;                     \
+        if ((y0 > 0) != (y1 > 0)) {                                                              \
+            if (((x0 * y1 - x1 * y0) / (y1 - y0)) > 0) r_cross++;                                \
+        }                                                                                        \
+        if ((y0 < 0) != (y1 < 0)) {                                                              \
+            if (((x0 * y1 - x1 * y0) / (y1 - y0)) < 0) l_cross++;                                \
+        }                                                                                        \
+        x1 = x0; y1 = y0;                                                                        \
+    }                                                                                            \
+    if ((r_cross & 1) != (l_cross & 1)) return true;                                             \
+    return (r_cross & 1) != 0;
+
+__device__ __forceinline__ bool pip_arrays(const double *xp, const double *yp, int n, double x, double y)
+{
+#define GX(i) xp[i]
+#define GY(i) yp[i]
+    BP_PIP_BODY(GX, GY)
+#undef GX
+#undef GY
+}
+__device__ __forceinline__ bool pip_scaled(const d2 *v, double scale, int n, double x, double y)
+{
+#define GX(i) (v[i].x * scale)
+#define GY(i) (v[i].y * scale)
+    BP_PIP_BODY(GX, GY)
+#undef GX
+#undef GY
+}
+
+__device__ __forceinline__ long long to_u16(double v) { return ((long long)v) & 0xFFFF; }
+
+// cv2.clipLine restated (third-party, unpinned)
+__device__ __forceinline__ bool clip_line(long long W, long long H, long long &x1, long long &y1, long long &x2, long long &y2)
+{
+    const long long right = W - 1, bottom = H - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+struct LineSpec { int valid; long long x0, y0, dx, dy, sx, sy; int vert; };
+
+// 8-connected Bresenham of cv2.line in closed form: after t steps along the driving axis the minor coordinate has
+// advanced m_t = floor((2*dmin*t + dmaj - 1) / (2*dmaj)) (dmaj > 0); left-to-right start like cv::LineIterator.
+__device__ __forceinline__ LineSpec make_line(long long W, long long H, long long x1, long long y1, long long x2, long long y2)
+{
+    LineSpec s;
+    s.valid = 1;
+    if ((unsigned long long)x1 >= (unsigned long long)W || (unsigned long long)x2 >= (unsigned long long)W ||
+        (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
+        if (!clip_line(W, H, x1, y1, x2, y2)) { s.valid = 0; }
+    }
+    long long dx = x2 - x1, dy = y2 - y1;
+    long long px = x1, py = y1;
+    if (dx < 0) { dx = -dx; dy = -dy; px = x2; py = y2; }
+    long long sy = 1;
+    if (dy < 0) { dy = -dy; sy = -1; }
+    s.x0 = px; s.y0 = py; s.dx = dx; s.dy = dy; s.sx = 1; s.sy = sy; s.vert = dy > dx;
+    return s;
+}
+__device__ __forceinline__ bool on_line(const LineSpec &s, long long x, long long y)
+{
+    if (!s.valid) return false;
+    const long long ax = (x - s.x0) * s.sx, ay = (y - s.y0) * s.sy; // steps along +x / signed y from the start
+    long long t, m, dmaj, dmin;
+    if (!s.vert) { t = ax; m = ay; dmaj = s.dx; dmin = s.dy; }
+    else { t = ay; m = ax; dmaj = s.dy; dmin = s.dx; }
+    if (t < 0 || t > dmaj) return false;
+    if (dmaj == 0) return m == 0;
+    const long long mt = (2 * dmin * t + dmaj - 1) / (2 * dmaj);
+    return m == mt;
+}
+
+__global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                         unsigned char *__restrict__ obs)
+{
+    const int env = blockIdx.x;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int tid = threadIdx.x;
+    const int nbcap = P.nbcap;
+    const size_t eb = (size_t)env * nbcap;
+    const int nb = D.e_nb[env];
+    const d2 *wv = D.wv + eb * BP_MAXV;
+    const int *nv = D.sc_nv + (size_t)D.e_trial[env] * nbcap;
+
+    __shared__ int s_ncand;
+    __shared__ unsigned short s_cand[OBS_MAXCAND];
+    __shared__ int s_bbx[OBS_MAXCAND][4]; // minr, maxr, minc, maxc
+    __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
+    __shared__ int s_fcnt, s_fbb[4];
+    if (tid == 0) s_ncand = 0;
+    __syncthreads();
+
+    const d2 sp = D.pxy[eb];
+    const double sa = D.ang[eb];
+    const d2 srot = D.rot[eb]; // (cos, sin) == bp_sincos(sa)
+    const int Hg = P.grid_h, Wg = P.grid_w, LH = P.obs_h, LW = P.obs_w;
+    const double m2gx = (double)Wg / P.map_w, m2gy = (double)Hg / P.map_h;
+
+    // candidate floes: culling by |centroid| range (occupancy_map.py:44-49) + pixel bbox vs window
+    const int wx = (int)(sp.x * m2gx);
+    const int wy = (int)((sp.y + P.vshift) * m2gy);
+    const int gi0 = (int)((double)(0 + wy) - ((double)LH / 2)), gj0 = (int)((double)(0 + wx) - ((double)LW / 2));
+    const int gi1 = (int)((double)(LH - 1 + wy) - ((double)LH / 2)), gj1 = (int)((double)(LW - 1 + wx) - ((double)LW / 2));
+    const int bh = (int)(P.map_h * P.m_to_pix), bw = (int)(P.map_w * P.m_to_pix);
+    for (int s = 1 + tid; s < nb; s += OBS_THREADS) {
+        const int n = nv[s];
+        const d2 *v = wv + (size_t)s * BP_MAXV;
+        const d2 c = poly_centroid_seq(v, n);
+        const double cx = __builtin_fabs(c.x), cy = __builtin_fabs(c.y);
+        if (__builtin_fabs(sp.x - cx) > P.obs_range || __builtin_fabs(sp.y - cy) > P.obs_range) continue;
+        double rmin = v[0].y * P.m_to_pix, rmax = rmin, cmin = v[0].x * P.m_to_pix, cmax = cmin;
+        for (int i = 1; i < n; i++) {
+            const double r = v[i].y * P.m_to_pix, cc = v[i].x * P.m_to_pix;
+            rmin = fmin(rmin, r); rmax = fmax(rmax, r); cmin = fmin(cmin, cc); cmax = fmax(cmax, cc);
+        }
+        long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
+        long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
+        if (maxr > bh - 1) maxr = bh - 1;
+        if (maxc > bw - 1) maxc = bw - 1;
+        if (maxr < gi0 || minr > gi1 || maxc < gj0 || minc > gj1 || maxr < minr || maxc < minc) continue;
+        const int slot = atomicAdd(&s_ncand, 1);
+        if (slot < OBS_MAXCAND) {
+            s_cand[slot] = (unsigned short)s;
+            s_bbx[slot][0] = (int)minr; s_bbx[slot][1] = (int)maxr; s_bbx[slot][2] = (int)minc; s_bbx[slot][3] = (int)maxc;
+        }
+    }
+    // ship footprint polygon in grid coords (vertices outside the grid are dropped, occupancy_map.py:318-325)
+    LineSpec line;
+    long long hpx, hpy;
+    {
+        const double ch = srot.x, sh = srot.y;
+        if (tid == 0) {
+            int cnt = 0;
+            double rmin = BP_INF, rmax = -BP_INF, cmin = BP_INF, cmax = -BP_INF;
+            for (int i = 0; i < P.num_ship_verts; i++) {
+                const double vx = P.ship_verts[i][0] * ch + P.ship_verts[i][1] * -sh + sp.x;
+                const double vy = P.ship_verts[i][0] * sh + P.ship_verts[i][1] * ch + sp.y;
+                const double gx = vx * m2gx, gy = vy * m2gy;
+                if (gy < 0 || gy >= Hg || gx < 0 || gx >= Wg) continue;
+                s_fr[cnt] = gy; s_fc[cnt] = gx; cnt++;
+                rmin = fmin(rmin, gy); rmax = fmax(rmax, gy); cmin = fmin(cmin, gx); cmax = fmax(cmax, gx);
+            }
+            s_fcnt = cnt;
+            if (cnt > 0) {
+                s_fbb[0] = (int)(long long)fmax(0.0, rmin); s_fbb[1] = (int)(long long)__builtin_ceil(rmax);
+                s_fbb[2] = (int)(long long)fmax(0.0, cmin); s_fbb[3] = (int)(long long)__builtin_ceil(cmax);
+            }
+        }
+        const double hx = P.ship_head[0] * ch + P.ship_head[1] * -sh + sp.x, hy = P.ship_head[0] * sh + P.ship_head[1] * ch + sp.y;
+        const double tx = P.ship_tail[0] * ch + P.ship_tail[1] * -sh + sp.x, ty = P.ship_tail[0] * sh + P.ship_tail[1] * ch + sp.y;
+        hpx = to_u16(hx * m2gx); hpy = to_u16(hy * m2gy);
+        const long long tpx = to_u16(tx * m2gx), tpy = to_u16(ty * m2gy);
+        line = make_line(Wg, Hg, hpx, hpy, tpx, tpy);
+        hpx = hpx < 0 ? 0 : (hpx > Wg - 1 ? Wg - 1 : hpx);
+        hpy = hpy < 0 ? 0 : (hpy > Hg - 1 ? Hg - 1 : hpy);
+    }
+    __syncthreads();
+    const int ncand = min(s_ncand, OBS_MAXCAND);
+    if (tid == 0 && s_ncand > OBS_MAXCAND) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+    const double g2m = P.map_h / (double)Hg;
+    const size_t plane = (size_t)LH * LW;
+    unsigned char *o = obs + (size_t)env * BP_OBS_C * plane;
+    (void)sa;
+    for (int px = tid; px < LH * LW; px += OBS_THREADS) {
+        const int li = px / LW, lj = px - li * LW;
+        const int gi = (int)((double)(li + wy) - ((double)LH / 2));
+        const int gj = (int)((double)(lj + wx) - ((double)LW / 2));
+        const bool inb = !(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg);
+        unsigned char f = 0, e = 255, orn = 0, oc = 0;
+        if (inb) {
+            // ch0
+            f = 127;
+            if (s_fcnt > 0 && gi >= s_fbb[0] && gi <= s_fbb[1] && gj >= s_fbb[2] && gj <= s_fbb[3]) {
+                if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) f = 255;
+            }
+            // ch1
+            double dd = P.goal_y - gi * g2m;
+            if (dd < 0) dd = 0;
+            e = (unsigned char)((dd / P.goal_y) * 255);
+            // ch2
+            if (on_line(line, gj, gi)) orn = 127;
+            if (gj == hpx && gi == hpy) orn = 255;
+            // ch3
+            for (int k = 0; k < ncand && !oc; k++) {
+                if (gi < s_bbx[k][0] || gi > s_bbx[k][1] || gj < s_bbx[k][2] || gj > s_bbx[k][3]) continue;
+                const int s = s_cand[k];
+                const int n = nv[s];
+                const d2 *v = wv + (size_t)s * BP_MAXV;
+                if (pip_scaled(v, P.m_to_pix, n, (double)gj, (double)gi)) oc = 255;
+            }
+        }
+        o[0 * plane + px] = f;
+        o[1 * plane + px] = e;
+        o[2 * plane + px] = orn;
+        o[3 * plane + px] = oc;
+    }
+}

@@ -1,0 +1,661 @@
+// k_physics: one 64-lane wavefront per environment, persistent over all sub-steps of one env.step() / reset().
+//
+// Restates one pymunk.Space.step (Chipmunk2D 7.0.3 cpSpaceStep; reference call sites ship_ice_env.py:219,281)
+// per sub-step, wave-synchronously:
+//   1  position integrate + world vertices + AABB of the bodies that move      (cpBodyUpdatePosition, cpPolyShapeCacheData)
+//   2  Verlet neighbour-list refresh for bodies that left their fat AABB          (any exact broadphase == cpBBTree)
+//   3  candidate pairs of moving bodies -> AABB test -> cached-axis early out     (cpSpaceCollideShapes / QueryReject)
+//   4  exact closest-feature query, 64 lanes per pair, + Chipmunk ContactPoints   (cpCollide PolyToPoly)
+//   5  arbiter slots (one per lane): hash-matched impulse carry-over, persistence  (cpArbiterUpdate, cpSpaceArbiterSetFilter)
+//   6  prestep, velocity integrate (damping 0), warm start, 10 sequential-impulse iterations scheduled by
+//      dependency level so that the result equals the sequential sweep in ascending (shapeA, shapeB) order
+//   7  ship x floe bookkeeping (ship_ice_env.py:155-173)
+// Bodies that do not move and arbiters none of whose bodies moved produce exactly the results of the previous
+// sub-step, so they are carried over instead of recomputed (exactness argument in DESIGN.md).
+#pragma once
+#include "bp_device.hpp"
+
+struct ArbReg {
+    unsigned key, stamp, h0, h1;
+    int state, count, level, rank;
+    double jn0, jt0, jn1, jt1;
+    d2 n, r1_0, r2_0, r1_1, r2_1;
+    double nMass0, tMass0, bias0, bounce0, jBias0;
+    double nMass1, tMass1, bias1, bounce1, jBias1;
+    double ma, ia, mb, ib;
+};
+
+struct EnvCtx {
+    int nb;
+    const int *nv;
+    const d2 *lv, *ln;
+    const double4 *mass;
+    d2 *pxy, *rot, *wv, *wn, *pv;
+    double *ang;
+    double4 *bb, *fat;
+    unsigned short *adj;
+    unsigned char *adjn, *hint;
+};
+
+struct LdsCtx {
+    d2 *sv, *sw, *sb;          // [nbcap] (vx,vy) (w,w_bias) (vbx,vby)
+    unsigned *mvs;             // [nbcap] stamp of the sub-step in which the body last moved
+    unsigned short *owner;     // [nbcap]
+    unsigned char *lastlvl;    // [nbcap]
+    d2 *stAv, *stAn, *stBv, *stBn; // [32] staging of the two polygons of a pair
+    d2 *tf;                    // [64][2] (cos, sin) (tx, ty) of the moving bodies of the current chunk
+    unsigned short *mv;        // [P.mvcap] moving-body list
+    unsigned char *rf;         // [64] refresh flags of the current chunk
+};
+
+struct SubState {
+    unsigned stamp;
+    double curr_dt;
+    int nmv;
+    unsigned long long prev_amask;
+    int nlevels;
+    double total_ke, total_imp;
+    unsigned n_post, n_contact, n_first;
+    int err;
+    int yaw_violated, boundary_violated;
+};
+
+struct Manifold { int count; d2 n; d2 p1_0, p2_0, p1_1, p2_1; unsigned h0, h1; int newhint; };
+
+__device__ __forceinline__ bool bb_overlap(double4 a, double4 b)
+{
+    return (a.x <= b.z && b.x <= a.z && a.y <= b.w && b.y <= a.w);
+}
+
+// Exact closest-feature query + ContactPoints for shapes sa < sb, cooperatively by the whole wave.
+// Every lane returns the same Manifold.
+__device__ __forceinline__ Manifold full_pair(const DevParams &P, const EnvCtx &E, const LdsCtx &L, int sa, int sb)
+{
+    const int lane = lane_id();
+    const int nA = E.nv[sa], nB = E.nv[sb];
+    const double rsum = P.poly_radius + P.poly_radius;
+    __syncthreads();
+    if (lane < 32) {
+        if (lane < nA) { L.stAv[lane] = E.wv[sa * BP_MAXV + lane]; L.stAn[lane] = E.wn[sa * BP_MAXV + lane]; }
+    } else {
+        const int q = lane - 32;
+        if (q < nB) { L.stBv[q] = E.wv[sb * BP_MAXV + q]; L.stBn[q] = E.wn[sb * BP_MAXV + q]; }
+    }
+    __syncthreads();
+    // face separations: lanes 0-31 planes of A against B's vertices, lanes 32-63 planes of B against A's
+    const bool isA = lane < 32;
+    const int f = isA ? lane : lane - 32;
+    const int nP = isA ? nA : nB, nQ = isA ? nB : nA;
+    const d2 *Pv = isA ? L.stAv : L.stBv, *Pn = isA ? L.stAn : L.stBn, *Qv = isA ? L.stBv : L.stAv;
+    const bool fvalid = f < nP;
+    const int fc = fvalid ? f : 0;
+    const d2 fn = Pn[fc], fp = Pv[fc];
+    double mn = BP_INF;
+    int jm = 0;
+    for (int j = 0; j < nQ; j++) {
+        const double d = vdot(fn, Qv[j]);
+        if (d < mn) { mn = d; jm = j; }
+    }
+    double s = fvalid ? (mn - vdot(fn, fp)) : -BP_INF;
+    int fi = fvalid ? f : 1000;
+    group_argmax_first(s, fi, jm, 32);
+    const double sA = __shfl(s, 0), sB = __shfl(s, 32);
+    const int iA = __shfl(fi, 0), iB = __shfl(fi, 32);
+    const int jA = __shfl(jm, 0), jB = __shfl(jm, 32);
+
+    Manifold M;
+    M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0);
+    M.p1_0 = M.p2_0 = M.p1_1 = M.p2_1 = mk2(0, 0);
+    const bool useA = (sA >= sB);
+    const double smax = useA ? sA : sB;
+    M.newhint = 255;
+    if (smax > rsum) { M.newhint = useA ? iA : (nA + iB); return M; }
+    d2 n;
+    bool touching = true;
+    if (smax <= 0.0) {
+        n = useA ? L.stAn[iA] : vneg(L.stBn[iB]);
+    } else {
+        // in_span tests for the best plane of each polygon
+        const int iA0 = (iA - 1 + nA) % nA;
+        const d2 aA = L.stAv[iA0], bA = L.stAv[iA], qA = L.stBv[jA];
+        const d2 eA = vsub(bA, aA);
+        const double uA = vdot(vsub(qA, aA), eA), eeA = vdot(eA, eA);
+        const bool spanA = !(uA < 0.0) && !(uA > eeA);
+        const int kA = (uA < 0.0) ? iA0 : iA;
+        const int iB0 = (iB - 1 + nB) % nB;
+        const d2 aB = L.stBv[iB0], bB = L.stBv[iB], qB = L.stAv[jB];
+        const d2 eB = vsub(bB, aB);
+        const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
+        const bool spanB = !(uB < 0.0) && !(uB > eeB);
+        const int kB = (uB < 0.0) ? iB0 : iB;
+        if (useA) {
+            if (spanA) n = L.stAn[iA];
+            else if (sB > 0.0 && spanB) n = vneg(L.stBn[iB]);
+            else {
+                const d2 p = vsub(L.stBv[jA], L.stAv[kA]);
+                const double d2_ = vlen(p);
+                if (d2_ > rsum) touching = false;
+                n = vmul(p, 1.0 / (d2_ + BP_DBL_MIN));
+            }
+        } else {
+            if (spanB) n = vneg(L.stBn[iB]);
+            else if (sA > 0.0 && spanA) n = L.stAn[iA];
+            else {
+                const d2 p = vsub(L.stBv[kB], L.stAv[jB]);
+                const double d2_ = vlen(p);
+                if (d2_ > rsum) touching = false;
+                n = vmul(p, 1.0 / (d2_ + BP_DBL_MIN));
+            }
+        }
+    }
+    if (!touching) return M;
+    // support vertices: lanes 0-31 -> A along n, lanes 32-63 -> B along -n
+    const d2 nn = vneg(n);
+    double sd = -BP_INF;
+    int si = 1000, dummy = 0;
+    if (isA) { if (f < nA) { sd = vdot(L.stAv[f], n); si = f; } }
+    else     { if (f < nB) { sd = vdot(L.stBv[f], nn); si = f; } }
+    group_argmax_first(sd, si, dummy, 32);
+    const int i1A = __shfl(si, 0), i1B = __shfl(si, 32);
+    // SupportEdgeForPoly
+    d2 e1a, e1b, e2a, e2b;
+    int e1ia, e1ib, e2ia, e2ib;
+    {
+        const int i0 = (i1A - 1 + nA) % nA, i2 = (i1A + 1) % nA;
+        if (vdot(n, L.stAn[i1A]) > vdot(n, L.stAn[i2])) { e1a = L.stAv[i0]; e1ia = i0; e1b = L.stAv[i1A]; e1ib = i1A; }
+        else { e1a = L.stAv[i1A]; e1ia = i1A; e1b = L.stAv[i2]; e1ib = i2; }
+    }
+    {
+        const int i0 = (i1B - 1 + nB) % nB, i2 = (i1B + 1) % nB;
+        if (vdot(nn, L.stBn[i1B]) > vdot(nn, L.stBn[i2])) { e2a = L.stBv[i0]; e2ia = i0; e2b = L.stBv[i1B]; e2ib = i1B; }
+        else { e2a = L.stBv[i1B]; e2ia = i1B; e2b = L.stBv[i2]; e2ib = i2; }
+    }
+    // ContactPoints
+    const double r1 = P.poly_radius, r2 = P.poly_radius;
+    const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
+    const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
+    const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
+    const double e2_denom = 1.0 / (d_e2_b - d_e2_a + BP_DBL_MIN);
+    M.n = n;
+    {
+        const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_b - d_e1_a) * e1_denom)));
+        const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_a - d_e2_a) * e2_denom)));
+        const double dist = vdot(vsub(p2, p1), n);
+        if (dist <= 0.0) {
+            M.p1_0 = p1; M.p2_0 = p2; M.h0 = ((unsigned)e1ia << 8) | (unsigned)e2ib; M.count = 1;
+        }
+    }
+    {
+        const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_a - d_e1_a) * e1_denom)));
+        const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_b - d_e2_a) * e2_denom)));
+        const double dist = vdot(vsub(p2, p1), n);
+        if (dist <= 0.0) {
+            const unsigned h = ((unsigned)e1ib << 8) | (unsigned)e2ia;
+            if (M.count == 0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = h; M.count = 1; }
+            else { M.p1_1 = p1; M.p2_1 = p2; M.h1 = h; M.count = 2; }
+        }
+    }
+    return M;
+}
+
+// Rebuild the neighbour list of body i around its current AABB (uniform call).
+__device__ __forceinline__ void refresh_body(const DevParams &P, const EnvCtx &E, int i, int &err)
+{
+    const int lane = lane_id();
+    const double4 b = E.bb[i];
+    double4 nf;
+    nf.x = b.x - P.skin; nf.y = b.y - P.skin; nf.z = b.z + P.skin; nf.w = b.w + P.skin;
+    if (lane == 0) E.fat[i] = nf;
+    __syncthreads();
+    int cnt = 0;
+    for (int base = 0; base < E.nb; base += 64) {
+        const int j = base + lane;
+        const bool valid = (j < E.nb) && (j != i);
+        const double4 fj = valid ? E.fat[j] : nf;
+        const bool ov = valid && bb_overlap(nf, fj);
+        const unsigned long long m = ballot(ov);
+        const int pos = cnt + popc_below(m, lane);
+        if (ov && pos < BP_KADJ) { E.adj[i * BP_KADJ + pos] = (unsigned short)j; E.hint[i * BP_KADJ + pos] = 0; }
+        cnt += __popcll(m);
+        if (ov) {
+            int nj = E.adjn[j];
+            bool found = false;
+            for (int s2 = 0; s2 < nj; s2++) found = found || (E.adj[j * BP_KADJ + s2] == (unsigned short)i);
+            if (!found) {
+                if (nj >= BP_KADJ) { // purge entries of j that no longer fat-overlap j
+                    int w = 0;
+                    for (int s2 = 0; s2 < nj; s2++) {
+                        const int k = E.adj[j * BP_KADJ + s2];
+                        const double4 fk = (k == i) ? nf : E.fat[k];
+                        if (bb_overlap(fj, fk)) {
+                            E.adj[j * BP_KADJ + w] = (unsigned short)k;
+                            E.hint[j * BP_KADJ + w] = E.hint[j * BP_KADJ + s2];
+                            w++;
+                        }
+                    }
+                    nj = w;
+                }
+                if (nj < BP_KADJ) {
+                    E.adj[j * BP_KADJ + nj] = (unsigned short)i;
+                    E.hint[j * BP_KADJ + nj] = 0;
+                    E.adjn[j] = (unsigned char)(nj + 1);
+                } else {
+                    E.adjn[j] = (unsigned char)nj;
+                    err |= BP_ERR_ADJ_OVERFLOW;
+                }
+            }
+        }
+    }
+    if (cnt > BP_KADJ) { err |= BP_ERR_ADJ_OVERFLOW; cnt = BP_KADJ; }
+    if (lane == 0) E.adjn[i] = (unsigned char)cnt;
+    __syncthreads();
+}
+
+// world vertices/normals/AABB of body i from its pose (one lane per vertex within a 32-lane group)
+__device__ __forceinline__ void world_from_pose(const DevParams &P, const EnvCtx &E, int i, bool active, int q, double4 t,
+                                                double4 &outbb)
+{
+    const int n = active ? E.nv[i] : 0;
+    const bool valid = active && (q < n);
+    double vx = 0, vy = 0;
+    if (valid) {
+        const d2 lv = E.lv[i * BP_MAXV + q], ln = E.ln[i * BP_MAXV + q];
+        const double c = t.x, s = t.y;
+        vx = (c * lv.x + (-s) * lv.y) + t.z;
+        vy = (s * lv.x + c * lv.y) + t.w;
+        const double nx = c * ln.x + (-s) * ln.y;
+        const double ny = s * ln.x + c * ln.y;
+        E.wv[i * BP_MAXV + q] = mk2(vx, vy);
+        E.wn[i * BP_MAXV + q] = mk2(nx, ny);
+    }
+    const double l = group_min(valid ? vx : BP_INF, 32);
+    const double r = group_max(valid ? vx : -BP_INF, 32);
+    const double bo = group_min(valid ? vy : BP_INF, 32);
+    const double tp = group_max(valid ? vy : -BP_INF, 32);
+    outbb.x = l - P.poly_radius; outbb.y = bo - P.poly_radius; outbb.z = r + P.poly_radius; outbb.w = tp + P.poly_radius;
+}
+
+__device__ __forceinline__ void apply_contact_impulses(const ArbReg &A, int c, d2 &va, double &wa, d2 &vb, double &wb, d2 j)
+{
+    const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
+    const d2 jn = vneg(j);
+    va = vadd(va, vmul(jn, A.ma));
+    wa += A.ia * vcross(r1, jn);
+    vb = vadd(vb, vmul(j, A.mb));
+    wb += A.ib * vcross(r2, j);
+}
+
+// One sub-step.  ship_rules: apply the yaw / boundary rules of ShipIceEnv.step after the sub-step.
+__device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, const EnvCtx &E, const LdsCtx &L, ArbReg &A,
+                                        SubState &S, const double dt, const bool ship_rules)
+{
+    const int lane = lane_id();
+    S.stamp += 1u;
+    const unsigned now = S.stamp;
+    const double prev_dt = S.curr_dt;
+    S.curr_dt = dt;
+    if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) A.state = ARB_NORMAL;
+
+    // ---- 1. integrate positions of the moving bodies; world geometry; AABBs ----------------------------------
+    unsigned long long refresh_any = 0;
+    for (int k0 = 0; k0 < S.nmv; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < S.nmv) {
+            const int i = L.mv[k];
+            const d2 v = L.sv[i], w2 = L.sw[i], vb = L.sb[i];
+            d2 p = E.pxy[i];
+            p.x = p.x + (v.x + vb.x) * dt;
+            p.y = p.y + (v.y + vb.y) * dt;
+            const double a = E.ang[i];
+            const double a2 = a + (w2.x + w2.y) * dt;
+            d2 r = E.rot[i];
+            if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
+            E.pxy[i] = p; E.ang[i] = a2; E.rot[i] = r;
+            L.sb[i] = mk2(0.0, 0.0);
+            L.sw[i] = mk2(w2.x, 0.0);
+            const double4 ms = E.mass[i];
+            double4 t;
+            t.x = r.x; t.y = r.y;
+            t.z = p.x - (ms.z * r.x - ms.w * r.y);
+            t.w = p.y - (ms.z * r.y + ms.w * r.x);
+            L.tf[2 * lane] = mk2(t.x, t.y);
+            L.tf[2 * lane + 1] = mk2(t.z, t.w);
+            L.mvs[i] = now;
+        }
+        __syncthreads();
+        const int cnt = min(64, S.nmv - k0);
+        for (int g0 = 0; g0 < cnt; g0 += 2) {
+            const int kk = g0 + (lane >> 5);
+            const bool act = kk < cnt;
+            const int i = act ? L.mv[k0 + kk] : 0;
+            double4 t;
+            { const d2 t0 = L.tf[2 * (act ? kk : 0)], t1 = L.tf[2 * (act ? kk : 0) + 1]; t.x = t0.x; t.y = t0.y; t.z = t1.x; t.w = t1.y; }
+            double4 nbb;
+            world_from_pose(P, E, i, act, lane & 31, t, nbb);
+            if (act && (lane & 31) == 0) {
+                E.bb[i] = nbb;
+                const double4 f = E.fat[i];
+                L.rf[kk] = !(nbb.x >= f.x && nbb.y >= f.y && nbb.z <= f.z && nbb.w <= f.w);
+            }
+        }
+        __syncthreads();
+        // ---- 2. Verlet refresh --------------------------------------------------------------------------------
+        unsigned long long rm = ballot((lane < cnt) && L.rf[lane < cnt ? lane : 0]);
+        refresh_any |= rm;
+        while (rm) {
+            const int kk = __ffsll((long long)rm) - 1;
+            rm &= rm - 1;
+            refresh_body(P, E, L.mv[k0 + kk], S.err);
+        }
+    }
+    __syncthreads();
+
+    // ---- 3./4. candidate pairs of moving bodies ----------------------------------------------------------------
+    const double rsum = P.poly_radius + P.poly_radius;
+    const int ncand_slots = S.nmv * BP_KADJ;
+    for (int base = 0; base < ncand_slots; base += 64) {
+        const int idx = base + lane;
+        const int k = idx / BP_KADJ, s = idx - k * BP_KADJ;
+        bool valid = k < S.nmv;
+        int i = 0, j = 0;
+        if (valid) {
+            i = L.mv[k];
+            valid = s < (int)E.adjn[i];
+        }
+        if (valid) {
+            j = E.adj[i * BP_KADJ + s];
+            if (L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
+        }
+        if (valid) valid = bb_overlap(E.bb[i], E.bb[j]);
+        int sa = min(i, j), sb = max(i, j);
+        if (valid) {
+            const int h = E.hint[i * BP_KADJ + s];
+            if (h != 255) {
+                const int nA = E.nv[sa], nB = E.nv[sb];
+                int pb, qb, fi;
+                if (h < nA) { pb = sa; qb = sb; fi = h; } else { pb = sb; qb = sa; fi = min(h - nA, nB - 1); }
+                const d2 fn = E.wn[pb * BP_MAXV + fi], fp = E.wv[pb * BP_MAXV + fi];
+                const int nq = E.nv[qb];
+                double mn = BP_INF;
+                for (int q = 0; q < nq; q++) {
+                    const double d = vdot(fn, E.wv[qb * BP_MAXV + q]);
+                    if (d < mn) mn = d;
+                }
+                const double sep = mn - vdot(fn, fp);
+                if (sep > rsum) valid = false;
+            }
+        }
+        unsigned long long cm = ballot(valid);
+        while (cm) {
+            const int l = __ffsll((long long)cm) - 1;
+            cm &= cm - 1;
+            const int usa = __shfl(sa, l), usb = __shfl(sb, l);
+            const Manifold M = full_pair(P, E, L, usa, usb);
+            if (lane == l) E.hint[i * BP_KADJ + s] = (unsigned char)M.newhint;
+            if (M.count > 0) {
+                // cpArbiterUpdate on the slot that owns this pair
+                const unsigned key = ((unsigned)usa << 16) | (unsigned)usb;
+                unsigned long long om = ballot(A.key == key);
+                bool fresh = false;
+                if (!om) { om = ballot(A.key == ARB_FREE_KEY); fresh = true; }
+                if (!om) { S.err |= BP_ERR_ARB_OVERFLOW; }
+                else {
+                    const int owner = __ffsll((long long)om) - 1;
+                    if (lane == owner) {
+                        if (fresh) { A.key = key; A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0; }
+                        const d2 pa = E.pxy[usa], pbp = E.pxy[usb];
+                        double njn0 = 0.0, njt0 = 0.0, njn1 = 0.0, njt1 = 0.0;
+                        if (A.count > 0 && A.h0 == M.h0) { njn0 = A.jn0; njt0 = A.jt0; }
+                        if (A.count > 1 && A.h1 == M.h0) { njn0 = A.jn1; njt0 = A.jt1; }
+                        if (M.count > 1) {
+                            if (A.count > 0 && A.h0 == M.h1) { njn1 = A.jn0; njt1 = A.jt0; }
+                            if (A.count > 1 && A.h1 == M.h1) { njn1 = A.jn1; njt1 = A.jt1; }
+                        }
+                        A.jn0 = njn0; A.jt0 = njt0; A.jn1 = njn1; A.jt1 = njt1;
+                        A.h0 = M.h0; A.h1 = M.h1;
+                        A.r1_0 = vsub(M.p1_0, pa); A.r2_0 = vsub(M.p2_0, pbp);
+                        A.r1_1 = vsub(M.p1_1, pa); A.r2_1 = vsub(M.p2_1, pbp);
+                        A.count = M.count;
+                        A.n = M.n;
+                        if (A.state == ARB_CACHED) A.state = ARB_FIRST;
+                        A.stamp = now;
+                        const double4 m1 = E.mass[usa], m2 = E.mass[usb];
+                        A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+                    }
+                }
+            }
+        }
+    }
+    // arbiters whose bodies did not move keep last sub-step's contacts
+    if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
+        const int a = (int)(A.key >> 16), b = (int)(A.key & 0xFFFFu);
+        if (L.mvs[a] != now && L.mvs[b] != now) A.stamp = now;
+    }
+    // ---- 5. cpSpaceArbiterSetFilter ---------------------------------------------------------------------------
+    if (A.key != ARB_FREE_KEY) {
+        const unsigned ticks = now - A.stamp;
+        if (ticks >= 1u && A.state != ARB_CACHED) A.state = ARB_CACHED;
+        if (ticks >= (unsigned)P.persistence) A.key = ARB_FREE_KEY;
+    }
+    const bool active = (A.key != ARB_FREE_KEY) && (A.stamp == now);
+    const unsigned long long amask = ballot(active);
+    const int ba = (int)(A.key >> 16), bbi = (int)(A.key & 0xFFFFu);
+
+    // ---- solve order: rank by key, dependency levels ----------------------------------------------------------
+    if (amask != S.prev_amask) {
+        int rank = 0;
+        unsigned long long m = amask;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned k = __shfl(A.key, l);
+            rank += (k < A.key) ? 1 : 0;
+        }
+        A.rank = rank;
+        if (active) { L.lastlvl[ba] = 0; L.lastlvl[bbi] = 0; }
+        __syncthreads();
+        const int nact = __popcll(amask);
+        int nlev = 0;
+        for (int r = 0; r < nact; r++) {
+            const unsigned long long rm = ballot(active && A.rank == r);
+            const int l = __ffsll((long long)rm) - 1;
+            const unsigned k = __shfl(A.key, l);
+            const double uma = __shfl(A.ma, l), umb = __shfl(A.mb, l);
+            const int a = (int)(k >> 16), b = (int)(k & 0xFFFFu);
+            const int la = (uma == 0.0) ? 0 : (int)L.lastlvl[a];
+            const int lb = (umb == 0.0) ? 0 : (int)L.lastlvl[b];
+            const int lvl = max(la, lb) + 1;
+            if (uma != 0.0) L.lastlvl[a] = (unsigned char)lvl;
+            if (umb != 0.0) L.lastlvl[b] = (unsigned char)lvl;
+            if (lane == l) A.level = lvl;
+            nlev = max(nlev, lvl);
+        }
+        S.nlevels = nlev;
+        S.prev_amask = amask;
+        __syncthreads();
+    }
+
+    // ---- 6a. prestep (cpArbiterPreStep) -----------------------------------------------------------------------
+    if (active) {
+        const d2 pa = E.pxy[ba], pb = E.pxy[bbi];
+        const d2 va = L.sv[ba], vb = L.sv[bbi];
+        const double wa = L.sw[ba].x, wb = L.sw[bbi].x;
+        const d2 n = A.n;
+        const d2 body_delta = vsub(pb, pa);
+        const d2 t = vperp(n);
+        {
+            const double rcn1 = vcross(A.r1_0, n), rcn2 = vcross(A.r2_0, n);
+            A.nMass0 = 1.0 / ((A.ma + A.ia * rcn1 * rcn1) + (A.mb + A.ib * rcn2 * rcn2));
+            const double rct1 = vcross(A.r1_0, t), rct2 = vcross(A.r2_0, t);
+            A.tMass0 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
+            const double dist = vdot(vadd(vsub(A.r2_0, A.r1_0), body_delta), n);
+            A.bias0 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
+            A.jBias0 = 0.0;
+            const d2 v1 = vadd(va, vmul(vperp(A.r1_0), wa));
+            const d2 v2 = vadd(vb, vmul(vperp(A.r2_0), wb));
+            A.bounce0 = vdot(vsub(v2, v1), n) * P.arb_e;
+        }
+        if (A.count > 1) {
+            const double rcn1 = vcross(A.r1_1, n), rcn2 = vcross(A.r2_1, n);
+            A.nMass1 = 1.0 / ((A.ma + A.ia * rcn1 * rcn1) + (A.mb + A.ib * rcn2 * rcn2));
+            const double rct1 = vcross(A.r1_1, t), rct2 = vcross(A.r2_1, t);
+            A.tMass1 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
+            const double dist = vdot(vadd(vsub(A.r2_1, A.r1_1), body_delta), n);
+            A.bias1 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
+            A.jBias1 = 0.0;
+            const d2 v1 = vadd(va, vmul(vperp(A.r1_1), wa));
+            const d2 v2 = vadd(vb, vmul(vperp(A.r2_1), wb));
+            A.bounce1 = vdot(vsub(v2, v1), n) * P.arb_e;
+        }
+    }
+    __syncthreads();
+    // ---- 6b. velocity integrate: damping^dt == 0, no gravity/forces -> dynamic bodies' v, w := +0 ---------------
+    for (int k0 = 0; k0 < S.nmv; k0 += 64) {
+        const int k = k0 + lane;
+        if (k < S.nmv) {
+            const int i = L.mv[k];
+            if (E.mass[i].x != 0.0) { L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, L.sw[i].y); }
+        }
+    }
+    __syncthreads();
+    // ---- 6c. warm start (cpArbiterApplyCachedImpulse) -----------------------------------------------------------
+    const double dt_coef = (prev_dt == 0.0) ? 0.0 : dt / prev_dt;
+    for (int lvl = 1; lvl <= S.nlevels; lvl++) {
+        if (active && A.level == lvl && A.state != ARB_FIRST) {
+            d2 va = L.sv[ba], vb = L.sv[bbi];
+            d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
+            {
+                const d2 j = vmul(vrotate(A.n, mk2(A.jn0, A.jt0)), dt_coef);
+                apply_contact_impulses(A, 0, va, wa2.x, vb, wb2.x, j);
+            }
+            if (A.count > 1) {
+                const d2 j = vmul(vrotate(A.n, mk2(A.jn1, A.jt1)), dt_coef);
+                apply_contact_impulses(A, 1, va, wa2.x, vb, wb2.x, j);
+            }
+            if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; }
+            if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; }
+        }
+        __syncthreads();
+    }
+    // ---- 6d. sequential impulses (cpArbiterApplyImpulse) ------------------------------------------------------
+    for (int it = 0; it < P.iterations; it++) {
+        for (int lvl = 1; lvl <= S.nlevels; lvl++) {
+            if (active && A.level == lvl) {
+                d2 va = L.sv[ba], vb = L.sv[bbi];
+                d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
+                d2 vba = L.sb[ba], vbb = L.sb[bbi];
+                const d2 n = A.n;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    if (c < A.count) {
+                        const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
+                        const double nMass = c ? A.nMass1 : A.nMass0, tMass = c ? A.tMass1 : A.tMass0;
+                        const double bias = c ? A.bias1 : A.bias0, bounce = c ? A.bounce1 : A.bounce0;
+                        const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
+                        const d2 vb2 = vadd(vbb, vmul(vperp(r2), wb2.y));
+                        const d2 v1 = vadd(va, vmul(vperp(r1), wa2.x));
+                        const d2 v2 = vadd(vb, vmul(vperp(r2), wb2.x));
+                        const d2 vr = vsub(v2, v1);
+                        const double vbn = vdot(vsub(vb2, vb1), n);
+                        const double vrn = vdot(vr, n);
+                        const double vrt = vdot(vr, vperp(n));
+                        const double jbn = (bias - vbn) * nMass;
+                        const double jbnOld = c ? A.jBias1 : A.jBias0;
+                        const double jBias = fmax(jbnOld + jbn, 0.0);
+                        const double jn = -(bounce + vrn) * nMass;
+                        const double jnOld = c ? A.jn1 : A.jn0;
+                        const double jnAcc = fmax(jnOld + jn, 0.0);
+                        const double jtMax = P.arb_u * jnAcc;
+                        const double jt = -vrt * tMass;
+                        const double jtOld = c ? A.jt1 : A.jt0;
+                        const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
+                        if (c) { A.jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
+                        else   { A.jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
+                        const d2 jb = vmul(n, jBias - jbnOld);
+                        const d2 jbneg = vneg(jb);
+                        vba = vadd(vba, vmul(jbneg, A.ma));
+                        wa2.y += A.ia * vcross(r1, jbneg);
+                        vbb = vadd(vbb, vmul(jb, A.mb));
+                        wb2.y += A.ib * vcross(r2, jb);
+                        const d2 j = vrotate(n, mk2(jnAcc - jnOld, jtAcc - jtOld));
+                        apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
+                    }
+                }
+                if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; L.sb[ba] = vba; }
+                if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; L.sb[bbi] = vbb; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 7. post-solve bookkeeping for ship(0) x floe arbiters, ascending key order ------------------------------
+    {
+        const bool shiparb = active && ba == 0;
+        const unsigned long long sm = ballot(shiparb);
+        if (sm) {
+            const double eCoef = (1 - P.arb_e) / (1 + P.arb_e);
+            double ke = 0.0;
+            d2 js = mk2(0.0, 0.0);
+            if (shiparb) {
+                ke += eCoef * A.jn0 * A.jn0 / A.nMass0 + A.jt0 * A.jt0 / A.tMass0;
+                js = vadd(js, vrotate(A.n, mk2(A.jn0, A.jt0)));
+                if (A.count > 1) {
+                    ke += eCoef * A.jn1 * A.jn1 / A.nMass1 + A.jt1 * A.jt1 / A.tMass1;
+                    js = vadd(js, vrotate(A.n, mk2(A.jn1, A.jt1)));
+                }
+            }
+            const double imp = vlen(js);
+            const int ns = __popcll(sm);
+            for (int r = 0; r < ns; r++) { // ship arbiters have the smallest keys: ranks 0..ns-1
+                const unsigned long long rm = ballot(shiparb && A.rank == r);
+                const int l = __ffsll((long long)rm) - 1;
+                S.total_ke += __shfl(ke, l);
+                S.total_imp += __shfl(imp, l);
+                S.n_post += 1u;
+                S.n_contact += (unsigned)__shfl(A.count, l);
+                S.n_first += (__shfl(A.state, l) == ARB_FIRST) ? 1u : 0u;
+            }
+        }
+    }
+    // ---- ship rules of ShipIceEnv.step (ship_ice_env.py:284-290) ------------------------------------------------
+    if (ship_rules) {
+        const double a0 = E.ang[0];
+        const double x0 = E.pxy[0].x;
+        if (a0 <= 0.0 || a0 >= BP_PI) {
+            if (lane == 0) L.sw[0] = mk2(0.0, L.sw[0].y);
+            S.yaw_violated = 1;
+        }
+        if (x0 < 0.0 || x0 > P.map_w) S.boundary_violated = 1;
+    }
+    __syncthreads();
+    // ---- next sub-step's moving list: bodies of active arbiters with a non-zero velocity, plus the ship ----------
+    {
+        bool wantA = false, wantB = false;
+        if (active) {
+            if (A.ma != 0.0) {
+                const d2 v = L.sv[ba], w2 = L.sw[ba], vb = L.sb[ba];
+                wantA = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
+            }
+            if (A.mb != 0.0) {
+                const d2 v = L.sv[bbi], w2 = L.sw[bbi], vb = L.sb[bbi];
+                wantB = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
+            }
+        }
+        if (wantA) L.owner[ba] = (unsigned short)(lane * 2);
+        __syncthreads();
+        if (wantB) L.owner[bbi] = (unsigned short)(lane * 2 + 1);
+        __syncthreads();
+        const bool gotA = wantA && L.owner[ba] == (unsigned short)(lane * 2);
+        const bool gotB = wantB && L.owner[bbi] == (unsigned short)(lane * 2 + 1);
+        const d2 v0 = L.sv[0], w0 = L.sw[0];
+        const int shipmv = (v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? 1 : 0;
+        const unsigned long long mA = ballot(gotA), mB = ballot(gotB);
+        const int nA_ = __popcll(mA);
+        if (lane == 0 && shipmv) L.mv[0] = 0;
+        if (gotA) L.mv[shipmv + popc_below(mA, lane)] = (unsigned short)ba;
+        if (gotB) L.mv[shipmv + nA_ + popc_below(mB, lane)] = (unsigned short)bbi;
+        S.nmv = shipmv + nA_ + __popcll(mB);
+    }
+    __syncthreads();
+    (void)refresh_any;
+    (void)D;
+}

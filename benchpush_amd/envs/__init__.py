@@ -1,0 +1,8 @@
+"""Environment registration, mirroring benchpush/environments/__init__.py:3-7 (id + max_episode_steps)."""
+from ..gym_shim import register
+
+register(
+    id="ship-ice-v0",
+    entry_point="benchpush_amd.envs.ship_ice:ShipIceEnv",
+    max_episode_steps=300,
+)

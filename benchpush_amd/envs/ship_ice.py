@@ -1,0 +1,255 @@
+"""ship-ice-v0 on MI355X: batched tensor environment + the reference-shaped single-env adapter.
+
+Reference: benchpush/environments/ship_ice_nav/ship_ice_env.py (ShipIceEnv).  ``BatchedShipIceEnv`` is the native
+surface (device tensors in / out, all envs stepped by one kernel launch pair); ``ShipIceEnv`` mirrors the reference
+class for drop-in use by BasePolicy / BaseMetric code (same constructor, reset()/step() returns, info keys,
+attributes ``cfg``, ``goal``, ``max_yaw_rate_step``, ``action_space``, ``observation_space``, ``unwrapped``).
+
+PyTorch is used only for device memory and streams; all compute is in libbenchpush_hip.so (C ABI).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..config import DotDict, default_cfg, merge_user_cfg, ship_ice_physics_params
+from ..gym_shim import Env, spaces
+from ..scenario import generate_ice_field, pack_trials
+
+__all__ = ["BatchedShipIceEnv", "ShipIceEnv", "default_trials"]
+
+_CONC_GEN = {  # synthetic generator radii per concentration (floe count ~ BASELINE.json configs)
+    0.1: dict(min_r=0.40, max_r=0.58), 0.2: dict(min_r=0.40, max_r=0.58), 0.3: dict(min_r=0.40, max_r=0.58),
+    0.4: dict(min_r=0.40, max_r=0.58), 0.5: dict(min_r=0.40, max_r=0.58),
+}
+
+
+def default_trials(concentration, num_trials, base_seed=0, goal_y=9.0):
+    """Synthetic stand-in for experiments_<conc>_100_r06_d40x12.pk (missing blobs): trial i <- seed base_seed+i."""
+    kw = _CONC_GEN.get(round(float(concentration), 2), dict(min_r=0.40, max_r=0.58))
+    return [generate_ice_field(float(concentration), base_seed + i, goal_y=goal_y, **kw) for i in range(num_trials)]
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class BatchedShipIceEnv:
+    """E independent ship-ice environments on one GPU.
+
+    reset(mask) / step(actions) follow ShipIceEnv.reset / .step (ship_ice_env.py:223-355) for every env at once.
+    Trial selection generalises ``episode_idx % len(experiment)`` (:188) to ``(global_env_id + episode_idx) % T``.
+    """
+
+    def __init__(self, num_envs, cfg=None, trials=None, device="cuda:0", env_id_offset=0, num_trials=100, base_seed=0):
+        if not torch.cuda.is_available():
+            raise _lib.BpError("BatchedShipIceEnv needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.L = _lib.load()
+        self.cfg = merge_user_cfg(default_cfg("ship_ice"), cfg)
+        assert self.cfg.concentration in [0.1, 0.2, 0.3, 0.4, 0.5]  # ship_ice_env.py:75
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self.params = ship_ice_physics_params(self.cfg)
+        self.goal = (0, self.cfg.goal_y)
+        self.max_yaw_rate_step = (math.pi / 2) / 7
+        if trials is None:
+            trials = default_trials(self.cfg.concentration, num_trials, base_seed, goal_y=self.cfg.goal_y)
+        if self.cfg.low_dim_state:  # ship_ice_env.py:190-191 pins one trial
+            trials = [trials[self.cfg.fixed_trial_idx]]
+        self.trials = trials
+        bcfg = _lib.make_config(self.params, self.cfg.ship.vertices, self.cfg.ship.head, self.cfg.ship.tail)
+        self.h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.L, None, self.L.bp_create(C.byref(bcfg), self.num_envs, int(env_id_offset), dev_index, C.byref(self.h)),
+                   "bp_create")
+        pk = pack_trials(trials, max_verts=_lib.MAXV)
+        self._pk = pk
+        T, F, V = pk["verts"].shape[:3]
+        _lib.check(self.L, self.h, self.L.bp_load_scenarios(
+            self.h, T, F, V, pk["verts"].ctypes.data_as(C.c_void_p), pk["counts"].ctypes.data_as(C.c_void_p),
+            pk["centres"].ctypes.data_as(C.c_void_p), pk["starts"].ctypes.data_as(C.c_void_p),
+            pk["nfloes"].ctypes.data_as(C.c_void_p)), "bp_load_scenarios")
+        self.nb_cap = self.L.bp_nb_cap(self.h)
+        self.obs_shape = (4, self.L.bp_obs_height(self.h), self.L.bp_obs_width(self.h))
+        E, dv = self.num_envs, self.device
+        self.obs = torch.zeros((E,) + self.obs_shape, dtype=torch.uint8, device=dv)
+        self.reward = torch.zeros(E, dtype=torch.float64, device=dv)
+        self.terminated = torch.zeros(E, dtype=torch.uint8, device=dv)
+        self.truncated = torch.zeros(E, dtype=torch.uint8, device=dv)
+        self.info = torch.zeros((E, _lib.INFO_COUNT), dtype=torch.float64, device=dv)
+        self._actions = torch.zeros(E, dtype=torch.float64, device=dv)
+
+    # -- helpers -----------------------------------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- API -----------------------------------------------------------------------------------------------
+    def reset(self, mask=None):
+        """Reset the envs selected by ``mask`` (uint8/bool tensor [E]; None = all). Returns (obs, info) views."""
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self.L, self.h, self.L.bp_reset(self.h, _ptr(m), _ptr(self.obs), _ptr(self.info), self._stream()), "bp_reset")
+        return self.obs, self.info
+
+    def step(self, actions):
+        """actions: tensor [E] in [-1, 1] (any float dtype).  Returns (obs, reward, terminated, truncated, info)."""
+        self._actions.copy_(actions.reshape(-1).to(self.device), non_blocking=True)
+        _lib.check(self.L, self.h, self.L.bp_step(self.h, _ptr(self._actions), _ptr(self.obs), _ptr(self.reward),
+                                                 _ptr(self.terminated), _ptr(self.truncated), _ptr(self.info),
+                                                 self._stream()), "bp_step")
+        return self.obs, self.reward, self.terminated, self.truncated, self.info
+
+    def step_physics(self, actions):
+        self._actions.copy_(actions.reshape(-1).to(self.device), non_blocking=True)
+        _lib.check(self.L, self.h, self.L.bp_step_physics(self.h, _ptr(self._actions), _ptr(self.reward), _ptr(self.terminated),
+                                                         _ptr(self.truncated), _ptr(self.info), self._stream()), "bp_step_physics")
+        return self.reward, self.terminated, self.truncated, self.info
+
+    def observe(self, mask=None):
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self.L, self.h, self.L.bp_observe(self.h, _ptr(m), _ptr(self.obs), self._stream()), "bp_observe")
+        return self.obs
+
+    def world_polys(self):
+        """info['obs'] for every env: (verts [E, nb_cap, 20, 2] f64, counts [E, nb_cap] i32); index 0 is the ship."""
+        out = torch.zeros((self.num_envs, self.nb_cap, _lib.MAXV, 2), dtype=torch.float64, device=self.device)
+        cnt = torch.zeros((self.num_envs, self.nb_cap), dtype=torch.int32, device=self.device)
+        _lib.check(self.L, self.h, self.L.bp_get_world_polys(self.h, _ptr(out), _ptr(cnt), self._stream()), "bp_get_world_polys")
+        return out, cnt
+
+    def body_state(self):
+        out = torch.zeros((self.num_envs, self.nb_cap, 9), dtype=torch.float64, device=self.device)
+        _lib.check(self.L, self.h, self.L.bp_get_body_state(self.h, _ptr(out), self._stream()), "bp_get_body_state")
+        return out
+
+    def low_dim_obs(self):
+        out = torch.zeros((self.num_envs, self.nb_cap - 1, 2), dtype=torch.float64, device=self.device)
+        _lib.check(self.L, self.h, self.L.bp_get_low_dim_obs(self.h, _ptr(out), self._stream()), "bp_get_low_dim_obs")
+        return out
+
+    def num_bodies(self):
+        out = np.zeros(self.num_envs, np.int32)
+        _lib.check(self.L, self.h, self.L.bp_get_num_bodies(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_num_bodies")
+        return out
+
+    def check_errors(self):
+        out = np.zeros(self.num_envs, np.int32)
+        rc = self.L.bp_check_errors(self.h, out.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise _lib.BpError("capacity overflow in envs %s: %s" % (np.nonzero(out)[0][:8].tolist(),
+                                                                     self.L.bp_last_error(self.h).decode()))
+
+    def enable_timing(self, on=True):
+        self.L.bp_enable_timing(self.h, int(on))
+
+    def kernel_time_ms(self):
+        p, r, n = C.c_double(), C.c_double(), C.c_int32()
+        _lib.check(self.L, self.h, self.L.bp_kernel_time_ms(self.h, C.byref(p), C.byref(r), C.byref(n)), "bp_kernel_time_ms")
+        return p.value, r.value, n.value
+
+    def debug_trace(self, buf, env=0):
+        self._dbg = buf
+        self.L.bp_debug_trace(self.h, _ptr(buf), int(env))
+
+
+class ShipIceEnv(Env):
+    """Reference-shaped single environment (E = 1) on the GPU path.
+
+    Same surface as the reference ShipIceEnv (ship_ice_env.py:33-355): ``reset(seed, options) -> (obs, info)``,
+    ``step(action) -> (obs, reward, terminated, False, info)`` with numpy observations and the reference's info keys.
+    ``random_start`` draws from python's ``random`` like the reference (:201-203) -- that needs a per-episode start
+    pose, which the trial tables do not carry, so it is applied by re-creating the single trial on reset.
+    """
+
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
+
+    def __init__(self, cfg=None, trials=None, device="cuda:0", num_trials=100, base_seed=0):
+        super().__init__()
+        self._b = BatchedShipIceEnv(1, cfg=cfg, trials=trials, device=device, num_trials=num_trials, base_seed=base_seed)
+        self.cfg = self._b.cfg
+        self.local_window_v_shift = 2
+        self.beta = 30
+        self.directional_reward_scale = 1.0
+        self.episode_idx = None
+        self.goal = (0, self.cfg.goal_y)
+        self.path = None
+        self.low_dim_state = self.cfg.low_dim_state
+        self.max_yaw_rate_step = (np.pi / 2) / 7
+        self.action_space = spaces.Box(low=-1, high=1, dtype=np.float32)
+        self.env_max_trial = len(self._b.trials)
+        if self.low_dim_state:
+            n = len(self._b.trials[0]["obstacles"])
+            self.observation_space = spaces.Box(low=-10, high=30, shape=(n * 2,), dtype=np.float64)
+        else:
+            if not self.cfg.egocentric_obs:
+                raise NotImplementedError("global (planner) observation mode is outside the accelerated path")
+            self.observation_space = spaces.Box(low=0, high=255, shape=self._b.obs_shape, dtype=np.uint8)
+        self.yaw_lim = (0, np.pi)
+        self.boundary_violation_limit = 0.0
+        self.total_work = [0, []]
+        self.t = 0
+
+    def _polys(self):
+        verts, cnt = self._b.world_polys()
+        verts = verts[0].cpu().numpy()
+        cnt = cnt[0].cpu().numpy()
+        nb = int(self._b.num_bodies()[0])
+        return [verts[i, : cnt[i]].copy() for i in range(1, nb)]
+
+    def _observation(self, obstacles):
+        if self.low_dim_state:
+            nb = int(self._b.num_bodies()[0])
+            return self._b.low_dim_obs()[0, : nb - 1].reshape(-1).cpu().numpy()
+        return self._b.obs[0].cpu().numpy()
+
+    def reset(self, seed=None, options=None):
+        self.episode_idx = 0 if self.episode_idx is None else self.episode_idx + 1
+        self._b.reset()
+        self.t = 0
+        self.total_work = [0, []]
+        info_t = self._b.info[0].cpu().numpy()
+        obstacles = self._polys()
+        self.obstacles = obstacles
+        info = {"state": (round(float(info_t[0]), 2), round(float(info_t[1]), 2), round(float(info_t[2]), 2)),
+                "total_work": self.total_work[0], "obs": obstacles}
+        return self._observation(obstacles), info
+
+    def step(self, action):
+        self.t += 1
+        a = torch.tensor([float(np.asarray(action, dtype=np.float32).reshape(-1)[0])], dtype=torch.float64)
+        self._b.step(a)
+        it = self._b.info[0].cpu().numpy()
+        reward = float(self._b.reward[0].item())
+        terminated = bool(self._b.terminated[0].item())
+        obstacles = self._polys()
+        self.obstacles = obstacles
+        work = float(it[4])
+        self.total_work[0] = float(it[3])
+        self.total_work[1].append(work)
+        info = {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)),
+                "total_work": self.total_work[0], "collision reward": float(it[5]), "scaled collision reward": float(it[6]),
+                "dist reward": float(it[7]), "trial_success": bool(it[8]), "obs": obstacles}
+        return self._observation(obstacles), reward, terminated, False, info
+
+    def update_path(self, new_path):
+        self.path = new_path
+
+    def render(self, mode="human", close=False):
+        raise NotImplementedError("rendering (pygame) is outside the accelerated path")
+
+    def close(self):
+        self._b.close()

@@ -1,0 +1,143 @@
+/*
+ * benchpush_amd.h -- C ABI of the MI355X-native batched ship-ice environment (libbenchpush_hip.so).
+ *
+ * The reference (IvanIZ/BenchPush) is pure Python and has no FFI for this path: the hot path is
+ * ShipIceEnv.step()/reset() calling pymunk.Space.step 400x per step plus pure-python rasters
+ * (benchpush/environments/ship_ice_nav/ship_ice_env.py:223-355,378-409).  This ABI is what a ctypes
+ * binding inside the reference's ShipIceEnv would bind instead; each entry point
+ * cites the reference code it replaces.
+ *
+ * Conventions: every function returns 0 on success or a negative BP_E* code, never throws; the caller
+ * owns all buffers passed in (PyTorch-ROCm allocations passed as raw device pointers); all device work
+ * is enqueued on the caller's HIP stream (hipStream_t passed as void*) and nothing synchronises
+ * except bp_load_scenarios and the bp_get_* / bp_check_errors host copies; a handle is bound to one
+ * device and is not thread-safe.  Physics arithmetic is IEEE binary64 ("f64").
+ */
+#ifndef BENCHPUSH_AMD_H
+#define BENCHPUSH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BP_ABI_VERSION 1
+#define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
+#define BP_MAX_SHIP_VERTS 32
+#define BP_OBS_C 4
+#define BP_INFO_COUNT 16
+
+enum {
+    BP_OK = 0,
+    BP_EINVAL = -1,      /* bad argument / unsupported configuration */
+    BP_ENOMEM = -2,
+    BP_EHIP = -3,        /* HIP runtime error, see bp_last_error */
+    BP_ENODEVICE = -4,   /* no usable GPU: the product path refuses to run without one */
+    BP_ESTATE = -5,      /* call order violated (e.g. step before load/reset) */
+    BP_ECAPACITY = -6    /* an in-kernel capacity (neighbour list / arbiter slots) overflowed */
+};
+
+/* per-env error bits reported by bp_check_errors */
+enum { BP_ERR_ADJ_OVERFLOW = 1, BP_ERR_ARB_OVERFLOW = 2, BP_ERR_LEVEL_OVERFLOW = 4 };
+
+/* info[e][k] columns written by bp_step / bp_reset (ship_ice_env.py:337-345 plus the callback
+ * bookkeeping of :150-180); state is raw (the host adapter applies round(.,2)). */
+enum {
+    BP_I_X = 0, BP_I_Y, BP_I_THETA, BP_I_TOTAL_WORK, BP_I_WORK, BP_I_COLL_REWARD, BP_I_SCALED_COLL,
+    BP_I_DIST_REWARD, BP_I_SUCCESS, BP_I_BOUNDARY, BP_I_YAW, BP_I_KE, BP_I_IMPULSE, BP_I_NPOST,
+    BP_I_NCONTACT, BP_I_NFIRST
+};
+
+/* Scalar configuration (ship_ice_nav/config.yaml + constants of ship_ice_env.py, see
+ * benchpush_amd/config.py:ship_ice_physics_params for the file:line of each). */
+typedef struct bp_config {
+    double dt;               /* env step (s) */
+    int32_t steps;           /* physics sub-steps per env step */
+    int32_t iterations;      /* solver iterations */
+    int32_t persistence;     /* Chipmunk collision_persistence */
+    int32_t settle_steps;    /* sub-steps run by reset */
+    double damping_pow;      /* pow(space.damping, dt/steps); only 0 is supported on the GPU */
+    double bias_coef;        /* 1 - pow(collision_bias, dt/steps) */
+    double slop;
+    double target_speed;
+    double max_yaw_rate;
+    double map_w, map_h;
+    double goal_y;
+    double m_to_pix;
+    double density;
+    double poly_radius;
+    double elasticity;
+    double friction;
+    double beta;
+    double boundary_penalty;
+    double terminal_reward;
+    double local_w, local_h;
+    double vshift;
+    double obs_range;
+    int32_t num_ship_verts;
+    int32_t _pad;
+    double ship_verts[BP_MAX_SHIP_VERTS][2];  /* cfg.ship.vertices */
+    double ship_head[2], ship_tail[2];
+} bp_config;
+
+typedef struct bp_handle bp_handle;
+
+/* Create a handle for `num_envs` environments on HIP device `device`.  `env_id_offset` is the global id
+ * of local env 0 (multi-GPU sharding: rank r owns [r*E/R, (r+1)*E/R)); trial selection uses the global id.
+ * Replaces ShipIceEnv.__init__ (ship_ice_env.py:37-106). */
+int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int32_t device, bp_handle **out);
+int bp_destroy(bp_handle *h);
+
+/* Upload `num_trials` ice fields (host pointers).  verts[T][F][V][2] raw world-space polygon vertices as stored in
+ * the reference's trial dicts ('vertices'), counts[T][F] vertex counts (0 = unused slot), centres[T][F][2]
+ * ('centre'), starts[T][3] ship start pose, nfloes[T].  Performs the body/shape construction of
+ * sim_utils.py:136-163 + ship.py:77-98 (convex hull, COG recentre, mass/moment from density) on the host and
+ * copies SoA arrays to the device.  Replaces the pickle load of ship_ice_env.py:76-80 and init_ship_ice_env :186-216. */
+int bp_load_scenarios(bp_handle *h, int32_t num_trials, int32_t F, int32_t V, const double *verts,
+                      const int32_t *counts, const double *centres, const double *starts, const int32_t *nfloes);
+
+/* reset() for the envs whose env_mask byte is non-zero (device pointer; NULL = all envs): next trial
+ * ((global_env_id + episode_idx) % num_trials), new space, 1000 settle sub-steps, first observation.
+ * obs: device uint8 [E][4][H][W] (rows of unmasked envs untouched); info: device double [E][BP_INFO_COUNT] or NULL.
+ * Replaces ShipIceEnv.reset (ship_ice_env.py:223-249). */
+int bp_reset(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, double *info, void *stream);
+
+/* One env.step() for every env: actions device double [E] in [-1,1]; obs device uint8 [E][4][H][W]; reward device
+ * double [E]; terminated / truncated device uint8 [E]; info device double [E][BP_INFO_COUNT] (may be NULL).
+ * Replaces ShipIceEnv.step (ship_ice_env.py:261-355): 400 x pymunk.Space.step, work, reward, raster. */
+int bp_step(bp_handle *h, const double *actions, uint8_t *obs, double *reward, uint8_t *terminated,
+            uint8_t *truncated, double *info, void *stream);
+
+/* Physics only / raster only halves of bp_step (profiling and tests). */
+int bp_step_physics(bp_handle *h, const double *actions, double *reward, uint8_t *terminated, uint8_t *truncated,
+                    double *info, void *stream);
+int bp_observe(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream);
+
+/* info['obs'] (cost_map.py:275-281): world-space hull vertices of every shape, device double [E][nb_cap][BP_MAXV][2],
+ * counts device int32 [E][nb_cap] (index 0 = ship, then floes in trial order). */
+int bp_get_world_polys(bp_handle *h, double *out, int32_t *counts, void *stream);
+/* body state, device double [E][nb_cap][9] = x, y, angle, vx, vy, w, v_bias.x, v_bias.y, w_bias */
+int bp_get_body_state(bp_handle *h, double *out, void *stream);
+/* low-dimensional observation (ship_ice_env.py:358-370): |centroid| of every floe, device double [E][nb_cap-1][2] */
+int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream);
+
+int32_t bp_nb_cap(const bp_handle *h);       /* body slots per env (ship + max floes, padded) */
+int32_t bp_obs_height(const bp_handle *h);
+int32_t bp_obs_width(const bp_handle *h);
+/* number of bodies (ship + floes) currently in each env: host int32 [E] (synchronises) */
+int bp_get_num_bodies(bp_handle *h, int32_t *out_host);
+/* Copies per-env error bits to host int32 [E] (may be NULL) and returns BP_ECAPACITY if any is set (synchronises). */
+int bp_check_errors(bp_handle *h, int32_t *out_host);
+/* kernel timing helper for bench.py: average duration (ms) of the physics kernel over launches since the last call,
+ * measured with HIP events on the launch stream (synchronises). */
+int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32_t *launches);
+int bp_enable_timing(bp_handle *h, int32_t on);
+
+const char *bp_last_error(const bp_handle *h);
+int32_t bp_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
