@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/sec of batched ship-ice-v0 env.step() on MI355X (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one batched env.step() over all envs of a rank: 400 physics sub-steps + work/reward + the 4x150x150 u8
+observation raster, followed by the auto-reset (new trial + 1000 settle sub-steps) of the envs that terminated --
+everything an RL collector needs per step.  Inputs (scenarios, actions) are resident in HBM before the timed region.
+Multi-GPU: environments shard over ranks (4096 per GPU, weak scaling, no data-path collective); the only collective
+is the all-gather of per-rank episode counters after the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes_per_env_step(nb, nf, maxv=20, obs_bytes=4 * 150 * 150):
+    """SURVEY.md section 8(d) accounting, restated for the binary64 state this build keeps.
+
+    A_min   : state resident on-chip for the 400 sub-steps (what this design does):
+              body state read+write 2*nb*9*8 B + geometry read nf*(2*V+3)*8 B + observation write + scalars.
+    A_stream: body state streamed from HBM every sub-step: 400*nb*9*8*2 B + contact cache + A_min's geometry/obs terms.
+    """
+    state = 2 * nb * 9 * 8
+    geom = nf * (2 * maxv + 3) * 8
+    scal = 256
+    a_min = state + geom + obs_bytes + scal
+    a_stream = 400 * nb * 9 * 8 * 2 + 400 * 64 * 64 + geom + obs_bytes + scal
+    return a_min, a_stream, state + geom + scal
+
+
+def cpu_baseline(env, trials, seconds_hint=15.0):
+    """Oracle (CPU restatement) timed on the host cores of this box on a bounded sample of the same workload."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle.oracle import OracleShipIce
+
+    cores = os.cpu_count() or 1
+    per_thread_envs, steps = 1, 12
+    cfg = env.cfg
+
+    def work(tid):
+        rng = np.random.default_rng(1000 + tid)
+        n = 0
+        for k in range(per_thread_envs):
+            o = OracleShipIce(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+            o.reset(trials[(tid * per_thread_envs + k) % len(trials)])
+            for _ in range(steps):
+                _, _, term, _ = o.step(float(np.float32(rng.uniform(-1, 1))))
+                n += 1
+                if term:
+                    o.reset(trials[(tid + n) % len(trials)])
+        return n
+
+    # one untimed call so the library is built/loaded
+    OracleShipIce(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+    t0 = time.time()
+    with ThreadPoolExecutor(cores) as ex:
+        total = sum(ex.map(work, range(cores)))
+    dt = time.time() - t0
+    return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d threads x %d env x %d env.step() (+reset incl. 1000 settle sub-steps) of the same 30%% "
+                      "ship-ice trials, oracle/bp_oracle.c, %.1f s wall" % (cores, per_thread_envs, steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--concentration", type=float, default=0.3)
+    ap.add_argument("--trials", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-auto-reset", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world != 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    from benchpush_amd.parallel import allgather_episode_metrics
+
+    E = args.envs_per_gpu
+    trials = default_trials(args.concentration, args.trials, base_seed=0)
+    env = BatchedShipIceEnv(E, cfg={"concentration": args.concentration}, trials=trials, device=device,
+                            env_id_offset=rank * E)
+    nf_mean = float(np.mean([len(t["obstacles"]) for t in trials]))
+    K, W = args.steps, args.warmup
+    # actions ~ U(-1,1), counter-style: a generator keyed by (seed, rank); resident in HBM before timing
+    g = torch.Generator(device=device)
+    g.manual_seed(1234 + rank)
+    actions = (torch.rand((K + W, E), generator=g, device=device, dtype=torch.float64) * 2 - 1).float().double()
+
+    env.reset()
+    ep_done = torch.zeros(E, dtype=torch.int64, device=device)
+    ep_success = torch.zeros(E, dtype=torch.int64, device=device)
+
+    def one_step(t):
+        obs, rew, term, trunc, info = env.step(actions[t])
+        if not args.no_auto_reset:
+            ep_done.add_(term.to(torch.int64))
+            ep_success.add_(info[:, 8].to(torch.int64))
+            env.reset(term)
+
+    for t in range(W):
+        one_step(t)
+    torch.cuda.synchronize()
+    env.enable_timing(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(W, W + K):
+        one_step(t)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    phys_ms, rast_ms, nlaunch = env.kernel_time_ms()
+    env.enable_timing(False)
+    env.check_errors()
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    tmax = float(tmax.item())
+    # episode metrics cross GPUs once, after the timed region (RCCL all-gather over xGMI)
+    local = torch.stack([ep_done.sum(), ep_success.sum()]).to(torch.float64).reshape(1, 2)
+    allm = allgather_episode_metrics(local, dist)
+    total_envs = E * world
+    value = total_envs * K / tmax
+
+    if rank == 0:
+        nb = int(round(nf_mean)) + 1
+        a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1)
+        roof = {
+            "bound": "hbm",
+            "kernel": "k_physics",
+            "achieved": a_phys * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
+            "achieved_stream": (a_stream - 4 * 150 * 150) * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
+            "raster_kernel": {"kernel": "k_observe", "achieved": 4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 if rast_ms > 0 else None,
+                              "ms": rast_ms},
+            "physics_ms": phys_ms, "launches": nlaunch,
+            "bytes_per_env_step": {"A_min": a_min, "A_stream": a_stream, "k_physics_min": a_phys},
+            "note": "k_physics keeps state on-chip for 400 sub-steps; it is latency/VALU-bound, not HBM-bound (DESIGN.md)",
+        }
+        roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                roof["traffic"] = json.load(open(tpath)).get("k_physics_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        out = {
+            "metric": "env-steps/sec at N=4096 envs (ship-ice-v0), 1/2/4/8 MI355X",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "ship-ice-v0, %d envs per GPU, %.0f%% concentration (mean %.1f floes), 400 sub-steps x 10 "
+                                   "solver iterations per env.step, 4x150x150 u8 obs, auto-reset" % (E, args.concentration * 100, nf_mean),
+                       "envs_per_gpu": E, "total_envs": total_envs, "concentration": args.concentration,
+                       "substeps_per_step": env.params["steps"], "auto_reset": not args.no_auto_reset,
+                       "episodes_finished": int(allm[:, 0].sum().item()), "episodes_success": int(allm[:, 1].sum().item())},
+            "substeps_per_s": value * env.params["steps"],
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env, trials)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -15,7 +15,7 @@ INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scale
              "n_contact_pts", "n_first_contact"]
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_reset", "bp_step", "bp_step_physics",
-           "bp_observe", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
+           "bp_observe", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_last_error"]
 
 
@@ -47,9 +47,15 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise BpError("libbenchpush_hip.so not found at %s -- build it with `python -m benchpush_amd.build` "
                       "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
-    L = C.CDLL(LIB_PATH)
+    path = LIB_PATH
+    if os.environ.get("BP_PROF") == "1":  # diagnostic build with in-kernel phase timers (tools/prof_phases.py)
+        path = LIB_PATH.replace(".so", "_prof.so")
+    L = C.CDLL(path)
     vp = C.c_void_p
     L.bp_abi_version.restype = C.c_int32
+    L.bp_sizeof_config.restype = C.c_int32
+    if L.bp_sizeof_config() != C.sizeof(BpConfig):
+        raise BpError("bp_config layout mismatch between _lib.BpConfig and the library")
     L.bp_create.argtypes = [C.POINTER(BpConfig), C.c_int32, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.bp_destroy.argtypes = [vp]
     L.bp_load_scenarios.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
@@ -70,6 +76,7 @@ def load():
     L.bp_last_error.argtypes = [vp]
     L.bp_last_error.restype = C.c_char_p
     L.bp_debug_trace.argtypes = [vp, vp, C.c_int32]
+    L.bp_debug_prof.argtypes = [vp, vp]
     _lib = L
     return L
 

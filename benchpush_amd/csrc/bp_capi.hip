@@ -65,6 +65,7 @@ static size_t lds_bytes_for(int nbcap)
 extern "C" {
 
 int32_t bp_abi_version(void) { return BP_ABI_VERSION; }
+int32_t bp_sizeof_config(void) { return (int32_t)sizeof(bp_config); }
 
 const char *bp_last_error(const bp_handle *h) { return h ? h->err.c_str() : "null handle"; }
 
@@ -231,7 +232,7 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     if ((rc = dalloc(h, &D.a_h0, E * BP_ACAP))) return rc;
     if ((rc = dalloc(h, &D.a_h1, E * BP_ACAP))) return rc;
     if ((rc = dalloc(h, &D.a_d, E * BP_ACAP * 14))) return rc;
-    D.dbg = nullptr; D.dbg_env = -1;
+    D.dbg = nullptr; D.dbg_env = -1; D.prof = nullptr;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     h->loaded = true;
@@ -443,6 +444,14 @@ int bp_debug_trace(bp_handle *h, double *dev_buf, int32_t env)
     if (!h) return BP_EINVAL;
     h->D.dbg = dev_buf;
     h->D.dbg_env = env;
+    return BP_OK;
+}
+
+// diagnostic builds (-DBP_PROF): per-env phase cycle counters, device buffer [E][24] u64 or NULL
+int bp_debug_prof(bp_handle *h, unsigned long long *dev_buf)
+{
+    if (!h) return BP_EINVAL;
+    h->D.prof = dev_buf;
     return BP_OK;
 }
 

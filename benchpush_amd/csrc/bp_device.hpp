@@ -57,6 +57,7 @@ struct DevPtrs {
     // debug
     double *dbg;             // optional [substeps][nbcap][3] pose trace of env dbg_env
     int dbg_env;
+    unsigned long long *prof; // optional [E][24] phase cycle counters (BP_PROF builds)
 };
 
 __device__ __forceinline__ d2 mk2(double x, double y) { d2 r; r.x = x; r.y = y; return r; }

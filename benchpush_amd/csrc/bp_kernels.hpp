@@ -84,6 +84,10 @@ __global__ __launch_bounds__(64) void k_physics(const DevParams P, const DevPtrs
 
     ArbReg A;
     SubState S;
+#ifdef BP_PROF
+    for (int q = 0; q < 24; q++) S.prof[q] = 0;
+    const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
+#endif
     S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
     A.level = 0; A.rank = 0;
     A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
@@ -269,6 +273,12 @@ __global__ __launch_bounds__(64) void k_physics(const DevParams P, const DevPtrs
         ad[6] = A.r1_0.x; ad[7] = A.r1_0.y; ad[8] = A.r2_0.x; ad[9] = A.r2_0.y;
         ad[10] = A.r1_1.x; ad[11] = A.r1_1.y; ad[12] = A.r2_1.x; ad[13] = A.r2_1.y;
     }
+#ifdef BP_PROF
+    if (D.prof != nullptr && lane == 0) {
+        S.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
+        for (int q = 0; q < 24; q++) D.prof[(size_t)env * 24 + q] = S.prof[q];
+    }
+#endif
     const int err_any = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |
                         (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
                         (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);

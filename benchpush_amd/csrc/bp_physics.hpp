@@ -15,6 +15,17 @@
 #pragma once
 #include "bp_device.hpp"
 
+// Optional in-kernel phase timers (diagnostic build only: -DBP_PROF).  Stamps go to D.prof, which nothing else reads.
+#ifdef BP_PROF
+#define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
+#define PROF_ACC(slot) { unsigned long long _n = __builtin_amdgcn_s_memtime(); S.prof[slot] += _n - _pt; _pt = _n; }
+#define PROF_CNT(slot, v) { S.prof[slot] += (unsigned long long)(v); }
+#else
+#define PROF_DECL
+#define PROF_ACC(slot)
+#define PROF_CNT(slot, v)
+#endif
+
 struct ArbReg {
     unsigned key, stamp, h0, h1;
     int state, count, level, rank;
@@ -58,6 +69,9 @@ struct SubState {
     unsigned n_post, n_contact, n_first;
     int err;
     int yaw_violated, boundary_violated;
+#ifdef BP_PROF
+    unsigned long long prof[24];
+#endif
 };
 
 struct Manifold { int count; d2 n; d2 p1_0, p2_0, p1_1, p2_1; unsigned h0, h1; int newhint; };
@@ -92,8 +106,9 @@ __device__ __forceinline__ Manifold full_pair(const DevParams &P, const EnvCtx &
     const d2 fn = Pn[fc], fp = Pv[fc];
     double mn = BP_INF;
     int jm = 0;
-    for (int j = 0; j < nQ; j++) {
-        const double d = vdot(fn, Qv[j]);
+#pragma unroll
+    for (int j = 0; j < BP_MAXV; j++) { // fixed trip count: slots >= nQ repeat vertex 0, which cannot win the strict '<'
+        const double d = vdot(fn, Qv[j < nQ ? j : 0]);
         if (d < mn) { mn = d; jm = j; }
     }
     double s = fvalid ? (mn - vdot(fn, fp)) : -BP_INF;
@@ -295,6 +310,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     const double prev_dt = S.curr_dt;
     S.curr_dt = dt;
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) A.state = ARB_NORMAL;
+    PROF_DECL
+    PROF_CNT(16, S.nmv)
 
     // ---- 1. integrate positions of the moving bodies; world geometry; AABBs ----------------------------------
     unsigned long long refresh_any = 0;
@@ -339,6 +356,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             }
         }
         __syncthreads();
+        PROF_ACC(0)
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
         unsigned long long rm = ballot((lane < cnt) && L.rf[lane < cnt ? lane : 0]);
         refresh_any |= rm;
@@ -346,7 +364,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             const int kk = __ffsll((long long)rm) - 1;
             rm &= rm - 1;
             refresh_body(P, E, L.mv[k0 + kk], S.err);
+            PROF_CNT(17, 1)
         }
+        PROF_ACC(1)
     }
     __syncthreads();
 
@@ -377,8 +397,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                 const d2 fn = E.wn[pb * BP_MAXV + fi], fp = E.wv[pb * BP_MAXV + fi];
                 const int nq = E.nv[qb];
                 double mn = BP_INF;
-                for (int q = 0; q < nq; q++) {
-                    const double d = vdot(fn, E.wv[qb * BP_MAXV + q]);
+#pragma unroll
+                for (int q = 0; q < BP_MAXV; q++) { // all loads in flight at once; slots >= nq repeat vertex 0
+                    const double d = vdot(fn, E.wv[qb * BP_MAXV + (q < nq ? q : 0)]);
                     if (d < mn) mn = d;
                 }
                 const double sep = mn - vdot(fn, fp);
@@ -386,11 +407,14 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             }
         }
         unsigned long long cm = ballot(valid);
+        PROF_ACC(2)
+        PROF_CNT(18, __popcll(cm))
         while (cm) {
             const int l = __ffsll((long long)cm) - 1;
             cm &= cm - 1;
             const int usa = __shfl(sa, l), usb = __shfl(sb, l);
             const Manifold M = full_pair(P, E, L, usa, usb);
+            PROF_ACC(3)
             if (lane == l) E.hint[i * BP_KADJ + s] = (unsigned char)M.newhint;
             if (M.count > 0) {
                 // cpArbiterUpdate on the slot that owns this pair
@@ -426,6 +450,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             }
         }
     }
+    PROF_ACC(4)
     // arbiters whose bodies did not move keep last sub-step's contacts
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
         const int a = (int)(A.key >> 16), b = (int)(A.key & 0xFFFFu);
@@ -475,6 +500,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         __syncthreads();
     }
 
+    PROF_ACC(5)
+    PROF_CNT(19, __popcll(amask))
+    PROF_CNT(20, S.nlevels)
     // ---- 6a. prestep (cpArbiterPreStep) -----------------------------------------------------------------------
     if (active) {
         const d2 pa = E.pxy[ba], pb = E.pxy[bbi];
@@ -518,6 +546,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         }
     }
     __syncthreads();
+    PROF_ACC(6)
     // ---- 6c. warm start (cpArbiterApplyCachedImpulse) -----------------------------------------------------------
     const double dt_coef = (prev_dt == 0.0) ? 0.0 : dt / prev_dt;
     for (int lvl = 1; lvl <= S.nlevels; lvl++) {
@@ -537,6 +566,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         }
         __syncthreads();
     }
+    PROF_ACC(7)
     // ---- 6d. sequential impulses (cpArbiterApplyImpulse) ------------------------------------------------------
     for (int it = 0; it < P.iterations; it++) {
         for (int lvl = 1; lvl <= S.nlevels; lvl++) {
@@ -587,6 +617,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             __syncthreads();
         }
     }
+    PROF_ACC(8)
     // ---- 7. post-solve bookkeeping for ship(0) x floe arbiters, ascending key order ------------------------------
     {
         const bool shiparb = active && ba == 0;
@@ -656,6 +687,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         S.nmv = shipmv + nA_ + __popcll(mB);
     }
     __syncthreads();
+    PROF_ACC(9)
     (void)refresh_any;
     (void)D;
 }

@@ -1,0 +1,2 @@
+from .base_metric import BaseMetric  # noqa: F401
+from .ship_ice_metric import BatchedShipIceMetric, ShipIceMetric  # noqa: F401

@@ -136,6 +136,7 @@ int bp_enable_timing(bp_handle *h, int32_t on);
 
 const char *bp_last_error(const bp_handle *h);
 int32_t bp_abi_version(void);
+int32_t bp_sizeof_config(void);   /* sizeof(bp_config), so a binding can verify its struct layout */
 
 #ifdef __cplusplus
 }

@@ -1205,3 +1205,39 @@ void orc_observe(orc_env *E, uint8_t *obs)
         }
     free(occ); free(foot); free(orient);
 }
+
+/* ---- test hooks for the numpy-only golden vectors (tests/golden/) ------------------------------------- */
+/* total_work_done (evaluation/metrics.py:96-113) on explicit polygon lists; verts concatenated [sum(counts)][2] */
+double orc_total_work(int npoly, const int *counts, const double *a, const double *b)
+{
+    double work = 0.0;
+    int off = 0;
+    for (int p = 0; p < npoly; p++) {
+        int n = counts[p];
+        double area = poly_area_np(n, a + 2 * off);
+        double ax, ay, bx, by;
+        poly_centroid_np(n, a + 2 * off, &ax, &ay);
+        poly_centroid_np(n, b + 2 * off, &bx, &by);
+        work += sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) * area;
+        off += n;
+    }
+    return work;
+}
+/* ego crop of an injected global map gmap[Hg][Wg] (occupancy_map.py:112-140 index arithmetic), oob_val outside */
+void orc_crop(const orc_params *P, const double *state, const double *gmap, double oob_val, uint8_t *out)
+{
+    double grid = 1.0 / P->m_to_pix;
+    int Wg = (int)(P->map_w / grid), Hg = (int)(P->map_h / grid);
+    int LH = (int)(P->local_h * P->m_to_pix), LW = (int)(P->local_w * P->m_to_pix);
+    double m2gx = (double)Wg / P->map_w, m2gy = (double)Hg / P->map_h;
+    int wx = (int)(state[0] * m2gx);
+    int wy = (int)((state[1] + P->vshift) * m2gy);
+    for (int li = 0; li < LH; li++)
+        for (int lj = 0; lj < LW; lj++) {
+            int gi = (int)((double)(li + wy) - ((double)LH / 2));
+            int gj = (int)((double)(lj + wx) - ((double)LW / 2));
+            double v = oob_val;
+            if (!(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg)) v = gmap[(size_t)gi * Wg + gj];
+            out[(size_t)li * LW + lj] = (uint8_t)(v * 255);
+        }
+}

@@ -66,6 +66,9 @@ def lib():
         L.orc_collide.restype = C.c_int
         L.orc_collide.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_double, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_total_work.restype = C.c_double
+        L.orc_total_work.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_crop.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
         _lib = L
     return _lib
 
@@ -191,3 +194,21 @@ def collide(a, ra, b, rb):
     h = np.zeros(2, np.uint32)
     c = lib().orc_collide(len(a), _p(a), ra, len(b), _p(b), rb, _p(n), _p(p1), _p(p2), _p(h))
     return c, n, p1[:c], p2[:c], h[:c]
+
+
+def total_work(polys_a, polys_b):
+    counts = np.array([len(p) for p in polys_a], np.int32)
+    a = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64) for p in polys_a]))
+    b = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64) for p in polys_b]))
+    return lib().orc_total_work(len(counts), _p(counts), _p(a), _p(b))
+
+
+def crop(params, state, gmap, oob_val=0.0):
+    p = OrcParams()
+    for k, v in params.items():
+        setattr(p, k, v)
+    st = np.ascontiguousarray(state, np.float64)
+    g = np.ascontiguousarray(gmap, np.float64)
+    out = np.zeros((int(params["local_h"] * params["m_to_pix"]), int(params["local_w"] * params["m_to_pix"])), np.uint8)
+    lib().orc_crop(C.byref(p), _p(st), _p(g), float(oob_val), _p(out))
+    return out

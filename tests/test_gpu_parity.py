@@ -1,0 +1,207 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same seeded inputs.
+
+Bar: bit-exact.  Physics state is binary64 on both sides with the same operation order, so body state, rewards and
+info scalars are compared with ==, contact counters and termination flags exactly, observations byte for byte.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(E, conc, trials, **kw):
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
+    return BatchedShipIceEnv(E, cfg=dict({"concentration": conc}, **kw), trials=trials, device="cuda:0")
+
+
+def _oracles(env, n):
+    from oracle.oracle import OracleShipIce
+    c = env.cfg
+    return [OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail) for _ in range(n)]
+
+
+def _run_parity(E, conc, T, steps, seed, action_fn=None, **cfgkw):
+    from benchpush_amd.envs.ship_ice import default_trials
+    trials = default_trials(conc, T, base_seed=seed)
+    env = _mk(E, conc, trials, **cfgkw)
+    obs, info = env.reset()
+    orcs = _oracles(env, E)
+    eps = [0] * E
+    for e, o in enumerate(orcs):
+        oo, _ = o.reset(trials[e % T])
+        assert np.array_equal(obs[e].cpu().numpy(), oo), ("reset obs", e)
+    rng = np.random.default_rng(seed)
+    ncontact = 0
+    for t in range(steps):
+        a = rng.uniform(-1, 1, E) if action_fn is None else np.array([action_fn(e, t) for e in range(E)], np.float64)
+        a = a.astype(np.float32).astype(np.float64)
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a))
+        bs = env.body_state().cpu().numpy()
+        nb = env.num_bodies()
+        go, gi, gr, gt = obs.cpu().numpy(), info.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy()
+        assert not trunc.any()
+        for e, o in enumerate(orcs):
+            oo, orr, ot, oi = o.step(float(a[e]))
+            ob = o.bodies()
+            assert nb[e] == len(ob)
+            assert np.array_equal(bs[e, : nb[e]], ob), ("bodies", t, e)
+            assert np.array_equal(go[e], oo), ("obs", t, e)
+            assert np.array_equal(gi[e], np.array(list(oi.values()))), ("info", t, e)
+            assert gr[e] == orr and bool(gt[e]) == ot, ("reward/term", t, e)
+            ncontact = max(ncontact, int(oi["n_contact_pts"]))
+        done = gt.astype(bool)
+        if done.any():
+            obs, info = env.reset(term)
+            for e in np.nonzero(done)[0]:
+                eps[e] += 1
+                oo, _ = orcs[e].reset(trials[(e + eps[e]) % T])
+                assert np.array_equal(obs[e].cpu().numpy(), oo), ("auto-reset obs", t, e)
+    env.check_errors()
+    return ncontact
+
+
+def test_parity_30pct_with_contacts_and_autoreset():
+    assert _run_parity(E=8, conc=0.3, T=3, steps=40, seed=0) > 1000
+
+
+def test_parity_50pct_dense_field():
+    assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
+
+
+def test_parity_10pct_plumbing_config():
+    # BASELINE.json configs[0]: 1 env, 10 % concentration, action 0
+    _run_parity(E=1, conc=0.1, T=1, steps=12, seed=3, action_fn=lambda e, t: 0.0)
+
+
+def test_parity_boundary_and_yaw_edges():
+    # hard-over rudder: reaches the yaw limit, then the channel boundary (-50, termination without success)
+    _run_parity(E=2, conc=0.1, T=2, steps=30, seed=5, action_fn=lambda e, t: 1.0 if e == 0 else -1.0)
+
+
+def test_parity_goal_variant():
+    _run_parity(E=2, conc=0.2, T=2, steps=8, seed=8, goal_y=19)
+
+
+def test_world_polys_and_low_dim_match_oracle():
+    from benchpush_amd.envs.ship_ice import default_trials
+    trials = default_trials(0.2, 1, base_seed=4)
+    env = _mk(1, 0.2, trials)
+    env.reset()
+    o = _oracles(env, 1)[0]
+    o.reset(trials[0])
+    for t in range(12):
+        env.step(torch.tensor([0.2]))
+        o.step(float(np.float32(0.2)))
+    v, c = env.world_polys()
+    ov, oc = o.world_polys()
+    nb = len(oc)
+    assert np.array_equal(c[0, :nb].cpu().numpy(), oc)
+    assert np.array_equal(v[0, :nb].cpu().numpy(), ov[:, :20])
+    from oracle.oracle import poly_centroid
+    ld = env.low_dim_obs()[0, : nb - 1].cpu().numpy()
+    for i in range(1, nb):
+        assert np.array_equal(ld[i - 1], np.abs(poly_centroid(ov[i, : oc[i]])))
+
+
+def test_sharding_invariance_and_determinism():
+    """Results depend on the global env id only: one handle of 8 envs == two handles of 4 with env_id_offset 0 / 4."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    trials = default_trials(0.3, 5, base_seed=2)
+    acts = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (10, 8)).astype(np.float32).astype(np.float64))
+
+    def run(E, off):
+        env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, device="cuda:0", env_id_offset=off)
+        env.reset()
+        out = []
+        for t in range(10):
+            obs, rew, term, _, info = env.step(acts[t, off:off + E])
+            out.append((obs.cpu().numpy().copy(), rew.cpu().numpy().copy(), info.cpu().numpy().copy()))
+            env.reset(term)
+        return out
+
+    full, lo, hi, again = run(8, 0), run(4, 0), run(4, 4), run(8, 0)
+    for t in range(10):
+        for k in range(3):
+            assert np.array_equal(full[t][k], np.concatenate([lo[t][k], hi[t][k]]))
+            assert np.array_equal(full[t][k], again[t][k])
+
+
+def test_full_size_properties_4096_envs():
+    """BASELINE.json configs[1] size: properties that need no oracle run."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    trials = default_trials(0.3, 16, base_seed=0)
+    E = 4096
+    env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+    obs, info = env.reset()
+    x0 = info[:, 0].clone()
+    # envs that share a trial and an action sequence must stay bit-identical (trial = global id % 16)
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(0)
+    base = (torch.rand((6, 16), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
+    prev_tw = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+    for t in range(6):
+        a = base[t].repeat(E // 16)
+        obs, rew, term, trunc, info = env.step(a)
+        assert torch.equal(obs.view(E // 16, 16, -1), obs.view(E // 16, 16, -1)[0:1].expand(E // 16, -1, -1))
+        assert torch.equal(rew.view(-1, 16), rew.view(-1, 16)[0:1].expand(E // 16, -1))
+        assert (info[:, 4] >= 0).all() and (info[:, 3] >= prev_tw).all()           # work >= 0, total_work monotone
+        prev_tw = info[:, 3].clone()
+        assert torch.allclose(info[:, 1], torch.full_like(info[:, 1], 1.0) + 0.24 * (t + 1), atol=0.24 * (t + 1))
+        assert not trunc.any() and not term.any()
+        ch0 = obs[:, 0]
+        assert ((ch0 == 0) | (ch0 == 127) | (ch0 == 255)).all()                      # footprint channel values
+        assert ((obs[:, 3] == 0) | (obs[:, 3] == 255)).all()                         # occupancy is binary
+        assert ((obs[:, 2] == 0) | (obs[:, 2] == 127) | (obs[:, 2] == 255)).all()
+        assert (obs[:, 2] == 255).sum(dim=(1, 2)).eq(1).all()                        # exactly one head pixel
+    env.check_errors()
+    assert torch.isfinite(info).all()
+    assert x0.min() >= 1.0 and x0.max() <= 11.0
+
+
+def test_gym_adapter_surface_and_metric_plumbing():
+    import benchpush_amd
+    from benchpush_amd.envs.ship_ice import default_trials
+    from benchpush_amd.metrics import ShipIceMetric
+    trials = default_trials(0.1, 2, base_seed=1)
+    env = benchpush_amd.make("ship-ice-v0", cfg={"concentration": 0.1}, trials=trials)
+    u = env.unwrapped
+    assert u.observation_space.shape == (4, 150, 150) and u.action_space.shape == ()
+    assert u.goal == (0, 9) and abs(u.max_yaw_rate_step - (math.pi / 2) / 7) < 1e-15 and u.cfg.ship.mass == 1
+    metric = ShipIceMetric("test", ship_mass=u.cfg.ship.mass, goal=u.goal)
+    obs, info = u.reset()
+    assert obs.dtype == np.uint8 and obs.shape == (4, 150, 150)
+    assert set(info) == {"state", "total_work", "obs"} and len(info["obs"]) == len(trials[0]["obstacles"])
+    metric.reset(info)
+    for t in range(40):
+        obs, r, done, trunc, info = u.step(np.float32(0.0))
+        assert set(info) == {"state", "total_work", "collision reward", "scaled collision reward", "dist reward",
+                             "trial_success", "obs"}
+        metric.update(info, r, done or trunc)
+        if done:
+            break
+    assert done and len(metric.efficiency_scores) == 1 and 0 < metric.effort_scores[0] <= 1
+    obs2, info2 = u.reset()   # second episode -> next trial
+    assert len(info2["obs"]) == len(trials[1]["obstacles"])
+    env.close()
+
+
+def test_cabi_call_order_errors():
+    from benchpush_amd import _lib
+    from benchpush_amd.config import default_cfg, ship_ice_physics_params
+    cfg = default_cfg("ship_ice")
+    L = _lib.load()
+    bc = _lib.make_config(ship_ice_physics_params(cfg), cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+    h = C.c_void_p()
+    assert L.bp_create(C.byref(bc), 2, 0, 0, C.byref(h)) == 0
+    a = torch.zeros(2, dtype=torch.float64, device="cuda:0")
+    assert L.bp_step(h, C.c_void_p(a.data_ptr()), None, None, None, None, None, None) == -5   # BP_ESTATE
+    assert L.bp_reset(h, None, None, None, None) == -5
+    assert b"bp_load_scenarios" in L.bp_last_error(h)
+    bad = _lib.make_config(dict(ship_ice_physics_params(cfg), damping_pow=0.5), cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+    h2 = C.c_void_p()
+    assert L.bp_create(C.byref(bad), 2, 0, 0, C.byref(h2)) == -1                              # BP_EINVAL
+    assert L.bp_destroy(h) == 0

@@ -1,0 +1,145 @@
+"""CPU-side tests of the product package: C ABI surface, host logic, sharding (gloo, world_size 2). No GPU compute."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    from benchpush_amd import _lib
+    from benchpush_amd.build import build_hip
+    build_hip()  # hipcc cross-compiles gfx950 without a GPU
+    L = _lib.load()
+    header = open(os.path.join(ROOT, "include", "benchpush_amd.h")).read()
+    declared = set(re.findall(r"\b(bp_[a-z_0-9]+)\s*\(", header))
+    assert {"bp_create", "bp_step", "bp_reset", "bp_load_scenarios", "bp_get_world_polys"} <= declared
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.bp_abi_version() == 1
+    assert set(_lib.EXPORTS) <= declared | {"bp_debug_trace"}
+
+
+def test_cabi_fails_loudly_without_gpu(ship_cfg):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from benchpush_amd import _lib
+    cfg, P = ship_cfg
+    L = _lib.load()
+    bc = _lib.make_config(P, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+    h = C.c_void_p()
+    assert L.bp_create(C.byref(bc), 4, 0, 0, C.byref(h)) == -4  # BP_ENODEVICE: no CPU fallback
+    assert not h.value
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
+    with pytest.raises(_lib.BpError):
+        BatchedShipIceEnv(2)
+
+
+def test_config_struct_layout_matches_header():
+    from benchpush_amd import _lib
+    assert C.sizeof(_lib.BpConfig) == _lib.load().bp_sizeof_config()
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "benchpush_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for needle in ("import oracle", "from oracle", "bp_oracle", "orc_", "libbp_oracle"):
+                    assert needle not in txt, (f, needle)
+
+
+def test_pack_trials_and_generator_are_deterministic():
+    from benchpush_amd.scenario import generate_ice_field, pack_trials
+    a = generate_ice_field(0.3, 5, min_r=0.4, max_r=0.58)
+    b = generate_ice_field(0.3, 5, min_r=0.4, max_r=0.58)
+    assert len(a["obstacles"]) == len(b["obstacles"]) > 200
+    assert all(np.array_equal(x["vertices"], y["vertices"]) for x, y in zip(a["obstacles"], b["obstacles"]))
+    conc = sum(o["area"] for o in a["obstacles"]) / (12 * 37)
+    assert abs(conc - 0.3) < 0.02
+    pk = pack_trials([a, b], max_verts=20)
+    assert pk["verts"].shape[0] == 2 and pk["counts"].max() <= 20 and pk["counts"].min() >= 0
+    assert pk["nfloes"].tolist() == [len(a["obstacles"])] * 2
+    v = np.array(a["obstacles"][3]["vertices"])
+    assert np.array_equal(pk["verts"][0, 3, : len(v)], v)
+    assert (pk["verts"][..., 0] >= 0).all() and (pk["verts"][..., 0] <= 12).all()
+
+
+def test_experiment_schema_round_trips_through_pickle(tmp_path):
+    import pickle
+    from benchpush_amd.scenario import generate_experiment, load_experiment
+    exp = generate_experiment(0.1, 2, base_seed=1, min_r=0.4, max_r=0.58)
+    p = tmp_path / "experiments_10_2.pk"
+    with open(p, "wb") as f:
+        pickle.dump(exp, f)
+    trials = load_experiment(str(p), 0.1)
+    assert set(trials[0].keys()) == {"goal", "ship_state", "obstacles"}  # consumer: ship_ice_env.py:188-198
+    assert set(trials[0]["obstacles"][0].keys()) >= {"vertices", "centre", "radius"}
+
+
+def test_gym_shim_registry_and_timelimit():
+    from benchpush_amd import gym_shim
+    if gym_shim.HAVE_GYMNASIUM:
+        pytest.skip("real gymnasium present")
+
+    class Dummy(gym_shim.Env):
+        action_space = gym_shim.spaces.Box(low=-1, high=1, dtype=np.float32)
+        observation_space = gym_shim.spaces.Box(low=0, high=255, shape=(4, 150, 150), dtype=np.uint8)
+
+        def __init__(self, cfg=None):
+            self.cfg = cfg
+
+        def reset(self, seed=None, options=None):
+            return 0, {}
+
+        def step(self, a):
+            return 0, 0.0, False, False, {}
+
+    gym_shim.register(id="dummy-v0", entry_point=Dummy, max_episode_steps=3)
+    env = gym_shim.make("dummy-v0", cfg={"x": 1})
+    assert env.unwrapped.cfg == {"x": 1} and isinstance(env.unwrapped, Dummy)
+    env.reset()
+    assert [env.step(0)[3] for _ in range(3)] == [False, False, True]  # TimeLimit truncation, as ids registered with 300
+    assert env.action_space.shape == () and env.observation_space.shape == (4, 150, 150)
+    import benchpush_amd  # noqa: F401
+    assert "ship-ice-v0" in gym_shim._REGISTRY and gym_shim._REGISTRY["ship-ice-v0"][1] == 300
+
+
+def test_shard_range_partitions_exactly():
+    from benchpush_amd.parallel import shard_range
+    for total, world in [(4096, 8), (4097, 8), (10, 3), (32768, 8)]:
+        r = [shard_range(total, k, world) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == total and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+
+
+_GLOO_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from benchpush_amd.parallel import allgather_episode_metrics, shard_range
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%%s" %% os.environ["BP_PORT"], rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+lo, hi = shard_range(10, rank, 2)
+local = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1) * torch.tensor([[1.0, 10.0, 100.0]], dtype=torch.float64)
+out = allgather_episode_metrics(local, dist)
+exp = torch.arange(0, 10, dtype=torch.float64).reshape(-1, 1) * torch.tensor([[1.0, 10.0, 100.0]], dtype=torch.float64)
+assert torch.equal(out, exp), (rank, out)
+dist.barrier(); dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_episode_metric_allgather_world_size_2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER % ROOT)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(os.environ, RANK=str(r), BP_PORT=port, MASTER_ADDR="127.0.0.1"),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=180)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)

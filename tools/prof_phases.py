@@ -1,0 +1,34 @@
+"""Phase breakdown of k_physics from the BP_PROF diagnostic build: BP_PROF=1 python tools/prof_phases.py [E] [steps]"""
+import os
+import sys
+
+os.environ["BP_PROF"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+
+E = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 14
+trials = default_trials(0.3, 100, base_seed=0)
+env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
+env.reset()
+prof = torch.zeros((E, 24), dtype=torch.int64, device=env.device)
+env.L.bp_debug_prof(env.h, prof.data_ptr())
+g = torch.Generator(device=env.device); g.manual_seed(1234)
+names = ["integrate", "refresh", "cand+hint", "full_pair", "arb_update", "filter+levels", "prestep+velint", "warm", "solver", "post+mvlist"]
+for t in range(STEPS):
+    a = (torch.rand(E, generator=g, device=env.device, dtype=torch.float64) * 2 - 1).float().double()
+    _, _, term, _, _ = env.step(a)
+    torch.cuda.synchronize()
+    p = prof.cpu().numpy().astype(np.float64)
+    if t >= STEPS - 3:
+        tot = p[:, 23]
+        worst = int(np.argmax(tot))
+        print("step %d: kernel cycles(100MHz ticks?) mean %.0f max %.0f (env %d)" % (t, tot.mean(), tot.max(), worst))
+        for who, row in (("mean", p.mean(0)), ("worst", p[worst])):
+            print("  %s: " % who + " ".join("%s=%.1f%%" % (n, 100 * row[i] / row[23]) for i, n in enumerate(names)))
+            print("        per-substep: nmv=%.2f refresh=%.3f fullpairs=%.2f nact=%.2f levels=%.2f" % (
+                row[16] / 400, row[17] / 400, row[18] / 400, row[19] / 400, row[20] / 400))
+    env.reset(term)
