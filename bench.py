@@ -160,7 +160,7 @@ def main():
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1)
         roof = {
             "bound": "hbm",
-            "kernel": "k_physics",
+            "kernel": "k_physics_step",
             "achieved": a_phys * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "achieved_stream": (a_stream - 4 * 150 * 150) * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
@@ -174,7 +174,7 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                roof["traffic"] = json.load(open(tpath)).get("k_physics_hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(tpath)).get("k_physics_step_hbm_bytes_per_launch")
             except Exception:
                 pass
         out = {

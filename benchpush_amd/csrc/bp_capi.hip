@@ -234,7 +234,8 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     if ((rc = dalloc(h, &D.a_d, E * BP_ACAP * 14))) return rc;
     D.dbg = nullptr; D.dbg_env = -1; D.prof = nullptr;
     HIPCHK(h, hipDeviceSynchronize());
-    HIPCHK(h, hipFuncSetAttribute((const void *)k_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     h->loaded = true;
     return BP_OK;
 }
@@ -252,8 +253,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         HIPCHK(h, hipEventRecord(e0, st));
     }
     if (physics) {
-        hipLaunchKernelGGL(k_physics, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mode, actions, mask, reward, term,
-                           trunc, info);
+        if (mode == MODE_STEP)
+            hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else
+            hipLaunchKernelGGL(k_physics_reset, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mask, info);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));

@@ -119,24 +119,35 @@ __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __ballot(p); }
 __device__ __forceinline__ int popc_below(unsigned long long m, int lane) { return __popcll(m & ((1ull << lane) - 1ull)); }
 
-// Butterfly arg-max over groups of `width` lanes (32 or 64): largest value, ties -> lowest index; `aux` rides along.
-__device__ __forceinline__ void group_argmax_first(double &v, int &idx, int &aux, int width)
+// ---- cross-lane reductions on DPP (row = 16 lanes) ------------------------------------------------------------------
+// min / max are exact and order-independent, so any reduction tree gives bit-identical results.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v)
 {
-    for (int off = width >> 1; off >= 1; off >>= 1) {
-        double ov = __shfl_xor(v, off);
-        int oi = __shfl_xor(idx, off);
-        int oa = __shfl_xor(aux, off);
-        bool take = (ov > v) || (ov == v && oi < idx);
-        if (take) { v = ov; idx = oi; aux = oa; }
-    }
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double group_min(double v, int width)
+// all 32 lanes of each half-wave receive the max / min of their half
+__device__ __forceinline__ double half_max(double v)
 {
-    for (int off = width >> 1; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    v = fmax(v, dpp_mov_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_mov_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_mov_f64<0x141>(v));  // row_half_mirror
+    v = fmax(v, dpp_mov_f64<0x140>(v));  // row_mirror
+    v = fmax(v, __shfl_xor(v, 16));
     return v;
 }
-__device__ __forceinline__ double group_max(double v, int width)
+__device__ __forceinline__ double half_min(double v)
 {
-    for (int off = width >> 1; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    v = fmin(v, dpp_mov_f64<0xB1>(v));
+    v = fmin(v, dpp_mov_f64<0x4E>(v));
+    v = fmin(v, dpp_mov_f64<0x141>(v));
+    v = fmin(v, dpp_mov_f64<0x140>(v));
+    v = fmin(v, __shfl_xor(v, 16));
     return v;
 }
+// LDS-only ordering point for a single-wave workgroup: LDS operations of one wave execute in order, so only the
+// compiler must be kept from moving LDS accesses across it (plus a drain of LGKM so values are in registers).
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }

@@ -31,10 +31,11 @@ __device__ __forceinline__ d2 poly_centroid_seq(const d2 *v, int n)
     return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
 }
 
-__global__ __launch_bounds__(64) void k_physics(const DevParams P, const DevPtrs D, const int mode, const double *__restrict__ actions,
-                                                const unsigned char *__restrict__ mask, double *__restrict__ reward,
-                                                unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
-                                                double *__restrict__ info)
+template <int mode>
+__device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
+                                             const unsigned char *__restrict__ mask, double *__restrict__ reward,
+                                             unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
+                                             double *__restrict__ info)
 {
     const int env = blockIdx.x;
     const int lane = lane_id();
@@ -334,6 +335,20 @@ __global__ __launch_bounds__(64) void k_physics(const DevParams P, const DevPtrs
             }
         }
     }
+}
+
+// env.step(): 400 sub-steps + work / reward / termination
+__global__ __launch_bounds__(64) void k_physics_step(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                     double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                     unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    physics_body<MODE_STEP>(P, D, actions, nullptr, reward, terminated, truncated, info);
+}
+// reset() of the masked envs: new space from the next trial + 1000 settle sub-steps
+__global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                      double *__restrict__ info)
+{
+    physics_body<MODE_RESET>(P, D, nullptr, mask, nullptr, nullptr, nullptr, info);
 }
 
 // ------------------------------------------------------------------------------------------------------------

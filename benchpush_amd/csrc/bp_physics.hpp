@@ -106,17 +106,19 @@ __device__ __forceinline__ Manifold full_pair(const DevParams &P, const EnvCtx &
     const d2 fn = Pn[fc], fp = Pv[fc];
     double mn = BP_INF;
     int jm = 0;
-#pragma unroll
+#pragma unroll 5
     for (int j = 0; j < BP_MAXV; j++) { // fixed trip count: slots >= nQ repeat vertex 0, which cannot win the strict '<'
         const double d = vdot(fn, Qv[j < nQ ? j : 0]);
         if (d < mn) { mn = d; jm = j; }
     }
-    double s = fvalid ? (mn - vdot(fn, fp)) : -BP_INF;
-    int fi = fvalid ? f : 1000;
-    group_argmax_first(s, fi, jm, 32);
-    const double sA = __shfl(s, 0), sB = __shfl(s, 32);
-    const int iA = __shfl(fi, 0), iB = __shfl(fi, 32);
-    const int jA = __shfl(jm, 0), jB = __shfl(jm, 32);
+    const double s = fvalid ? (mn - vdot(fn, fp)) : -BP_INF;
+    // arg-max with lowest-index tie-break: exact max, then the first lane that holds it
+    const double smx = half_max(s);
+    const unsigned long long eqm = ballot(s == smx);
+    const int iA = __ffs((unsigned)(eqm & 0xFFFFFFFFull)) - 1, iB = __ffs((unsigned)(eqm >> 32)) - 1;
+    const double sA = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__double2hiint(smx), 0) << 32) | (unsigned)__builtin_amdgcn_readlane(__double2loint(smx), 0));
+    const double sB = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__double2hiint(smx), 32) << 32) | (unsigned)__builtin_amdgcn_readlane(__double2loint(smx), 32));
+    const int jA = __builtin_amdgcn_readlane(jm, iA), jB = __builtin_amdgcn_readlane(jm, 32 + iB);
 
     Manifold M;
     M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0);
@@ -167,11 +169,11 @@ __device__ __forceinline__ Manifold full_pair(const DevParams &P, const EnvCtx &
     // support vertices: lanes 0-31 -> A along n, lanes 32-63 -> B along -n
     const d2 nn = vneg(n);
     double sd = -BP_INF;
-    int si = 1000, dummy = 0;
-    if (isA) { if (f < nA) { sd = vdot(L.stAv[f], n); si = f; } }
-    else     { if (f < nB) { sd = vdot(L.stBv[f], nn); si = f; } }
-    group_argmax_first(sd, si, dummy, 32);
-    const int i1A = __shfl(si, 0), i1B = __shfl(si, 32);
+    if (isA) { if (f < nA) sd = vdot(L.stAv[f], n); }
+    else     { if (f < nB) sd = vdot(L.stBv[f], nn); }
+    const double sdm = half_max(sd);
+    const unsigned long long sdq = ballot(sd == sdm);
+    const int i1A = __ffs((unsigned)(sdq & 0xFFFFFFFFull)) - 1, i1B = __ffs((unsigned)(sdq >> 32)) - 1;
     // SupportEdgeForPoly
     d2 e1a, e1b, e2a, e2b;
     int e1ia, e1ib, e2ia, e2ib;
@@ -283,10 +285,10 @@ __device__ __forceinline__ void world_from_pose(const DevParams &P, const EnvCtx
         E.wv[i * BP_MAXV + q] = mk2(vx, vy);
         E.wn[i * BP_MAXV + q] = mk2(nx, ny);
     }
-    const double l = group_min(valid ? vx : BP_INF, 32);
-    const double r = group_max(valid ? vx : -BP_INF, 32);
-    const double bo = group_min(valid ? vy : BP_INF, 32);
-    const double tp = group_max(valid ? vy : -BP_INF, 32);
+    const double l = half_min(valid ? vx : BP_INF);
+    const double r = half_max(valid ? vx : -BP_INF);
+    const double bo = half_min(valid ? vy : BP_INF);
+    const double tp = half_max(valid ? vy : -BP_INF);
     outbb.x = l - P.poly_radius; outbb.y = bo - P.poly_radius; outbb.z = r + P.poly_radius; outbb.w = tp + P.poly_radius;
 }
 
@@ -372,10 +374,18 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
 
     // ---- 3./4. candidate pairs of moving bodies ----------------------------------------------------------------
     const double rsum = P.poly_radius + P.poly_radius;
-    const int ncand_slots = S.nmv * BP_KADJ;
+    int kmax = 0; // largest neighbour count among the moving bodies (wave-uniform, found with 5 ballots per chunk)
+    for (int k0 = 0; k0 < S.nmv; k0 += 64) {
+        const int k = k0 + lane;
+        const int cnt = (k < S.nmv) ? (int)E.adjn[L.mv[k]] : 0;
+        int m = 0;
+        for (int bit = 16; bit >= 1; bit >>= 1) { if (ballot(cnt >= (m | bit))) m |= bit; }
+        kmax = max(kmax, m);
+    }
+    const int ncand_slots = S.nmv * kmax;
     for (int base = 0; base < ncand_slots; base += 64) {
         const int idx = base + lane;
-        const int k = idx / BP_KADJ, s = idx - k * BP_KADJ;
+        const int k = idx / kmax, s = idx - k * kmax;
         bool valid = k < S.nmv;
         int i = 0, j = 0;
         if (valid) {
@@ -397,8 +407,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                 const d2 fn = E.wn[pb * BP_MAXV + fi], fp = E.wv[pb * BP_MAXV + fi];
                 const int nq = E.nv[qb];
                 double mn = BP_INF;
-#pragma unroll
-                for (int q = 0; q < BP_MAXV; q++) { // all loads in flight at once; slots >= nq repeat vertex 0
+#pragma unroll 5
+                for (int q = 0; q < BP_MAXV; q++) { // several loads in flight at once; slots >= nq repeat vertex 0
                     const double d = vdot(fn, E.wv[qb * BP_MAXV + (q < nq ? q : 0)]);
                     if (d < mn) mn = d;
                 }
@@ -466,40 +476,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     const unsigned long long amask = ballot(active);
     const int ba = (int)(A.key >> 16), bbi = (int)(A.key & 0xFFFFu);
 
-    // ---- solve order: rank by key, dependency levels ----------------------------------------------------------
-    if (amask != S.prev_amask) {
-        int rank = 0;
-        unsigned long long m = amask;
-        while (m) {
-            const int l = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const unsigned k = __shfl(A.key, l);
-            rank += (k < A.key) ? 1 : 0;
-        }
-        A.rank = rank;
-        if (active) { L.lastlvl[ba] = 0; L.lastlvl[bbi] = 0; }
-        __syncthreads();
-        const int nact = __popcll(amask);
-        int nlev = 0;
-        for (int r = 0; r < nact; r++) {
-            const unsigned long long rm = ballot(active && A.rank == r);
-            const int l = __ffsll((long long)rm) - 1;
-            const unsigned k = __shfl(A.key, l);
-            const double uma = __shfl(A.ma, l), umb = __shfl(A.mb, l);
-            const int a = (int)(k >> 16), b = (int)(k & 0xFFFFu);
-            const int la = (uma == 0.0) ? 0 : (int)L.lastlvl[a];
-            const int lb = (umb == 0.0) ? 0 : (int)L.lastlvl[b];
-            const int lvl = max(la, lb) + 1;
-            if (uma != 0.0) L.lastlvl[a] = (unsigned char)lvl;
-            if (umb != 0.0) L.lastlvl[b] = (unsigned char)lvl;
-            if (lane == l) A.level = lvl;
-            nlev = max(nlev, lvl);
-        }
-        S.nlevels = nlev;
-        S.prev_amask = amask;
-        __syncthreads();
-    }
-
     PROF_ACC(5)
     PROF_CNT(19, __popcll(amask))
     PROF_CNT(20, S.nlevels)
@@ -536,6 +512,65 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             A.bounce1 = vdot(vsub(v2, v1), n) * P.arb_e;
         }
     }
+    // ---- warm set: arbiters that can produce a non-zero impulse this sub-step ------------------------------------
+    // Seeds: a kinematic body that moves, a cached impulse, a bias or a bounce term; closed under "shares a dynamic
+    // body".  Every other arbiter provably keeps all its impulses at exactly 0 and is skipped.
+    bool warm = false;
+    if (active) {
+        warm = (A.jn0 != 0.0) || (A.jt0 != 0.0) || (A.bias0 != 0.0) || (A.bounce0 != 0.0);
+        if (A.count > 1) warm = warm || (A.jn1 != 0.0) || (A.jt1 != 0.0) || (A.bias1 != 0.0) || (A.bounce1 != 0.0);
+        if (A.ma == 0.0) { const d2 v = L.sv[ba]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[ba].x != 0.0); }
+        if (A.mb == 0.0) { const d2 v = L.sv[bbi]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[bbi].x != 0.0); }
+        if (A.ma != 0.0) L.owner[ba] = 0;
+        if (A.mb != 0.0) L.owner[bbi] = 0;
+    }
+    unsigned long long wmask = ballot(warm);
+    if (wmask != 0 && wmask != amask) {
+        lds_sync();
+        for (;;) {
+            if (warm) { if (A.ma != 0.0) L.owner[ba] = 1; if (A.mb != 0.0) L.owner[bbi] = 1; }
+            lds_sync();
+            if (active && !warm) warm = (A.ma != 0.0 && L.owner[ba] != 0) || (A.mb != 0.0 && L.owner[bbi] != 0);
+            const unsigned long long nm = ballot(warm);
+            if (nm == wmask) break;
+            wmask = nm;
+        }
+    }
+    const bool any_bias = ballot(warm && ((A.bias0 != 0.0) || (A.count > 1 && A.bias1 != 0.0))) != 0;
+    // ---- solve order over the warm set: rank by key, dependency levels (cached while the warm set is unchanged) ----
+    if (wmask != S.prev_amask) {
+        int rank = 0;
+        unsigned long long m = wmask;
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
+            rank += (k < A.key) ? 1 : 0;
+        }
+        A.rank = rank;
+        if (warm) { L.lastlvl[ba] = 0; L.lastlvl[bbi] = 0; }
+        lds_sync();
+        const int nact = __popcll(wmask);
+        int nlev = 0;
+        for (int r = 0; r < nact; r++) {
+            const unsigned long long rm = ballot(warm && A.rank == r);
+            const int l = __ffsll((long long)rm) - 1;
+            const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
+            const bool adyn = __builtin_amdgcn_readlane(__double2hiint(A.ma), l) != 0 || __builtin_amdgcn_readlane(__double2loint(A.ma), l) != 0;
+            const bool bdyn = __builtin_amdgcn_readlane(__double2hiint(A.mb), l) != 0 || __builtin_amdgcn_readlane(__double2loint(A.mb), l) != 0;
+            const int a = (int)(k >> 16), b = (int)(k & 0xFFFFu);
+            const int la = adyn ? (int)L.lastlvl[a] : 0;
+            const int lb = bdyn ? (int)L.lastlvl[b] : 0;
+            const int lvl = max(la, lb) + 1;
+            if (adyn) L.lastlvl[a] = (unsigned char)lvl;
+            if (bdyn) L.lastlvl[b] = (unsigned char)lvl;
+            if (lane == l) A.level = lvl;
+            nlev = max(nlev, lvl);
+        }
+        S.nlevels = nlev;
+        S.prev_amask = wmask;
+    }
+    PROF_CNT(21, __popcll(wmask))
     __syncthreads();
     // ---- 6b. velocity integrate: damping^dt == 0, no gravity/forces -> dynamic bodies' v, w := +0 ---------------
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {
@@ -549,8 +584,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     PROF_ACC(6)
     // ---- 6c. warm start (cpArbiterApplyCachedImpulse) -----------------------------------------------------------
     const double dt_coef = (prev_dt == 0.0) ? 0.0 : dt / prev_dt;
-    for (int lvl = 1; lvl <= S.nlevels; lvl++) {
-        if (active && A.level == lvl && A.state != ARB_FIRST) {
+    const int nlevels = wmask ? S.nlevels : 0;
+    for (int lvl = 1; lvl <= nlevels; lvl++) {
+        if (warm && A.level == lvl && A.state != ARB_FIRST) {
             d2 va = L.sv[ba], vb = L.sv[bbi];
             d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
             {
@@ -564,16 +600,18 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; }
             if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; }
         }
-        __syncthreads();
+        lds_sync();
     }
     PROF_ACC(7)
     // ---- 6d. sequential impulses (cpArbiterApplyImpulse) ------------------------------------------------------
     for (int it = 0; it < P.iterations; it++) {
-        for (int lvl = 1; lvl <= S.nlevels; lvl++) {
-            if (active && A.level == lvl) {
+        bool changed = false;
+        for (int lvl = 1; lvl <= nlevels; lvl++) {
+            if (warm && A.level == lvl) {
                 d2 va = L.sv[ba], vb = L.sv[bbi];
                 d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
-                d2 vba = L.sb[ba], vbb = L.sb[bbi];
+                d2 vba = mk2(0.0, 0.0), vbb = mk2(0.0, 0.0);
+                if (any_bias) { vba = L.sb[ba]; vbb = L.sb[bbi]; }
                 const d2 n = A.n;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -581,17 +619,20 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                         const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
                         const double nMass = c ? A.nMass1 : A.nMass0, tMass = c ? A.tMass1 : A.tMass0;
                         const double bias = c ? A.bias1 : A.bias0, bounce = c ? A.bounce1 : A.bounce0;
-                        const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
-                        const d2 vb2 = vadd(vbb, vmul(vperp(r2), wb2.y));
                         const d2 v1 = vadd(va, vmul(vperp(r1), wa2.x));
                         const d2 v2 = vadd(vb, vmul(vperp(r2), wb2.x));
                         const d2 vr = vsub(v2, v1);
-                        const double vbn = vdot(vsub(vb2, vb1), n);
                         const double vrn = vdot(vr, n);
                         const double vrt = vdot(vr, vperp(n));
-                        const double jbn = (bias - vbn) * nMass;
                         const double jbnOld = c ? A.jBias1 : A.jBias0;
-                        const double jBias = fmax(jbnOld + jbn, 0.0);
+                        double jBias = jbnOld;
+                        if (any_bias) { // with no bias term anywhere every bias impulse stays exactly 0
+                            const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
+                            const d2 vb2 = vadd(vbb, vmul(vperp(r2), wb2.y));
+                            const double vbn = vdot(vsub(vb2, vb1), n);
+                            const double jbn = (bias - vbn) * nMass;
+                            jBias = fmax(jbnOld + jbn, 0.0);
+                        }
                         const double jn = -(bounce + vrn) * nMass;
                         const double jnOld = c ? A.jn1 : A.jn0;
                         const double jnAcc = fmax(jnOld + jn, 0.0);
@@ -599,23 +640,29 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                         const double jt = -vrt * tMass;
                         const double jtOld = c ? A.jt1 : A.jt0;
                         const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
+                        changed = changed || (jnAcc != jnOld) || (jtAcc != jtOld) || (jBias != jbnOld);
                         if (c) { A.jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
                         else   { A.jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
-                        const d2 jb = vmul(n, jBias - jbnOld);
-                        const d2 jbneg = vneg(jb);
-                        vba = vadd(vba, vmul(jbneg, A.ma));
-                        wa2.y += A.ia * vcross(r1, jbneg);
-                        vbb = vadd(vbb, vmul(jb, A.mb));
-                        wb2.y += A.ib * vcross(r2, jb);
+                        if (any_bias) {
+                            const d2 jb = vmul(n, jBias - jbnOld);
+                            const d2 jbneg = vneg(jb);
+                            vba = vadd(vba, vmul(jbneg, A.ma));
+                            wa2.y += A.ia * vcross(r1, jbneg);
+                            vbb = vadd(vbb, vmul(jb, A.mb));
+                            wb2.y += A.ib * vcross(r2, jb);
+                        }
                         const d2 j = vrotate(n, mk2(jnAcc - jnOld, jtAcc - jtOld));
                         apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
                     }
                 }
-                if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; L.sb[ba] = vba; }
-                if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; L.sb[bbi] = vbb; }
+                if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; if (any_bias) L.sb[ba] = vba; }
+                if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; if (any_bias) L.sb[bbi] = vbb; }
             }
-            __syncthreads();
+            lds_sync();
         }
+        // an iteration that changed no accumulated impulse applied only zero impulses: the state is a fixed point and
+        // the remaining iterations would repeat it exactly
+        if (!ballot(changed)) break;
     }
     PROF_ACC(8)
     // ---- 7. post-solve bookkeeping for ship(0) x floe arbiters, ascending key order ------------------------------
@@ -623,27 +670,32 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         const bool shiparb = active && ba == 0;
         const unsigned long long sm = ballot(shiparb);
         if (sm) {
-            const double eCoef = (1 - P.arb_e) / (1 + P.arb_e);
-            double ke = 0.0;
-            d2 js = mk2(0.0, 0.0);
-            if (shiparb) {
-                ke += eCoef * A.jn0 * A.jn0 / A.nMass0 + A.jt0 * A.jt0 / A.tMass0;
-                js = vadd(js, vrotate(A.n, mk2(A.jn0, A.jt0)));
-                if (A.count > 1) {
-                    ke += eCoef * A.jn1 * A.jn1 / A.nMass1 + A.jt1 * A.jt1 / A.tMass1;
-                    js = vadd(js, vrotate(A.n, mk2(A.jn1, A.jt1)));
+            // integer bookkeeping is order-free; cold arbiters add exactly +0 to the float sums
+            S.n_post += (unsigned)__popcll(sm);
+            S.n_contact += (unsigned)__popcll(sm) + (unsigned)__popcll(ballot(shiparb && A.count > 1));
+            S.n_first += (unsigned)__popcll(ballot(shiparb && A.state == ARB_FIRST));
+            const bool ws = shiparb && warm;
+            const unsigned long long wsm = ballot(ws);
+            if (wsm) {
+                const double eCoef = (1 - P.arb_e) / (1 + P.arb_e);
+                double ke = 0.0;
+                d2 js = mk2(0.0, 0.0);
+                if (ws) {
+                    ke += eCoef * A.jn0 * A.jn0 / A.nMass0 + A.jt0 * A.jt0 / A.tMass0;
+                    js = vadd(js, vrotate(A.n, mk2(A.jn0, A.jt0)));
+                    if (A.count > 1) {
+                        ke += eCoef * A.jn1 * A.jn1 / A.nMass1 + A.jt1 * A.jt1 / A.tMass1;
+                        js = vadd(js, vrotate(A.n, mk2(A.jn1, A.jt1)));
+                    }
                 }
-            }
-            const double imp = vlen(js);
-            const int ns = __popcll(sm);
-            for (int r = 0; r < ns; r++) { // ship arbiters have the smallest keys: ranks 0..ns-1
-                const unsigned long long rm = ballot(shiparb && A.rank == r);
-                const int l = __ffsll((long long)rm) - 1;
-                S.total_ke += __shfl(ke, l);
-                S.total_imp += __shfl(imp, l);
-                S.n_post += 1u;
-                S.n_contact += (unsigned)__shfl(A.count, l);
-                S.n_first += (__shfl(A.state, l) == ARB_FIRST) ? 1u : 0u;
+                const double imp = vlen(js);
+                const int ns = __popcll(wsm);
+                for (int r = 0; r < ns; r++) { // warm ship arbiters have the smallest keys of the warm set: ranks 0..ns-1
+                    const unsigned long long rm = ballot(ws && A.rank == r);
+                    const int l = __ffsll((long long)rm) - 1;
+                    S.total_ke += __shfl(ke, l);
+                    S.total_imp += __shfl(imp, l);
+                }
             }
         }
     }
