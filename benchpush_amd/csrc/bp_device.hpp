@@ -148,6 +148,17 @@ __device__ __forceinline__ double half_min(double v)
     v = fmin(v, __shfl_xor(v, 16));
     return v;
 }
+// order-preserving bijection binary64 -> u64 (for LDS integer atomics); -0 must be folded into +0 by the caller
+__device__ __forceinline__ unsigned long long f64_key(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_f64(unsigned long long k)
+{
+    const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+    return __builtin_bit_cast(double, b);
+}
 // LDS-only ordering point for a single-wave workgroup: LDS operations of one wave execute in order, so only the
 // compiler must be kept from moving LDS accesses across it (plus a drain of LGKM so values are in registers).
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }

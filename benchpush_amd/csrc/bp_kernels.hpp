@@ -49,16 +49,24 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         L.sv = (d2 *)p; p += sizeof(d2) * nbcap;
         L.sw = (d2 *)p; p += sizeof(d2) * nbcap;
         L.sb = (d2 *)p; p += sizeof(d2) * nbcap;
-        L.stAv = (d2 *)p; p += sizeof(d2) * 32;
-        L.stAn = (d2 *)p; p += sizeof(d2) * 32;
-        L.stBv = (d2 *)p; p += sizeof(d2) * 32;
-        L.stBn = (d2 *)p; p += sizeof(d2) * 32;
+        L.mbox = (d2 *)p; p += sizeof(d2) * 6 * BP_MBOX;
+        L.res_smA = (unsigned long long *)p; p += 8 * 64;
+        L.res_smB = (unsigned long long *)p; p += 8 * 64;
         L.tf = (d2 *)p; p += sizeof(d2) * 128;
         L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
+        L.res_iA = (unsigned *)p; p += 4 * 64;
+        L.res_iB = (unsigned *)p; p += 4 * 64;
+        L.res_jA = (unsigned *)p; p += 4 * 64;
+        L.res_jB = (unsigned *)p; p += 4 * 64;
         L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
+        L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
         L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
-        L.lastlvl = (unsigned char *)p; p += nbcap;
+        L.pl_off = (unsigned short *)p; p += 2 * 64;
+        L.pl_sa = (unsigned short *)p; p += 2 * 64;
+        L.pl_sb = (unsigned short *)p; p += 2 * 64;
         L.rf = (unsigned char *)p; p += 64;
+        L.pl_na = (unsigned char *)p; p += 64;
+        L.pl_nb = (unsigned char *)p; p += 64;
     }
 
     // ---- env context ----

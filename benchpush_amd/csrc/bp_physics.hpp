@@ -52,12 +52,18 @@ struct LdsCtx {
     d2 *sv, *sw, *sb;          // [nbcap] (vx,vy) (w,w_bias) (vbx,vby)
     unsigned *mvs;             // [nbcap] stamp of the sub-step in which the body last moved
     unsigned short *owner;     // [nbcap]
-    unsigned char *lastlvl;    // [nbcap]
-    d2 *stAv, *stAn, *stBv, *stBn; // [32] staging of the two polygons of a pair
+    unsigned short *colmask;   // [nbcap] colours already used at a body (solve-order colouring)
     d2 *tf;                    // [64][2] (cos, sin) (tx, ty) of the moving bodies of the current chunk
     unsigned short *mv;        // [P.mvcap] moving-body list
     unsigned char *rf;         // [64] refresh flags of the current chunk
+    // batched narrow phase (per candidate round, indexed by survivor rank)
+    unsigned long long *res_smA, *res_smB; // [64] order-preserving keys of the best plane separation of A / B
+    unsigned *res_iA, *res_iB, *res_jA, *res_jB; // [64] plane index / support vertex of the best plane
+    unsigned short *pl_off, *pl_sa, *pl_sb;      // [64]
+    unsigned char *pl_na, *pl_nb;                // [64]
+    d2 *mbox;                  // [BP_MBOX][6] manifold mailbox
 };
+#define BP_MBOX 32
 
 struct SubState {
     unsigned stamp;
@@ -79,140 +85,6 @@ struct Manifold { int count; d2 n; d2 p1_0, p2_0, p1_1, p2_1; unsigned h0, h1; i
 __device__ __forceinline__ bool bb_overlap(double4 a, double4 b)
 {
     return (a.x <= b.z && b.x <= a.z && a.y <= b.w && b.y <= a.w);
-}
-
-// Exact closest-feature query + ContactPoints for shapes sa < sb, cooperatively by the whole wave.
-// Every lane returns the same Manifold.
-__device__ __forceinline__ Manifold full_pair(const DevParams &P, const EnvCtx &E, const LdsCtx &L, int sa, int sb)
-{
-    const int lane = lane_id();
-    const int nA = E.nv[sa], nB = E.nv[sb];
-    const double rsum = P.poly_radius + P.poly_radius;
-    __syncthreads();
-    if (lane < 32) {
-        if (lane < nA) { L.stAv[lane] = E.wv[sa * BP_MAXV + lane]; L.stAn[lane] = E.wn[sa * BP_MAXV + lane]; }
-    } else {
-        const int q = lane - 32;
-        if (q < nB) { L.stBv[q] = E.wv[sb * BP_MAXV + q]; L.stBn[q] = E.wn[sb * BP_MAXV + q]; }
-    }
-    __syncthreads();
-    // face separations: lanes 0-31 planes of A against B's vertices, lanes 32-63 planes of B against A's
-    const bool isA = lane < 32;
-    const int f = isA ? lane : lane - 32;
-    const int nP = isA ? nA : nB, nQ = isA ? nB : nA;
-    const d2 *Pv = isA ? L.stAv : L.stBv, *Pn = isA ? L.stAn : L.stBn, *Qv = isA ? L.stBv : L.stAv;
-    const bool fvalid = f < nP;
-    const int fc = fvalid ? f : 0;
-    const d2 fn = Pn[fc], fp = Pv[fc];
-    double mn = BP_INF;
-    int jm = 0;
-#pragma unroll 5
-    for (int j = 0; j < BP_MAXV; j++) { // fixed trip count: slots >= nQ repeat vertex 0, which cannot win the strict '<'
-        const double d = vdot(fn, Qv[j < nQ ? j : 0]);
-        if (d < mn) { mn = d; jm = j; }
-    }
-    const double s = fvalid ? (mn - vdot(fn, fp)) : -BP_INF;
-    // arg-max with lowest-index tie-break: exact max, then the first lane that holds it
-    const double smx = half_max(s);
-    const unsigned long long eqm = ballot(s == smx);
-    const int iA = __ffs((unsigned)(eqm & 0xFFFFFFFFull)) - 1, iB = __ffs((unsigned)(eqm >> 32)) - 1;
-    const double sA = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__double2hiint(smx), 0) << 32) | (unsigned)__builtin_amdgcn_readlane(__double2loint(smx), 0));
-    const double sB = __builtin_bit_cast(double, ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(__double2hiint(smx), 32) << 32) | (unsigned)__builtin_amdgcn_readlane(__double2loint(smx), 32));
-    const int jA = __builtin_amdgcn_readlane(jm, iA), jB = __builtin_amdgcn_readlane(jm, 32 + iB);
-
-    Manifold M;
-    M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0);
-    M.p1_0 = M.p2_0 = M.p1_1 = M.p2_1 = mk2(0, 0);
-    const bool useA = (sA >= sB);
-    const double smax = useA ? sA : sB;
-    M.newhint = 255;
-    if (smax > rsum) { M.newhint = useA ? iA : (nA + iB); return M; }
-    d2 n;
-    bool touching = true;
-    if (smax <= 0.0) {
-        n = useA ? L.stAn[iA] : vneg(L.stBn[iB]);
-    } else {
-        // in_span tests for the best plane of each polygon
-        const int iA0 = (iA - 1 + nA) % nA;
-        const d2 aA = L.stAv[iA0], bA = L.stAv[iA], qA = L.stBv[jA];
-        const d2 eA = vsub(bA, aA);
-        const double uA = vdot(vsub(qA, aA), eA), eeA = vdot(eA, eA);
-        const bool spanA = !(uA < 0.0) && !(uA > eeA);
-        const int kA = (uA < 0.0) ? iA0 : iA;
-        const int iB0 = (iB - 1 + nB) % nB;
-        const d2 aB = L.stBv[iB0], bB = L.stBv[iB], qB = L.stAv[jB];
-        const d2 eB = vsub(bB, aB);
-        const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
-        const bool spanB = !(uB < 0.0) && !(uB > eeB);
-        const int kB = (uB < 0.0) ? iB0 : iB;
-        if (useA) {
-            if (spanA) n = L.stAn[iA];
-            else if (sB > 0.0 && spanB) n = vneg(L.stBn[iB]);
-            else {
-                const d2 p = vsub(L.stBv[jA], L.stAv[kA]);
-                const double d2_ = vlen(p);
-                if (d2_ > rsum) touching = false;
-                n = vmul(p, 1.0 / (d2_ + BP_DBL_MIN));
-            }
-        } else {
-            if (spanB) n = vneg(L.stBn[iB]);
-            else if (sA > 0.0 && spanA) n = L.stAn[iA];
-            else {
-                const d2 p = vsub(L.stBv[kB], L.stAv[jB]);
-                const double d2_ = vlen(p);
-                if (d2_ > rsum) touching = false;
-                n = vmul(p, 1.0 / (d2_ + BP_DBL_MIN));
-            }
-        }
-    }
-    if (!touching) return M;
-    // support vertices: lanes 0-31 -> A along n, lanes 32-63 -> B along -n
-    const d2 nn = vneg(n);
-    double sd = -BP_INF;
-    if (isA) { if (f < nA) sd = vdot(L.stAv[f], n); }
-    else     { if (f < nB) sd = vdot(L.stBv[f], nn); }
-    const double sdm = half_max(sd);
-    const unsigned long long sdq = ballot(sd == sdm);
-    const int i1A = __ffs((unsigned)(sdq & 0xFFFFFFFFull)) - 1, i1B = __ffs((unsigned)(sdq >> 32)) - 1;
-    // SupportEdgeForPoly
-    d2 e1a, e1b, e2a, e2b;
-    int e1ia, e1ib, e2ia, e2ib;
-    {
-        const int i0 = (i1A - 1 + nA) % nA, i2 = (i1A + 1) % nA;
-        if (vdot(n, L.stAn[i1A]) > vdot(n, L.stAn[i2])) { e1a = L.stAv[i0]; e1ia = i0; e1b = L.stAv[i1A]; e1ib = i1A; }
-        else { e1a = L.stAv[i1A]; e1ia = i1A; e1b = L.stAv[i2]; e1ib = i2; }
-    }
-    {
-        const int i0 = (i1B - 1 + nB) % nB, i2 = (i1B + 1) % nB;
-        if (vdot(nn, L.stBn[i1B]) > vdot(nn, L.stBn[i2])) { e2a = L.stBv[i0]; e2ia = i0; e2b = L.stBv[i1B]; e2ib = i1B; }
-        else { e2a = L.stBv[i1B]; e2ia = i1B; e2b = L.stBv[i2]; e2ib = i2; }
-    }
-    // ContactPoints
-    const double r1 = P.poly_radius, r2 = P.poly_radius;
-    const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
-    const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
-    const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
-    const double e2_denom = 1.0 / (d_e2_b - d_e2_a + BP_DBL_MIN);
-    M.n = n;
-    {
-        const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_b - d_e1_a) * e1_denom)));
-        const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_a - d_e2_a) * e2_denom)));
-        const double dist = vdot(vsub(p2, p1), n);
-        if (dist <= 0.0) {
-            M.p1_0 = p1; M.p2_0 = p2; M.h0 = ((unsigned)e1ia << 8) | (unsigned)e2ib; M.count = 1;
-        }
-    }
-    {
-        const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_a - d_e1_a) * e1_denom)));
-        const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_b - d_e2_a) * e2_denom)));
-        const double dist = vdot(vsub(p2, p1), n);
-        if (dist <= 0.0) {
-            const unsigned h = ((unsigned)e1ib << 8) | (unsigned)e2ia;
-            if (M.count == 0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = h; M.count = 1; }
-            else { M.p1_1 = p1; M.p2_1 = p2; M.h1 = h; M.count = 2; }
-        }
-    }
-    return M;
 }
 
 // Rebuild the neighbour list of body i around its current AABB (uniform call).
@@ -416,48 +288,241 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                 if (sep > rsum) valid = false;
             }
         }
-        unsigned long long cm = ballot(valid);
+        const unsigned long long cm = ballot(valid);
         PROF_ACC(2)
         PROF_CNT(18, __popcll(cm))
-        while (cm) {
-            const int l = __ffsll((long long)cm) - 1;
-            cm &= cm - 1;
-            const int usa = __shfl(sa, l), usb = __shfl(sb, l);
-            const Manifold M = full_pair(P, E, L, usa, usb);
-            PROF_ACC(3)
-            if (lane == l) E.hint[i * BP_KADJ + s] = (unsigned char)M.newhint;
-            if (M.count > 0) {
-                // cpArbiterUpdate on the slot that owns this pair
-                const unsigned key = ((unsigned)usa << 16) | (unsigned)usb;
-                unsigned long long om = ballot(A.key == key);
-                bool fresh = false;
-                if (!om) { om = ballot(A.key == ARB_FREE_KEY); fresh = true; }
-                if (!om) { S.err |= BP_ERR_ARB_OVERFLOW; }
-                else {
-                    const int owner = __ffsll((long long)om) - 1;
-                    if (lane == owner) {
-                        if (fresh) { A.key = key; A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0; }
-                        const d2 pa = E.pxy[usa], pbp = E.pxy[usb];
-                        double njn0 = 0.0, njt0 = 0.0, njn1 = 0.0, njt1 = 0.0;
-                        if (A.count > 0 && A.h0 == M.h0) { njn0 = A.jn0; njt0 = A.jt0; }
-                        if (A.count > 1 && A.h1 == M.h0) { njn0 = A.jn1; njt0 = A.jt1; }
-                        if (M.count > 1) {
-                            if (A.count > 0 && A.h0 == M.h1) { njn1 = A.jn0; njt1 = A.jt0; }
-                            if (A.count > 1 && A.h1 == M.h1) { njn1 = A.jn1; njt1 = A.jt1; }
-                        }
-                        A.jn0 = njn0; A.jt0 = njt0; A.jn1 = njn1; A.jt1 = njt1;
-                        A.h0 = M.h0; A.h1 = M.h1;
-                        A.r1_0 = vsub(M.p1_0, pa); A.r2_0 = vsub(M.p2_0, pbp);
-                        A.r1_1 = vsub(M.p1_1, pa); A.r2_1 = vsub(M.p2_1, pbp);
-                        A.count = M.count;
-                        A.n = M.n;
-                        if (A.state == ARB_CACHED) A.state = ARB_FIRST;
-                        A.stamp = now;
-                        const double4 m1 = E.mass[usa], m2 = E.mass[usb];
-                        A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+        if (cm == 0) continue;
+        // ---- 4a. face separations of every surviving pair: one (pair, plane) item per lane --------------------------
+        // A pair's planes never straddle a 64-item round (its block is moved to the next round if it would), so the
+        // per-round LDS atomics see all planes of a pair together.
+        const int nc = __popcll(cm);
+        const int myr = popc_below(cm, lane); // rank of this lane's pair among the survivors
+        const int nA_l = valid ? E.nv[sa] : 0, nB_l = valid ? E.nv[sb] : 0;
+        int total = 0;
+        {
+            unsigned long long m = cm;
+            int r = 0;
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const int c = __builtin_amdgcn_readlane(nA_l + nB_l, l);
+                if ((total & 63) + c > 64) total = (total + 63) & ~63;
+                if (lane == l) {
+                    L.pl_off[r] = (unsigned short)total;
+                    L.pl_sa[r] = (unsigned short)sa; L.pl_sb[r] = (unsigned short)sb;
+                    L.pl_na[r] = (unsigned char)nA_l; L.pl_nb[r] = (unsigned char)nB_l;
+                    L.res_smA[r] = 0ull; L.res_smB[r] = 0ull; L.res_iA[r] = 0xFFFFFFFFu; L.res_iB[r] = 0xFFFFFFFFu;
+                }
+                total += c;
+                r++;
+            }
+        }
+        lds_sync();
+        for (int t0 = 0; t0 < total; t0 += 64) {
+            const int t = t0 + lane;
+            int r = 0;
+            {   // largest r with pl_off[r] <= t
+                int lo = 0, hi = nc - 1;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)L.pl_off[mid] <= t) lo = mid; else hi = mid - 1; }
+                r = lo;
+            }
+            const int pna = L.pl_na[r], pnb = L.pl_nb[r];
+            int fidx = t - (int)L.pl_off[r];
+            const bool tv = (fidx >= 0) && (fidx < pna + pnb);
+            const bool onA = fidx < pna;
+            unsigned long long skey = 0ull;
+            int jm = 0;
+            if (tv) {
+                const int psa = L.pl_sa[r], psb = L.pl_sb[r];
+                const int pbody = onA ? psa : psb, qbody = onA ? psb : psa;
+                const int f = onA ? fidx : fidx - pna;
+                const int nq = onA ? pnb : pna;
+                const d2 fn = E.wn[pbody * BP_MAXV + f], fp = E.wv[pbody * BP_MAXV + f];
+                double mn = BP_INF;
+#pragma unroll 5
+                for (int q = 0; q < BP_MAXV; q++) { // slots >= nq repeat vertex 0, which cannot win the strict '<'
+                    const double d = vdot(fn, E.wv[qbody * BP_MAXV + (q < nq ? q : 0)]);
+                    if (d < mn) { mn = d; jm = q; }
+                }
+                const double sp = (mn - vdot(fn, fp)) + 0.0; // "+ 0.0": -0 and +0 share one key
+                skey = f64_key(sp);
+                fidx = f;
+                atomicMax(onA ? &L.res_smA[r] : &L.res_smB[r], skey);
+            }
+            lds_sync();
+            bool isbest = false;
+            if (tv) {
+                isbest = (skey == (onA ? L.res_smA[r] : L.res_smB[r]));
+                if (isbest) atomicMin(onA ? &L.res_iA[r] : &L.res_iB[r], (unsigned)fidx); // ties -> lowest plane index
+            }
+            lds_sync();
+            if (isbest && (unsigned)fidx == (onA ? L.res_iA[r] : L.res_iB[r])) { if (onA) L.res_jA[r] = (unsigned)jm; else L.res_jB[r] = (unsigned)jm; }
+        }
+        lds_sync();
+        PROF_ACC(3)
+        // ---- 4b. closest features -> normal -> Chipmunk ContactPoints, one pair per lane ------------------------------
+        Manifold M;
+        M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0); M.newhint = 255;
+        M.p1_0 = M.p2_0 = M.p1_1 = M.p2_1 = mk2(0, 0);
+        if (valid) {
+            const int nA = nA_l, nB = nB_l;
+            const d2 *Av = E.wv + sa * BP_MAXV, *An = E.wn + sa * BP_MAXV, *Bv = E.wv + sb * BP_MAXV, *Bn = E.wn + sb * BP_MAXV;
+            const double sA = key_f64(L.res_smA[myr]), sB = key_f64(L.res_smB[myr]);
+            const int iA = (int)L.res_iA[myr], iB = (int)L.res_iB[myr], jA = (int)L.res_jA[myr], jB = (int)L.res_jB[myr];
+            const bool useA = (sA >= sB);
+            const double smax = useA ? sA : sB;
+            bool touching = true;
+            d2 n = mk2(0, 0);
+            if (smax > rsum) { M.newhint = useA ? iA : (nA + iB); touching = false; }
+            else if (smax <= 0.0) { n = useA ? An[iA] : vneg(Bn[iB]); }
+            else {
+                const int iA0 = (iA - 1 + nA) % nA;
+                const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
+                const d2 eA = vsub(bA, aA);
+                const double uA = vdot(vsub(qA, aA), eA), eeA = vdot(eA, eA);
+                const bool spanA = !(uA < 0.0) && !(uA > eeA);
+                const int kA = (uA < 0.0) ? iA0 : iA;
+                const int iB0 = (iB - 1 + nB) % nB;
+                const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
+                const d2 eB = vsub(bB, aB);
+                const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
+                const bool spanB = !(uB < 0.0) && !(uB > eeB);
+                const int kB = (uB < 0.0) ? iB0 : iB;
+                if (useA) {
+                    if (spanA) n = An[iA];
+                    else if (sB > 0.0 && spanB) n = vneg(Bn[iB]);
+                    else {
+                        const d2 pp = vsub(Bv[jA], Av[kA]);
+                        const double dl = vlen(pp);
+                        if (dl > rsum) touching = false;
+                        n = vmul(pp, 1.0 / (dl + BP_DBL_MIN));
+                    }
+                } else {
+                    if (spanB) n = vneg(Bn[iB]);
+                    else if (sA > 0.0 && spanA) n = An[iA];
+                    else {
+                        const d2 pp = vsub(Bv[kB], Av[jB]);
+                        const double dl = vlen(pp);
+                        if (dl > rsum) touching = false;
+                        n = vmul(pp, 1.0 / (dl + BP_DBL_MIN));
                     }
                 }
             }
+            if (touching) {
+                const d2 nn = vneg(n);
+                // support vertices (PolySupportPointIndex): first maximum of v . n
+                int i1A = 0, i1B = 0;
+                {
+                    double mx = -BP_INF;
+#pragma unroll 5
+                    for (int q = 0; q < BP_MAXV; q++) { // slots >= nA repeat vertex 0: equal, cannot win the strict '>'
+                        const double d = vdot(Av[q < nA ? q : 0], n);
+                        if (d > mx) { mx = d; i1A = q; }
+                    }
+                    mx = -BP_INF;
+#pragma unroll 5
+                    for (int q = 0; q < BP_MAXV; q++) {
+                        const double d = vdot(Bv[q < nB ? q : 0], nn);
+                        if (d > mx) { mx = d; i1B = q; }
+                    }
+                }
+                d2 e1a, e1b, e2a, e2b;
+                int e1ia, e1ib, e2ia, e2ib;
+                {
+                    const int i0 = (i1A - 1 + nA) % nA, i2 = (i1A + 1) % nA;
+                    if (vdot(n, An[i1A]) > vdot(n, An[i2])) { e1a = Av[i0]; e1ia = i0; e1b = Av[i1A]; e1ib = i1A; }
+                    else { e1a = Av[i1A]; e1ia = i1A; e1b = Av[i2]; e1ib = i2; }
+                }
+                {
+                    const int i0 = (i1B - 1 + nB) % nB, i2 = (i1B + 1) % nB;
+                    if (vdot(nn, Bn[i1B]) > vdot(nn, Bn[i2])) { e2a = Bv[i0]; e2ia = i0; e2b = Bv[i1B]; e2ib = i1B; }
+                    else { e2a = Bv[i1B]; e2ia = i1B; e2b = Bv[i2]; e2ib = i2; }
+                }
+                const double r1 = P.poly_radius, r2 = P.poly_radius;
+                const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
+                const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
+                const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
+                const double e2_denom = 1.0 / (d_e2_b - d_e2_a + BP_DBL_MIN);
+                M.n = n;
+                {
+                    const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_b - d_e1_a) * e1_denom)));
+                    const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_a - d_e2_a) * e2_denom)));
+                    const double dist = vdot(vsub(p2, p1), n);
+                    if (dist <= 0.0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = ((unsigned)e1ia << 8) | (unsigned)e2ib; M.count = 1; }
+                }
+                {
+                    const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_a - d_e1_a) * e1_denom)));
+                    const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_b - d_e2_a) * e2_denom)));
+                    const double dist = vdot(vsub(p2, p1), n);
+                    if (dist <= 0.0) {
+                        const unsigned h = ((unsigned)e1ib << 8) | (unsigned)e2ia;
+                        if (M.count == 0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = h; M.count = 1; }
+                        else { M.p1_1 = p1; M.p2_1 = p2; M.h1 = h; M.count = 2; }
+                    }
+                }
+            }
+            E.hint[i * BP_KADJ + s] = (unsigned char)M.newhint;
+        }
+        PROF_ACC(10)
+        // ---- 4c. cpArbiterUpdate: hand each manifold to the lane that owns the pair's arbiter slot ---------------------
+        const unsigned long long dm = ballot(valid && M.count > 0);
+        const int drank = popc_below(dm, lane);
+        const int ndel = __popcll(dm);
+        for (int dbase = 0; dbase < ndel; dbase += BP_MBOX) {
+            const bool mine = valid && M.count > 0 && drank >= dbase && drank < dbase + BP_MBOX;
+            if (mine) {
+                d2 *mb = L.mbox + (drank - dbase) * 6;
+                mb[0] = M.n; mb[1] = M.p1_0; mb[2] = M.p2_0; mb[3] = M.p1_1; mb[4] = M.p2_1;
+                mb[5] = mk2(__hiloint2double((int)M.h0, M.count), __hiloint2double((int)M.h1, 0));
+            }
+            lds_sync();
+            int my_mb = -1;
+            bool fresh = false;
+            unsigned long long m = dm;
+            int dr = 0;
+            while (m) { // slot search / allocation in pair order (wave-uniform)
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                if (dr >= dbase && dr < dbase + BP_MBOX) {
+                    const unsigned key = ((unsigned)__builtin_amdgcn_readlane(sa, l) << 16) | (unsigned)__builtin_amdgcn_readlane(sb, l);
+                    unsigned long long om = ballot(A.key == key);
+                    bool fr = false;
+                    if (!om) { om = ballot(A.key == ARB_FREE_KEY); fr = true; }
+                    if (!om) { S.err |= BP_ERR_ARB_OVERFLOW; }
+                    else {
+                        const int owner = __ffsll((long long)om) - 1;
+                        if (lane == owner) { my_mb = dr - dbase; fresh = fr; A.key = key; }
+                    }
+                }
+                dr++;
+            }
+            if (my_mb >= 0) {
+                const d2 *mb = L.mbox + my_mb * 6;
+                const d2 mn_ = mb[0], mp10 = mb[1], mp20 = mb[2], mp11 = mb[3], mp21 = mb[4], mh = mb[5];
+                const unsigned mh0 = (unsigned)__double2hiint(mh.x), mh1 = (unsigned)__double2hiint(mh.y);
+                const int mcount = __double2loint(mh.x);
+                if (fresh) { A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0; }
+                const int usa = (int)(A.key >> 16), usb = (int)(A.key & 0xFFFFu);
+                const d2 pa = E.pxy[usa], pbp = E.pxy[usb];
+                double njn0 = 0.0, njt0 = 0.0, njn1 = 0.0, njt1 = 0.0;
+                if (A.count > 0 && A.h0 == mh0) { njn0 = A.jn0; njt0 = A.jt0; }
+                if (A.count > 1 && A.h1 == mh0) { njn0 = A.jn1; njt0 = A.jt1; }
+                if (mcount > 1) {
+                    if (A.count > 0 && A.h0 == mh1) { njn1 = A.jn0; njt1 = A.jt0; }
+                    if (A.count > 1 && A.h1 == mh1) { njn1 = A.jn1; njt1 = A.jt1; }
+                }
+                A.jn0 = njn0; A.jt0 = njt0; A.jn1 = njn1; A.jt1 = njt1;
+                A.h0 = mh0; A.h1 = mh1;
+                A.r1_0 = vsub(mp10, pa); A.r2_0 = vsub(mp20, pbp);
+                A.r1_1 = vsub(mp11, pa); A.r2_1 = vsub(mp21, pbp);
+                A.count = mcount;
+                A.n = mn_;
+                if (A.state == ARB_CACHED) A.state = ARB_FIRST;
+                A.stamp = now;
+                const double4 m1 = E.mass[usa], m2 = E.mass[usb];
+                A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+            }
+            lds_sync();
         }
     }
     PROF_ACC(4)
@@ -537,10 +602,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         }
     }
     const bool any_bias = ballot(warm && ((A.bias0 != 0.0) || (A.count > 1 && A.bias1 != 0.0))) != 0;
-    // ---- solve order over the warm set: rank by key, dependency levels (cached while the warm set is unchanged) ----
-    if (wmask != S.prev_amask) {
+    // ---- solve order: greedy colouring of the active set in ascending key order (cached while the set is unchanged);
+    //      arbiters of one colour share no dynamic body, so a colour runs in parallel; order = (colour, key) ----------
+    if (amask != S.prev_amask) {
         int rank = 0;
-        unsigned long long m = wmask;
+        unsigned long long m = amask;
         while (m) {
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
@@ -548,27 +614,29 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             rank += (k < A.key) ? 1 : 0;
         }
         A.rank = rank;
-        if (warm) { L.lastlvl[ba] = 0; L.lastlvl[bbi] = 0; }
         lds_sync();
-        const int nact = __popcll(wmask);
+        if (active) { L.colmask[ba] = 0; L.colmask[bbi] = 0; }
+        lds_sync();
+        const int nact = __popcll(amask);
         int nlev = 0;
         for (int r = 0; r < nact; r++) {
-            const unsigned long long rm = ballot(warm && A.rank == r);
+            const unsigned long long rm = ballot(active && A.rank == r);
             const int l = __ffsll((long long)rm) - 1;
             const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
             const bool adyn = __builtin_amdgcn_readlane(__double2hiint(A.ma), l) != 0 || __builtin_amdgcn_readlane(__double2loint(A.ma), l) != 0;
             const bool bdyn = __builtin_amdgcn_readlane(__double2hiint(A.mb), l) != 0 || __builtin_amdgcn_readlane(__double2loint(A.mb), l) != 0;
             const int a = (int)(k >> 16), b = (int)(k & 0xFFFFu);
-            const int la = adyn ? (int)L.lastlvl[a] : 0;
-            const int lb = bdyn ? (int)L.lastlvl[b] : 0;
-            const int lvl = max(la, lb) + 1;
-            if (adyn) L.lastlvl[a] = (unsigned char)lvl;
-            if (bdyn) L.lastlvl[b] = (unsigned char)lvl;
-            if (lane == l) A.level = lvl;
-            nlev = max(nlev, lvl);
+            const unsigned ua = adyn ? (unsigned)L.colmask[a] : 0u, ub = bdyn ? (unsigned)L.colmask[b] : 0u;
+            const unsigned used = ua | ub;
+            int c = __ffs(~used) - 1;
+            if (c > 15) { c = 15; S.err |= BP_ERR_LEVEL_OVERFLOW; }
+            if (adyn) L.colmask[a] = (unsigned short)(ua | (1u << c));
+            if (bdyn) L.colmask[b] = (unsigned short)(ub | (1u << c));
+            if (lane == l) A.level = c + 1;
+            nlev = max(nlev, c + 1);
         }
         S.nlevels = nlev;
-        S.prev_amask = wmask;
+        S.prev_amask = amask;
     }
     PROF_CNT(21, __popcll(wmask))
     __syncthreads();
@@ -585,7 +653,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     // ---- 6c. warm start (cpArbiterApplyCachedImpulse) -----------------------------------------------------------
     const double dt_coef = (prev_dt == 0.0) ? 0.0 : dt / prev_dt;
     const int nlevels = wmask ? S.nlevels : 0;
+    unsigned lvlmask = 0; // colours that hold at least one warm arbiter
+    for (int lvl = 1; lvl <= nlevels; lvl++) if (ballot(warm && A.level == lvl)) lvlmask |= 1u << lvl;
     for (int lvl = 1; lvl <= nlevels; lvl++) {
+        if (!(lvlmask & (1u << lvl))) continue;
         if (warm && A.level == lvl && A.state != ARB_FIRST) {
             d2 va = L.sv[ba], vb = L.sv[bbi];
             d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
@@ -607,6 +678,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     for (int it = 0; it < P.iterations; it++) {
         bool changed = false;
         for (int lvl = 1; lvl <= nlevels; lvl++) {
+            if (!(lvlmask & (1u << lvl))) continue;
             if (warm && A.level == lvl) {
                 d2 va = L.sv[ba], vb = L.sv[bbi];
                 d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
@@ -689,9 +761,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                     }
                 }
                 const double imp = vlen(js);
-                const int ns = __popcll(wsm);
-                for (int r = 0; r < ns; r++) { // warm ship arbiters have the smallest keys of the warm set: ranks 0..ns-1
+                const int ns = __popcll(sm);
+                for (int r = 0; r < ns; r++) { // ship arbiters have the smallest keys of the active set: ranks 0..ns-1
                     const unsigned long long rm = ballot(ws && A.rank == r);
+                    if (!rm) continue;
                     const int l = __ffsll((long long)rm) - 1;
                     S.total_ke += __shfl(ke, l);
                     S.total_imp += __shfl(imp, l);

@@ -26,9 +26,9 @@
  * kernels, <=2 ulp from libm) so that a GPU implementation can be bit-identical.
  *
  * Deliberate, documented choices where Chipmunk's behaviour is not a function of its inputs alone:
- *   - Arbiter (contact pair) solve order: ascending (shapeA, shapeB) index, shapeA < shapeB.  Chipmunk's
- *     order falls out of its BB-tree / hash-set internals; any fixed order is an equally valid
- *     Gauss-Seidel sweep.
+ *   - Arbiter (contact pair) solve order: ascending (colour, shapeA, shapeB) with shapeA < shapeB and colour from a
+ *     greedy colouring in ascending (shapeA, shapeB) order (see space_step).  Chipmunk's order falls out of its
+ *     BB-tree / hash-set internals; any fixed order is an equally valid Gauss-Seidel sweep.
  *   - The closest-feature query (Chipmunk: GJK+EPA, cpCollision.c) is restated as an exact
  *     separating-axis / closest-feature search that yields the same (normal, touching?) answer up
  *     to rounding; only the normal and the boolean reach cpCollision.c:ContactPoints.
@@ -175,6 +175,7 @@ typedef struct orc_env {
     /* arbiter table sorted by key */
     arb_t *arbs; int narb, caparb;
     int *active; int nactive, capactive;
+    int *solve, *color; int capsolve; uint32_t *used; long stat_ncol_max;
     long stamp;
     double curr_dt;
     /* sweep order */
@@ -674,6 +675,40 @@ static void space_step(orc_env *E, double dt)
         }
         E->narb = w;
     }
+    /* Solve order.  Chipmunk sweeps its arbiter array in BB-tree/hash order; any fixed order is a valid Gauss-Seidel
+     * sweep.  Here: greedy colouring in ascending key order (an arbiter takes the smallest colour not yet used by
+     * either of its finite-mass bodies), then ascending (colour, key).  Arbiters of one colour share no dynamic body,
+     * which is what lets a GPU run a colour in parallel with a bit-identical result. */
+    if (E->nactive > E->capsolve) {
+        E->capsolve = E->nactive * 2;
+        E->solve = (int *)realloc(E->solve, (size_t)E->capsolve * sizeof(int));
+        E->color = (int *)realloc(E->color, (size_t)E->capsolve * sizeof(int));
+    }
+    {
+        if (!E->used) E->used = (uint32_t *)calloc((size_t)E->nb + 1, sizeof(uint32_t));
+        for (int k = 0; k < E->nactive; k++) {
+            int pos; arb_find(E, (uint32_t)E->active[k], &pos);
+            E->used[E->shapes[E->arbs[pos].sa].body] = 0; E->used[E->shapes[E->arbs[pos].sb].body] = 0;
+        }
+        int ncol = 0;
+        for (int k = 0; k < E->nactive; k++) {
+            int pos; arb_find(E, (uint32_t)E->active[k], &pos);
+            int ba = E->shapes[E->arbs[pos].sa].body, bb = E->shapes[E->arbs[pos].sb].body;
+            uint32_t m = 0;
+            if (E->bodies[ba].m_inv != 0.0) m |= E->used[ba];
+            if (E->bodies[bb].m_inv != 0.0) m |= E->used[bb];
+            int c = 0;
+            while (m & (1u << c)) c++;
+            E->color[k] = c;
+            if (E->bodies[ba].m_inv != 0.0) E->used[ba] |= 1u << c;
+            if (E->bodies[bb].m_inv != 0.0) E->used[bb] |= 1u << c;
+            if (c + 1 > ncol) ncol = c + 1;
+        }
+        int w = 0;
+        for (int c = 0; c < ncol; c++)
+            for (int k = 0; k < E->nactive; k++) if (E->color[k] == c) E->solve[w++] = E->active[k];
+        if (ncol > E->stat_ncol_max) E->stat_ncol_max = ncol;
+    }
     /* prestep */
     for (int k = 0; k < E->nactive; k++) {
         int pos; arb_find(E, (uint32_t)E->active[k], &pos);
@@ -689,13 +724,13 @@ static void space_step(orc_env *E, double dt)
     /* warm start */
     double dt_coef = (prev_dt == 0.0 ? 0.0 : dt / prev_dt);
     for (int k = 0; k < E->nactive; k++) {
-        int pos; arb_find(E, (uint32_t)E->active[k], &pos);
+        int pos; arb_find(E, (uint32_t)E->solve[k], &pos);
         arb_apply_cached(E, &E->arbs[pos], dt_coef);
     }
     /* solver */
     for (int it = 0; it < E->P.iterations; it++)
         for (int k = 0; k < E->nactive; k++) {
-            int pos; arb_find(E, (uint32_t)E->active[k], &pos);
+            int pos; arb_find(E, (uint32_t)E->solve[k], &pos);
             arb_apply_impulse(E, &E->arbs[pos]);
         }
     /* post-solve callbacks: ship(type 1) x floe(type 2) bookkeeping, ship_ice_env.py:155-173 */
@@ -765,6 +800,7 @@ void orc_destroy(orc_env *E)
 {
     if (!E) return;
     free(E->bodies); free(E->shapes); free(E->arbs); free(E->active); free(E->order); free(E->prev_wv);
+    free(E->solve); free(E->color); free(E->used);
     free(E);
 }
 
@@ -784,7 +820,7 @@ static void snapshot_world(orc_env *E)
 int orc_reset(orc_env *E, int nf, const double *floe_verts, const int *counts, const double *centres,
               int nsv, const double *ship_verts, const double *head, const double *tail, const double *start)
 {
-    free(E->bodies); free(E->shapes); free(E->order); free(E->prev_wv);
+    free(E->bodies); free(E->shapes); free(E->order); free(E->prev_wv); free(E->used); E->used = NULL;
     E->bodies = (body_t *)calloc((size_t)nf + 1, sizeof(body_t));
     E->shapes = (shape_t *)calloc((size_t)nf + 1, sizeof(shape_t));
     E->order = (int *)calloc((size_t)nf + 1, sizeof(int));
@@ -971,7 +1007,7 @@ void orc_get_local_polys(const orc_env *E, double *verts, double *normals)
 void orc_get_stats(const orc_env *E, long *out)
 {
     out[0] = E->stat_substeps; out[1] = E->stat_pairs_bb; out[2] = E->stat_narrow; out[3] = E->stat_arb_sum;
-    out[4] = E->stat_arb_max; out[5] = E->stat_moving_sum; out[6] = E->stat_hot_sum; out[7] = E->narb;
+    out[4] = E->stat_arb_max; out[5] = E->stat_moving_sum; out[6] = E->stat_hot_sum; out[7] = E->stat_ncol_max;
 }
 void orc_get_info(const orc_env *E, double *info)
 {

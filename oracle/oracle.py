@@ -157,7 +157,7 @@ class OracleShipIce:
     def stats(self):
         out = np.zeros(8, np.int64)
         self.L.orc_get_stats(self.h, _p(out))
-        return dict(zip(["substeps", "pairs_bb", "narrow", "arb_sum", "arb_max", "moving_sum", "hot_sum", "narb"], out.tolist()))
+        return dict(zip(["substeps", "pairs_bb", "narrow", "arb_sum", "arb_max", "moving_sum", "hot_sum", "ncol_max"], out.tolist()))
 
 
 def sincos(x):

@@ -17,7 +17,7 @@ env.reset()
 prof = torch.zeros((E, 24), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
 g = torch.Generator(device=env.device); g.manual_seed(1234)
-names = ["integrate", "refresh", "cand+hint", "full_pair", "arb_update", "filter+levels", "prestep+velint", "warm", "solver", "post+mvlist"]
+names = ["integrate", "refresh", "cand+hint", "face_seps", "deliver", "filter", "prestep+warmset", "velint+warm", "solver", "post+mvlist", "manifolds"]
 for t in range(STEPS):
     a = (torch.rand(E, generator=g, device=env.device, dtype=torch.float64) * 2 - 1).float().double()
     _, _, term, _, _ = env.step(a)
@@ -29,6 +29,6 @@ for t in range(STEPS):
         print("step %d: kernel cycles(100MHz ticks?) mean %.0f max %.0f (env %d)" % (t, tot.mean(), tot.max(), worst))
         for who, row in (("mean", p.mean(0)), ("worst", p[worst])):
             print("  %s: " % who + " ".join("%s=%.1f%%" % (n, 100 * row[i] / row[23]) for i, n in enumerate(names)))
-            print("        per-substep: nmv=%.2f refresh=%.3f fullpairs=%.2f nact=%.2f levels=%.2f" % (
-                row[16] / 400, row[17] / 400, row[18] / 400, row[19] / 400, row[20] / 400))
+            print("        per-substep: nmv=%.2f refresh=%.3f fullpairs=%.2f nact=%.2f levels=%.2f nwarm=%.2f" % (
+                row[16] / 400, row[17] / 400, row[18] / 400, row[19] / 400, row[20] / 400, row[21] / 400))
     env.reset(term)
