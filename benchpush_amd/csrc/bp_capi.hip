@@ -58,8 +58,8 @@ static int dalloc(bp_handle *h, T **p, size_t n, int fill_byte = 0)
 static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
 static size_t lds_bytes_for(int nbcap)
 {
-    return sizeof(d2) * nbcap * 3 + sizeof(d2) * 6 * BP_MBOX + 8 * 64 * 2 + sizeof(d2) * 128 + sizeof(unsigned) * nbcap + 4 * 64 * 4 +
-           sizeof(unsigned short) * nbcap * 2 + sizeof(unsigned short) * mvcap_for(nbcap) + 2 * 64 * 3 + 64 * 3;
+    return sizeof(d2) * BP_NSLOT * 3 + sizeof(d2) * 128 + 2560 + sizeof(unsigned) * nbcap + sizeof(unsigned short) * nbcap * 2 +
+           sizeof(unsigned short) * mvcap_for(nbcap) + (size_t)nbcap + 64 + 64;
 }
 
 extern "C" {

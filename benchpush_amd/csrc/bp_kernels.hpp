@@ -46,27 +46,30 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     LdsCtx L;
     {
         char *p = (char *)bp_smem;
-        L.sv = (d2 *)p; p += sizeof(d2) * nbcap;
-        L.sw = (d2 *)p; p += sizeof(d2) * nbcap;
-        L.sb = (d2 *)p; p += sizeof(d2) * nbcap;
-        L.mbox = (d2 *)p; p += sizeof(d2) * 6 * BP_MBOX;
+        L.sv = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+        L.sw = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+        L.sb = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+        L.tf = (d2 *)p; p += sizeof(d2) * 128;
+        // scratch region shared by the plane search (res_*, pl_*) and, afterwards, the manifold mailbox
+        char *scr = p;
+        L.mbox = (d2 *)scr;
         L.res_smA = (unsigned long long *)p; p += 8 * 64;
         L.res_smB = (unsigned long long *)p; p += 8 * 64;
-        L.tf = (d2 *)p; p += sizeof(d2) * 128;
-        L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
         L.res_iA = (unsigned *)p; p += 4 * 64;
         L.res_iB = (unsigned *)p; p += 4 * 64;
         L.res_jA = (unsigned *)p; p += 4 * 64;
         L.res_jB = (unsigned *)p; p += 4 * 64;
-        L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
-        L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
-        L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
         L.pl_off = (unsigned short *)p; p += 2 * 64;
         L.pl_sa = (unsigned short *)p; p += 2 * 64;
         L.pl_sb = (unsigned short *)p; p += 2 * 64;
-        L.rf = (unsigned char *)p; p += 64;
         L.pl_na = (unsigned char *)p; p += 64;
-        L.pl_nb = (unsigned char *)p; p += 64;
+        L.pl_nb = (unsigned char *)p; p += 64;   // scratch = 2560 B >= mailbox 16 * 96 B
+        L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
+        L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
+        L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
+        L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
+        L.slot_of = (unsigned char *)p; p += nbcap;
+        L.rf = (unsigned char *)p; p += 64;
     }
 
     // ---- env context ----
@@ -97,6 +100,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     for (int q = 0; q < 24; q++) S.prof[q] = 0;
     const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
+    S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0;
     S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
     A.level = 0; A.rank = 0;
     A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
@@ -108,7 +112,9 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         for (int base = 0; base < nbcap; base += 64) {
             const int i = base + lane;
             if (i < nbcap) {
-                L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, 0.0); L.sb[i] = mk2(0.0, 0.0); L.mvs[i] = 0u;
+                L.mvs[i] = 0u;
+                L.slot_of[i] = (i == 0) ? 0 : 255;
+                if (i == 0) { L.sv[0] = mk2(0.0, 0.0); L.sw[0] = mk2(0.0, 0.0); L.sb[0] = mk2(0.0, 0.0); }
                 if (i < E.nb) {
                     const double4 ps = D.sc_pose[tb + i];
                     double sn, cs;
@@ -163,21 +169,18 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             const int i = base + lane;
             if (i < E.nb) L.mv[i] = (unsigned short)i;
         }
-        S.stamp = 0; S.curr_dt = 0.0; S.nmv = E.nb;
+        S.stamp = 0; S.curr_dt = 0.0; S.nmv = E.nb; S.nslots = 1;
+        A.slotA = A.slotB = 0;
         S.total_ke = 0.0; S.total_imp = 0.0; S.n_post = S.n_contact = S.n_first = 0;
         __syncthreads();
     } else {
         // ---- load persistent state ----
         for (int base = 0; base < nbcap; base += 64) {
             const int i = base + lane;
-            if (i < nbcap) {
-                const bool in = i < E.nb;
-                L.sv[i] = in ? D.velv[eb + i] : mk2(0.0, 0.0);
-                L.sw[i] = in ? D.velw[eb + i] : mk2(0.0, 0.0);
-                L.sb[i] = in ? D.velb[eb + i] : mk2(0.0, 0.0);
-                L.mvs[i] = 0u;
-            }
+            if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i == 0) ? 0 : 255; }
         }
+        if (lane == 0) { L.sv[0] = D.velv[eb]; L.sw[0] = D.velw[eb]; L.sb[0] = D.velb[eb]; }
+        S.nslots = 1;
         const size_t ab = (size_t)env * BP_ACAP + lane;
         A.key = D.a_key[ab]; A.stamp = D.a_stamp[ab];
         { const unsigned sc = D.a_sc[ab]; A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
@@ -186,6 +189,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         A.jn0 = ad[0]; A.jt0 = ad[1]; A.jn1 = ad[2]; A.jt1 = ad[3];
         A.n = mk2(ad[4], ad[5]);
         A.r1_0 = mk2(ad[6], ad[7]); A.r2_0 = mk2(ad[8], ad[9]); A.r1_1 = mk2(ad[10], ad[11]); A.r2_1 = mk2(ad[12], ad[13]);
+        A.slotA = A.slotB = 0;
         if (A.key != ARB_FREE_KEY) {
             const double4 m1 = E.mass[A.key >> 16], m2 = E.mass[A.key & 0xFFFFu];
             A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
@@ -202,21 +206,43 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             L.sw[0] = mk2(act, L.sw[0].y);
         }
         __syncthreads();
-        // moving list: every body with a non-zero velocity
+        // moving list: every body with a non-zero velocity gets a velocity slot (the ship owns slot 0)
         int n = 0;
         for (int base = 0; base < E.nb; base += 64) {
             const int i = base + lane;
             bool mvg = false;
+            d2 v = mk2(0.0, 0.0), w2 = v, vb = v;
             if (i < E.nb) {
-                const d2 v = L.sv[i], w2 = L.sw[i], vb = L.sb[i];
+                if (i == 0) { v = L.sv[0]; w2 = L.sw[0]; vb = L.sb[0]; }
+                else { v = D.velv[eb + i]; w2 = D.velw[eb + i]; vb = D.velb[eb + i]; }
                 mvg = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
             }
             const unsigned long long m = ballot(mvg);
+            const unsigned long long ms = ballot(mvg && i != 0);
             if (mvg) { const int pos = n + popc_below(m, lane); if (pos < P.mvcap) L.mv[pos] = (unsigned short)i; }
+            if (mvg && i != 0) {
+                int sl = S.nslots + popc_below(ms, lane);
+                if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
+                L.slot_of[i] = (unsigned char)sl;
+                L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb;
+            }
             n += __popcll(m);
+            S.nslots = min(S.nslots + __popcll(ms), BP_NSLOT);
         }
         if (n > P.mvcap) { S.err |= BP_ERR_ARB_OVERFLOW; n = P.mvcap; }
         S.nmv = n;
+        lds_sync();
+        // velocity slots for the bodies of the persisted arbiters
+        {
+            unsigned long long m = ballot(A.key != ARB_FREE_KEY);
+            while (m) {
+                const int l = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
+                const int s1 = slot_get(L, S, (int)(key >> 16)), s2 = slot_get(L, S, (int)(key & 0xFFFFu));
+                if (lane == l) { A.slotA = s1; A.slotB = s2; }
+            }
+        }
         __syncthreads();
     }
 
@@ -224,6 +250,24 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     for (int it = 0; it < nsub; it++) {
         substep(P, D, E, L, A, S, P.dt_sub, mode == MODE_STEP);
+        if (S.quiescent && D.dbg == nullptr) {
+            // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
+            // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active
+            // arbiters are re-stamped (FIRST -> NORMAL), cached ones age out after `persistence` sub-steps, and the
+            // post-solve callback keeps counting the (cold) ship arbiters.
+            const unsigned k = (unsigned)(nsub - 1 - it);
+            if (k > 0) {
+                const unsigned now = S.stamp;
+                if (A.key != ARB_FREE_KEY) {
+                    if (A.stamp == now) { A.stamp = now + k; A.state = ARB_NORMAL; }
+                    else if ((now + k) - A.stamp >= (unsigned)P.persistence) A.key = ARB_FREE_KEY;
+                }
+                S.stamp = now + k;
+                S.n_post += k * S.ship_post;
+                S.n_contact += k * S.ship_contacts;
+            }
+            break;
+        }
         if (D.dbg != nullptr && env == D.dbg_env) {
             for (int base = 0; base < E.nb; base += 64) {
                 const int i = base + lane;
@@ -271,7 +315,11 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     // ---- write back persistent state ----
     for (int base = 0; base < nbcap; base += 64) {
         const int i = base + lane;
-        if (i < nbcap) { D.velv[eb + i] = L.sv[i]; D.velw[eb + i] = L.sw[i]; D.velb[eb + i] = L.sb[i]; }
+        if (i < nbcap) {
+            const int sl = L.slot_of[i];
+            const d2 z = mk2(0.0, 0.0);
+            D.velv[eb + i] = (sl != 255) ? L.sv[sl] : z; D.velw[eb + i] = (sl != 255) ? L.sw[sl] : z; D.velb[eb + i] = (sl != 255) ? L.sb[sl] : z;
+        }
     }
     {
         const size_t ab = (size_t)env * BP_ACAP + lane;

@@ -34,6 +34,7 @@ struct ArbReg {
     double nMass0, tMass0, bias0, bounce0, jBias0;
     double nMass1, tMass1, bias1, bounce1, jBias1;
     double ma, ia, mb, ib;
+    int slotA, slotB;          // velocity slots of the two bodies
 };
 
 struct EnvCtx {
@@ -49,7 +50,8 @@ struct EnvCtx {
 };
 
 struct LdsCtx {
-    d2 *sv, *sw, *sb;          // [nbcap] (vx,vy) (w,w_bias) (vbx,vby)
+    d2 *sv, *sw, *sb;          // [BP_NSLOT] (vx,vy) (w,w_bias) (vbx,vby) of the bodies that hold a velocity slot
+    unsigned char *slot_of;    // [nbcap] velocity slot of a body, 255 = none (velocity is exactly zero)
     unsigned *mvs;             // [nbcap] stamp of the sub-step in which the body last moved
     unsigned short *owner;     // [nbcap]
     unsigned short *colmask;   // [nbcap] colours already used at a body (solve-order colouring)
@@ -63,22 +65,43 @@ struct LdsCtx {
     unsigned char *pl_na, *pl_nb;                // [64]
     d2 *mbox;                  // [BP_MBOX][6] manifold mailbox
 };
-#define BP_MBOX 32
+#define BP_MBOX 16
+#define BP_NSLOT 96
 
 struct SubState {
     unsigned stamp;
     double curr_dt;
     int nmv;
+    int nslots;
     unsigned long long prev_amask;
     int nlevels;
     double total_ke, total_imp;
     unsigned n_post, n_contact, n_first;
     int err;
     int yaw_violated, boundary_violated;
+    int quiescent;             // set by substep(): nothing moves and no arbiter is warm -> later sub-steps are no-ops
+    unsigned ship_post, ship_contacts; // per-sub-step bookkeeping increments of the (cold) ship arbiters
 #ifdef BP_PROF
     unsigned long long prof[24];
 #endif
 };
+
+// Velocity slot of `body` (wave-uniform call): allocate a zeroed one on first use.  Slot 0 is the ship.
+__device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, int body)
+{
+    int s = L.slot_of[body];
+    if (s == 255) {
+        s = S.nslots;
+        if (s >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; s = BP_NSLOT - 1; }
+        else S.nslots = s + 1;
+        if (lane_id() == 0) {
+            L.slot_of[body] = (unsigned char)s;
+            L.sv[s] = mk2(0.0, 0.0); L.sw[s] = mk2(0.0, 0.0); L.sb[s] = mk2(0.0, 0.0);
+        }
+        lds_sync();
+    }
+    return s;
+}
 
 struct Manifold { int count; d2 n; d2 p1_0, p2_0, p1_1, p2_1; unsigned h0, h1; int newhint; };
 
@@ -193,7 +216,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         const int k = k0 + lane;
         if (k < S.nmv) {
             const int i = L.mv[k];
-            const d2 v = L.sv[i], w2 = L.sw[i], vb = L.sb[i];
+            const int sl = L.slot_of[i];
+            d2 v = mk2(0.0, 0.0), w2 = mk2(0.0, 0.0), vb = mk2(0.0, 0.0);
+            if (sl != 255) { v = L.sv[sl]; w2 = L.sw[sl]; vb = L.sb[sl]; }
             d2 p = E.pxy[i];
             p.x = p.x + (v.x + vb.x) * dt;
             p.y = p.y + (v.y + vb.y) * dt;
@@ -202,8 +227,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             d2 r = E.rot[i];
             if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
             E.pxy[i] = p; E.ang[i] = a2; E.rot[i] = r;
-            L.sb[i] = mk2(0.0, 0.0);
-            L.sw[i] = mk2(w2.x, 0.0);
+            if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(w2.x, 0.0); }
             const double4 ms = E.mass[i];
             double4 t;
             t.x = r.x; t.y = r.y;
@@ -468,6 +492,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         const unsigned long long dm = ballot(valid && M.count > 0);
         const int drank = popc_below(dm, lane);
         const int ndel = __popcll(dm);
+        lds_sync(); // the mailbox aliases the plane-search scratch: all reads of it are done
         for (int dbase = 0; dbase < ndel; dbase += BP_MBOX) {
             const bool mine = valid && M.count > 0 && drank >= dbase && drank < dbase + BP_MBOX;
             if (mine) {
@@ -491,7 +516,12 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                     if (!om) { S.err |= BP_ERR_ARB_OVERFLOW; }
                     else {
                         const int owner = __ffsll((long long)om) - 1;
-                        if (lane == owner) { my_mb = dr - dbase; fresh = fr; A.key = key; }
+                        int s1 = 0, s2 = 0;
+                        if (fr) { s1 = slot_get(L, S, (int)(key >> 16)); s2 = slot_get(L, S, (int)(key & 0xFFFFu)); }
+                        if (lane == owner) {
+                            my_mb = dr - dbase; fresh = fr; A.key = key;
+                            if (fr) { A.slotA = s1; A.slotB = s2; }
+                        }
                     }
                 }
                 dr++;
@@ -547,8 +577,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     // ---- 6a. prestep (cpArbiterPreStep) -----------------------------------------------------------------------
     if (active) {
         const d2 pa = E.pxy[ba], pb = E.pxy[bbi];
-        const d2 va = L.sv[ba], vb = L.sv[bbi];
-        const double wa = L.sw[ba].x, wb = L.sw[bbi].x;
+        const d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
+        const double wa = L.sw[A.slotA].x, wb = L.sw[A.slotB].x;
         const d2 n = A.n;
         const d2 body_delta = vsub(pb, pa);
         const d2 t = vperp(n);
@@ -584,8 +614,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     if (active) {
         warm = (A.jn0 != 0.0) || (A.jt0 != 0.0) || (A.bias0 != 0.0) || (A.bounce0 != 0.0);
         if (A.count > 1) warm = warm || (A.jn1 != 0.0) || (A.jt1 != 0.0) || (A.bias1 != 0.0) || (A.bounce1 != 0.0);
-        if (A.ma == 0.0) { const d2 v = L.sv[ba]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[ba].x != 0.0); }
-        if (A.mb == 0.0) { const d2 v = L.sv[bbi]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[bbi].x != 0.0); }
+        if (A.ma == 0.0) { const d2 v = L.sv[A.slotA]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotA].x != 0.0); }
+        if (A.mb == 0.0) { const d2 v = L.sv[A.slotB]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotB].x != 0.0); }
         if (A.ma != 0.0) L.owner[ba] = 0;
         if (A.mb != 0.0) L.owner[bbi] = 0;
     }
@@ -645,7 +675,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         const int k = k0 + lane;
         if (k < S.nmv) {
             const int i = L.mv[k];
-            if (E.mass[i].x != 0.0) { L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, L.sw[i].y); }
+            const int sl = L.slot_of[i];
+            if (sl != 255 && E.mass[i].x != 0.0) { L.sv[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(0.0, L.sw[sl].y); }
         }
     }
     __syncthreads();
@@ -658,8 +689,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     for (int lvl = 1; lvl <= nlevels; lvl++) {
         if (!(lvlmask & (1u << lvl))) continue;
         if (warm && A.level == lvl && A.state != ARB_FIRST) {
-            d2 va = L.sv[ba], vb = L.sv[bbi];
-            d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
+            d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
+            d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
             {
                 const d2 j = vmul(vrotate(A.n, mk2(A.jn0, A.jt0)), dt_coef);
                 apply_contact_impulses(A, 0, va, wa2.x, vb, wb2.x, j);
@@ -668,8 +699,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                 const d2 j = vmul(vrotate(A.n, mk2(A.jn1, A.jt1)), dt_coef);
                 apply_contact_impulses(A, 1, va, wa2.x, vb, wb2.x, j);
             }
-            if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; }
-            if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; }
+            if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; }
+            if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; }
         }
         lds_sync();
     }
@@ -680,10 +711,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         for (int lvl = 1; lvl <= nlevels; lvl++) {
             if (!(lvlmask & (1u << lvl))) continue;
             if (warm && A.level == lvl) {
-                d2 va = L.sv[ba], vb = L.sv[bbi];
-                d2 wa2 = L.sw[ba], wb2 = L.sw[bbi];
+                d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
+                d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
                 d2 vba = mk2(0.0, 0.0), vbb = mk2(0.0, 0.0);
-                if (any_bias) { vba = L.sb[ba]; vbb = L.sb[bbi]; }
+                if (any_bias) { vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
                 const d2 n = A.n;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -727,8 +758,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                         apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
                     }
                 }
-                if (A.ma != 0.0) { L.sv[ba] = va; L.sw[ba] = wa2; if (any_bias) L.sb[ba] = vba; }
-                if (A.mb != 0.0) { L.sv[bbi] = vb; L.sw[bbi] = wb2; if (any_bias) L.sb[bbi] = vbb; }
+                if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; if (any_bias) L.sb[A.slotA] = vba; }
+                if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; if (any_bias) L.sb[A.slotB] = vbb; }
             }
             lds_sync();
         }
@@ -741,6 +772,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     {
         const bool shiparb = active && ba == 0;
         const unsigned long long sm = ballot(shiparb);
+        S.ship_post = (unsigned)__popcll(sm);
+        S.ship_contacts = (unsigned)__popcll(sm) + (unsigned)__popcll(ballot(shiparb && A.count > 1));
         if (sm) {
             // integer bookkeeping is order-free; cold arbiters add exactly +0 to the float sums
             S.n_post += (unsigned)__popcll(sm);
@@ -788,11 +821,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         bool wantA = false, wantB = false;
         if (active) {
             if (A.ma != 0.0) {
-                const d2 v = L.sv[ba], w2 = L.sw[ba], vb = L.sb[ba];
+                const d2 v = L.sv[A.slotA], w2 = L.sw[A.slotA], vb = L.sb[A.slotA];
                 wantA = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
             }
             if (A.mb != 0.0) {
-                const d2 v = L.sv[bbi], w2 = L.sw[bbi], vb = L.sb[bbi];
+                const d2 v = L.sv[A.slotB], w2 = L.sw[A.slotB], vb = L.sb[A.slotB];
                 wantB = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
             }
         }
@@ -811,6 +844,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         if (gotB) L.mv[shipmv + nA_ + popc_below(mB, lane)] = (unsigned short)bbi;
         S.nmv = shipmv + nA_ + __popcll(mB);
     }
+    S.quiescent = (S.nmv == 0) && (wmask == 0);
     __syncthreads();
     PROF_ACC(9)
     (void)refresh_any;
