@@ -15,7 +15,7 @@ INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scale
              "n_contact_pts", "n_first_contact"]
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_reset", "bp_step", "bp_step_physics",
-           "bp_observe", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
+           "bp_observe", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_last_error"]
 
 
@@ -76,6 +76,7 @@ def load():
     L.bp_last_error.argtypes = [vp]
     L.bp_last_error.restype = C.c_char_p
     L.bp_debug_trace.argtypes = [vp, vp, C.c_int32]
+    L.bp_set_resettle.argtypes = [vp, C.c_int32]
     L.bp_debug_prof.argtypes = [vp, vp]
     _lib = L
     return L

@@ -19,6 +19,7 @@ struct bp_handle {
     int nbcap = 0;
     int num_trials = 0;
     bool loaded = false, was_reset = false;
+    bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -201,7 +202,8 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     HIPCHK(h, hipMemcpy(d_pose, h_pose.data(), sizeof(double4) * h_pose.size(), hipMemcpyHostToDevice));
     D.sc_nb = d_nb; D.sc_nv = d_nv; D.sc_lv = d_lv; D.sc_ln = d_ln; D.sc_mass = d_mass; D.sc_pose = d_pose;
 
-    const size_t E = (size_t)h->num_envs, EB = E * nbcap;
+    // per-env state for the E envs plus T settled reset templates (slot E + t = trial t)
+    const size_t E = (size_t)h->num_envs + (size_t)T, EB = E * nbcap;
     if ((rc = dalloc(h, &D.e_trial, E))) return rc;
     if ((rc = dalloc(h, &D.e_episode, E, 0xFF))) return rc; // -1
     if ((rc = dalloc(h, &D.e_nb, E))) return rc;
@@ -236,6 +238,10 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    // settle every trial once (new space + bodies + 1000 sub-steps, ship_ice_env.py:109-220); reset() copies from these
+    hipLaunchKernelGGL(k_physics_reset, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipDeviceSynchronize());
     h->loaded = true;
     return BP_OK;
 }
@@ -255,8 +261,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
     if (physics) {
         if (mode == MODE_STEP)
             hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (h->resettle)
+            hipLaunchKernelGGL(k_physics_reset, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mask, info, 0);
         else
-            hipLaunchKernelGGL(k_physics_reset, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mask, info);
+            hipLaunchKernelGGL(k_reset_copy, dim3(h->num_envs), dim3(256), 0, st, h->P, h->D, mask, info);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
@@ -437,6 +445,15 @@ int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32
     if (raster_ms) *raster_ms = n ? r / n : 0.0;
     if (launches) *launches = n;
     h->ev_used = 0;
+    return BP_OK;
+}
+
+// reset() normally copies the per-trial settled template (a pure function of the trial); on != 0 makes it re-run the
+// 1000 settle sub-steps in place like the reference does (same result; used by the tests to prove that).
+int bp_set_resettle(bp_handle *h, int32_t on)
+{
+    if (!h) return BP_EINVAL;
+    h->resettle = on != 0;
     return BP_OK;
 }
 

@@ -35,11 +35,12 @@ template <int mode>
 __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
-                                             double *__restrict__ info)
+                                             double *__restrict__ info, const int tmpl)
 {
-    const int env = blockIdx.x;
+    // MODE_RESET with tmpl != 0 settles the per-trial reset templates: state slot num_envs + t holds trial t
+    const int env = (mode == MODE_RESET && tmpl) ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
     const int lane = lane_id();
-    if (mode == MODE_RESET && mask != nullptr && mask[env] == 0) return;
+    if (mode == MODE_RESET && !tmpl && mask != nullptr && mask[env] == 0) return;
     const int nbcap = P.nbcap;
 
     // ---- carve LDS ----
@@ -77,7 +78,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     int trial, episode;
     if (mode == MODE_RESET) {
         episode = D.e_episode[env] + 1; // first reset: -1 -> 0 (ship_ice_env.py:226-229)
-        trial = (int)(((long long)P.env_offset + env + episode) % P.num_trials);
+        trial = tmpl ? (int)blockIdx.x : (int)(((long long)P.env_offset + env + episode) % P.num_trials);
     } else {
         episode = D.e_episode[env];
         trial = D.e_trial[env];
@@ -398,13 +399,67 @@ __global__ __launch_bounds__(64) void k_physics_step(const DevParams P, const De
                                                      double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                      unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
-    physics_body<MODE_STEP>(P, D, actions, nullptr, reward, terminated, truncated, info);
+    physics_body<MODE_STEP>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
 }
 // reset() of the masked envs: new space from the next trial + 1000 settle sub-steps
 __global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
-                                                      double *__restrict__ info)
+                                                      double *__restrict__ info, const int tmpl)
 {
-    physics_body<MODE_RESET>(P, D, nullptr, mask, nullptr, nullptr, nullptr, info);
+    physics_body<MODE_RESET>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+}
+
+// reset() from the settled per-trial template (ship_ice_env.py:223-249 is a pure function of the trial when
+// random_start is off): copy the template state of trial (global_env_id + episode) % T into the env.
+template <typename T>
+__device__ __forceinline__ void copy_span(T *dst, const T *src, size_t n, int tid, int nt)
+{
+    for (size_t i = tid; i < n; i += nt) dst[i] = src[i];
+}
+__global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                    double *__restrict__ info)
+{
+    const int env = blockIdx.x;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int episode = D.e_episode[env] + 1;
+    const int trial = (int)(((long long)P.env_offset + env + episode) % P.num_trials);
+    const size_t nb = P.nbcap, d = (size_t)env * nb, s = (size_t)(P.num_envs + trial) * nb;
+    copy_span(D.pxy + d, D.pxy + s, nb, tid, nt);
+    copy_span(D.ang + d, D.ang + s, nb, tid, nt);
+    copy_span(D.rot + d, D.rot + s, nb, tid, nt);
+    copy_span(D.velv + d, D.velv + s, nb, tid, nt);
+    copy_span(D.velw + d, D.velw + s, nb, tid, nt);
+    copy_span(D.velb + d, D.velb + s, nb, tid, nt);
+    copy_span(D.wv + d * BP_MAXV, D.wv + s * BP_MAXV, nb * BP_MAXV, tid, nt);
+    copy_span(D.wn + d * BP_MAXV, D.wn + s * BP_MAXV, nb * BP_MAXV, tid, nt);
+    copy_span(D.pv + d * BP_MAXV, D.pv + s * BP_MAXV, nb * BP_MAXV, tid, nt);
+    copy_span(D.bb + d, D.bb + s, nb, tid, nt);
+    copy_span(D.fat + d, D.fat + s, nb, tid, nt);
+    copy_span((unsigned long long *)(D.adj + d * BP_KADJ), (const unsigned long long *)(D.adj + s * BP_KADJ), nb * BP_KADJ / 4, tid, nt);
+    copy_span((unsigned long long *)(D.hint + d * BP_KADJ), (const unsigned long long *)(D.hint + s * BP_KADJ), nb * BP_KADJ / 8, tid, nt);
+    copy_span((unsigned long long *)(D.adjn + d), (const unsigned long long *)(D.adjn + s), nb / 8, tid, nt);
+    const size_t ad = (size_t)env * BP_ACAP, as = (size_t)(P.num_envs + trial) * BP_ACAP;
+    copy_span(D.a_key + ad, D.a_key + as, BP_ACAP, tid, nt);
+    copy_span(D.a_stamp + ad, D.a_stamp + as, BP_ACAP, tid, nt);
+    copy_span(D.a_sc + ad, D.a_sc + as, BP_ACAP, tid, nt);
+    copy_span(D.a_h0 + ad, D.a_h0 + as, BP_ACAP, tid, nt);
+    copy_span(D.a_h1 + ad, D.a_h1 + as, BP_ACAP, tid, nt);
+    copy_span(D.a_d + ad * 14, D.a_d + as * 14, (size_t)BP_ACAP * 14, tid, nt);
+    if (tid == 0) {
+        const int se = P.num_envs + trial;
+        D.e_trial[env] = trial; D.e_episode[env] = episode; D.e_nb[env] = D.e_nb[se];
+        D.e_stamp[env] = D.e_stamp[se]; D.e_currdt[env] = D.e_currdt[se];
+        D.e_total_work[env] = 0.0; D.e_ke[env] = D.e_ke[se]; D.e_imp[env] = D.e_imp[se];
+        for (int q = 0; q < 4; q++) D.e_cnt[env * 4 + q] = D.e_cnt[se * 4 + q];
+        if (D.e_err[se]) atomicOr(&D.e_err[env], D.e_err[se]);
+        if (info) {
+            double *o = info + (size_t)env * BP_INFO_COUNT;
+            for (int q = 0; q < BP_INFO_COUNT; q++) o[q] = 0.0;
+            o[BP_I_X] = D.pxy[s].x; o[BP_I_Y] = D.pxy[s].y; o[BP_I_THETA] = D.ang[s];
+            o[BP_I_KE] = D.e_ke[se]; o[BP_I_IMPULSE] = D.e_imp[se];
+            o[BP_I_NPOST] = (double)D.e_cnt[se * 4 + 0]; o[BP_I_NCONTACT] = (double)D.e_cnt[se * 4 + 1]; o[BP_I_NFIRST] = (double)D.e_cnt[se * 4 + 2];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -153,6 +153,10 @@ class BatchedShipIceEnv:
             raise _lib.BpError("capacity overflow in envs %s: %s" % (np.nonzero(out)[0][:8].tolist(),
                                                                      self.L.bp_last_error(self.h).decode()))
 
+    def set_resettle(self, on=True):
+        """Re-run the 1000 settle sub-steps on every reset instead of copying the settled per-trial template."""
+        self.L.bp_set_resettle(self.h, int(on))
+
     def enable_timing(self, on=True):
         self.L.bp_enable_timing(self.h, int(on))
 

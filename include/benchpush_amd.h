@@ -109,6 +109,10 @@ int bp_reset(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, double *info, 
 int bp_step(bp_handle *h, const double *actions, uint8_t *obs, double *reward, uint8_t *terminated,
             uint8_t *truncated, double *info, void *stream);
 
+/* reset() copies a per-trial template that was settled once at load time (the reference's reset is a pure function of
+ * the trial when cfg.random_start is off); on != 0 re-runs the settle sub-steps in place instead (identical result). */
+int bp_set_resettle(bp_handle *h, int32_t on);
+
 /* Physics only / raster only halves of bp_step (profiling and tests). */
 int bp_step_physics(bp_handle *h, const double *actions, double *reward, uint8_t *terminated, uint8_t *truncated,
                     double *info, void *stream);
