@@ -41,38 +41,21 @@ def algorithmic_bytes_per_env_step(nb, nf, maxv=20, obs_bytes=4 * 150 * 150):
     return a_min, a_stream, state + geom + scal
 
 
-def cpu_baseline(env, trials, seconds_hint=15.0):
-    """Oracle (CPU restatement) timed on the host cores of this box on a bounded sample of the same workload."""
-    from concurrent.futures import ThreadPoolExecutor
-
-    from oracle.oracle import OracleShipIce
+def cpu_baseline(env, trials):
+    """Oracle (CPU restatement, oracle/bp_oracle.c) timed on the host cores of this box, OpenMP over envs, on a bounded
+    sample of the same workload: same trials, same 400 sub-steps x 10 iterations + observation raster per env.step()."""
+    from benchpush_amd.scenario import pack_trials
+    from oracle import oracle as orc
 
     cores = os.cpu_count() or 1
-    per_thread_envs, steps = 1, 12
+    nenv, steps = 2 * cores, 10
+    pk = pack_trials(trials[: min(len(trials), nenv)], max_verts=24)
     cfg = env.cfg
-
-    def work(tid):
-        rng = np.random.default_rng(1000 + tid)
-        n = 0
-        for k in range(per_thread_envs):
-            o = OracleShipIce(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
-            o.reset(trials[(tid * per_thread_envs + k) % len(trials)])
-            for _ in range(steps):
-                _, _, term, _ = o.step(float(np.float32(rng.uniform(-1, 1))))
-                n += 1
-                if term:
-                    o.reset(trials[(tid + n) % len(trials)])
-        return n
-
-    # one untimed call so the library is built/loaded
-    OracleShipIce(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
-    t0 = time.time()
-    with ThreadPoolExecutor(cores) as ex:
-        total = sum(ex.map(work, range(cores)))
-    dt = time.time() - t0
-    return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d threads x %d env x %d env.step() (+reset incl. 1000 settle sub-steps) of the same 30%% "
-                      "ship-ice trials, oracle/bp_oracle.c, %.1f s wall" % (cores, per_thread_envs, steps, dt)}
+    orc.bench(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail, pk, min(nenv, 4), 1, cores)  # warm the library
+    n, sec = orc.bench(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail, pk, nenv, steps, cores)
+    return {"value": n / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d envs x %d env.step() (30%% ship-ice trials, 400 sub-steps x 10 iterations + raster each), OpenMP on %d "
+                      "threads, step loop only (resets untimed), %.2f s wall = %.0f core-seconds" % (nenv, steps, cores, sec, sec * cores)}
 
 
 def main():

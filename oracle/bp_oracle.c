@@ -39,6 +39,9 @@
 #include <string.h>
 #include <float.h>
 #include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 
 #define ORC_MAXV 24
 #define ORC_OBS_C 4
@@ -1276,4 +1279,59 @@ void orc_crop(const orc_params *P, const double *state, const double *gmap, doub
             if (!(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg)) v = gmap[(size_t)gi * Wg + gj];
             out[(size_t)li * LW + lj] = (uint8_t)(v * 255);
         }
+}
+
+/* ---- CPU baseline driver (bench.py cpu_baseline leg): nenv oracle envs stepped nsteps times on nthreads cores ----- */
+/* Trials in the packed layout of benchpush_amd.scenario.pack_trials.  Env e plays trial e % T with actions from a
+ * 64-bit LCG in [-1, 1).  Only the env.step() loop is timed (resets, incl. their 1000 settle sub-steps, are not).
+ * Returns wall seconds of the step loop; *out_steps = env-steps executed. */
+double orc_bench(const orc_params *P, int T, int F, int V, const double *verts, const int *counts, const double *centres,
+                 const double *starts, const int *nfloes, int nsv, const double *ship_verts, const double *head,
+                 const double *tail, int nenv, int nsteps, int nthreads, int with_obs, long *out_steps)
+{
+    orc_env **envs = (orc_env **)calloc((size_t)nenv, sizeof(orc_env *));
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int e = 0; e < nenv; e++) {
+        int t = e % T;
+        int nf = nfloes[t];
+        double *fv = (double *)malloc(sizeof(double) * 2 * (size_t)V * (size_t)(nf > 0 ? nf : 1));
+        int off = 0;
+        for (int f = 0; f < nf; f++) {
+            int n = counts[(size_t)t * F + f];
+            memcpy(fv + 2 * (size_t)off, verts + ((size_t)t * F + f) * V * 2, sizeof(double) * 2 * (size_t)n);
+            off += n;
+        }
+        envs[e] = orc_create(P);
+        orc_reset(envs[e], nf, fv, counts + (size_t)t * F, centres + (size_t)t * F * 2, nsv, ship_verts, head, tail, starts + 3 * t);
+        free(fv);
+    }
+    long total = 0;
+    double t0 = 0.0, t1 = 0.0;
+#ifdef _OPENMP
+    t0 = omp_get_wtime();
+#endif
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total)
+    for (int e = 0; e < nenv; e++) {
+        uint64_t st = 0x9E3779B97F4A7C15ull * (uint64_t)(e + 1);
+        uint8_t *obs = with_obs ? (uint8_t *)malloc(4 * 150 * 150) : NULL;
+        for (int k = 0; k < nsteps; k++) {
+            st = st * 6364136223846793005ull + 1442695040888963407ull;
+            double a = (double)(float)(((double)(st >> 11) / 9007199254740992.0) * 2.0 - 1.0);
+            double r; int term;
+            orc_step(envs[e], a, obs, &r, &term, NULL);
+            total++;
+            if (term) break;
+        }
+        free(obs);
+    }
+#ifdef _OPENMP
+    t1 = omp_get_wtime();
+#endif
+    for (int e = 0; e < nenv; e++) orc_destroy(envs[e]);
+    free(envs);
+    if (out_steps) *out_steps = total;
+    return t1 - t0;
 }

@@ -69,6 +69,10 @@ def lib():
         L.orc_total_work.restype = C.c_double
         L.orc_total_work.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_crop.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_bench.restype = C.c_double
+        L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.POINTER(C.c_long)]
         _lib = L
     return _lib
 
@@ -212,3 +216,19 @@ def crop(params, state, gmap, oob_val=0.0):
     out = np.zeros((int(params["local_h"] * params["m_to_pix"]), int(params["local_w"] * params["m_to_pix"])), np.uint8)
     lib().orc_crop(C.byref(p), _p(st), _p(g), float(oob_val), _p(out))
     return out
+
+
+def bench(params, ship_vertices, head, tail, packed, nenv, nsteps, nthreads, with_obs=True):
+    """Time nenv oracle envs x nsteps env.step() on nthreads cores (OpenMP). Returns (env_steps, seconds)."""
+    p = OrcParams()
+    for k, v in params.items():
+        setattr(p, k, v)
+    sv = np.ascontiguousarray(ship_vertices, np.float64)
+    hd = np.ascontiguousarray(head, np.float64)
+    tl = np.ascontiguousarray(tail, np.float64)
+    T, F, V = packed["verts"].shape[:3]
+    n = C.c_long()
+    sec = lib().orc_bench(C.byref(p), T, F, V, _p(packed["verts"]), _p(packed["counts"]), _p(packed["centres"]),
+                          _p(packed["starts"]), _p(packed["nfloes"]), len(sv), _p(sv), _p(hd), _p(tl), int(nenv), int(nsteps),
+                          int(nthreads), int(with_obs), C.byref(n))
+    return n.value, sec
