@@ -19,6 +19,8 @@ struct bp_handle {
     int nbcap = 0;
     int num_trials = 0;
     bool loaded = false, was_reset = false;
+    int *order_buf = nullptr;
+    bool steps_done = false;
     bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
     DevParams P;
     DevPtrs D;
@@ -214,6 +216,9 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     if ((rc = dalloc(h, &D.e_ke, E))) return rc;
     if ((rc = dalloc(h, &D.e_imp, E))) return rc;
     if ((rc = dalloc(h, &D.e_cnt, E * 4))) return rc;
+    if ((rc = dalloc(h, &D.e_cost, E))) return rc;
+    if ((rc = dalloc(h, &h->order_buf, E))) return rc;
+    D.order = nullptr;
     if ((rc = dalloc(h, &D.pxy, EB))) return rc;
     if ((rc = dalloc(h, &D.ang, EB))) return rc;
     if ((rc = dalloc(h, &D.rot, EB))) return rc;
@@ -259,6 +264,12 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         HIPCHK(h, hipEventRecord(e0, st));
     }
     if (physics) {
+        if (mode == MODE_STEP && h->steps_done) { // heaviest-first dispatch order from the previous step's per-env cycles
+            hipLaunchKernelGGL(k_make_order, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->order_buf, h->num_envs);
+            HIPCHK(h, hipGetLastError());
+            h->D.order = h->order_buf;
+        }
+        if (mode == MODE_STEP) h->steps_done = true;
         if (mode == MODE_STEP)
             hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (h->resettle)

@@ -42,6 +42,8 @@ struct DevPtrs {
     unsigned *e_stamp;
     double *e_currdt, *e_total_work, *e_ke, *e_imp;
     unsigned *e_cnt;         // [E][4] n_post_solve, n_contact_pts, n_first_contact, -
+    unsigned *e_cost;        // [E] wave cycles (>>8) the env's last step took: dispatch-order hint only
+    const int *order;        // [E] env handled by workgroup b (heaviest first), or null = identity
     d2 *pxy;                 // [E][nbcap] position of COG
     double *ang;             // [E][nbcap]
     d2 *rot;                 // [E][nbcap] cos, sin

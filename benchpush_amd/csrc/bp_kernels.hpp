@@ -38,7 +38,9 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
                                              double *__restrict__ info, const int tmpl)
 {
     // MODE_RESET with tmpl != 0 settles the per-trial reset templates: state slot num_envs + t holds trial t
-    const int env = (mode == MODE_RESET && tmpl) ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
+    const int env = (mode == MODE_RESET) ? (tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x)
+                                         : (D.order != nullptr ? D.order[blockIdx.x] : (int)blockIdx.x);
+    const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = lane_id();
     if (mode == MODE_RESET && !tmpl && mask != nullptr && mask[env] == 0) return;
     const int nbcap = P.nbcap;
@@ -344,6 +346,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         const d2 sp = E.pxy[0];
         const double sa = E.ang[0];
         D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
+        if (mode == MODE_STEP) D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
         D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
         D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
         if (err_any) atomicOr(&D.e_err[env], err_any);
@@ -406,6 +409,39 @@ __global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const D
                                                       double *__restrict__ info, const int tmpl)
 {
     physics_body<MODE_RESET>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+}
+
+// Dispatch order for the next step: envs sorted by the cycles their last step took, heaviest first (bucket sort).
+// Workgroups start in index order, so the long-running environments start first and the launch tail shrinks.
+// The order only permutes independent environments: results do not depend on it.
+__global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict__ cost, int *__restrict__ order, int n)
+{
+    __shared__ unsigned hist[257];
+    __shared__ unsigned smax;
+    const int tid = threadIdx.x;
+    if (tid < 257) hist[tid] = 0;
+    if (tid == 0) smax = 1;
+    __syncthreads();
+    unsigned mx = 0;
+    for (int i = tid; i < n; i += blockDim.x) mx = max(mx, cost[i]);
+    atomicMax(&smax, mx);
+    __syncthreads();
+    const unsigned long long m = smax;
+    for (int i = tid; i < n; i += blockDim.x) {
+        const unsigned b = 255u - (unsigned)(((unsigned long long)cost[i] * 255ull) / m);
+        atomicAdd(&hist[b], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        unsigned acc = 0;
+        for (int b = 0; b < 256; b++) { const unsigned c = hist[b]; hist[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const unsigned b = 255u - (unsigned)(((unsigned long long)cost[i] * 255ull) / m);
+        const unsigned pos = atomicAdd(&hist[b], 1u);
+        order[pos] = i;
+    }
 }
 
 // reset() from the settled per-trial template (ship_ice_env.py:223-249 is a pure function of the trial when
