@@ -25,7 +25,7 @@ struct bp_handle {
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0, obs_lds_bytes = 0;
     std::string err;
     // timing
     bool timing = false;
@@ -112,6 +112,9 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     P.grid_h = (int)(cfg->map_h / grid);
     P.obs_h = (int)(cfg->local_h * cfg->m_to_pix);
     P.obs_w = (int)(cfg->local_w * cfg->m_to_pix);
+    if ((P.obs_h * P.obs_w) % 4 != 0) { delete h; return BP_EINVAL; }
+    h->obs_lds_bytes = (size_t)((P.obs_h * P.obs_w + 15) & ~15) + (size_t)((P.obs_h + 15) & ~15) + sizeof(double) * 2 * OBS_MAXCAND * BP_MAXV;
+    if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
     *out = h;
     return BP_OK;
 }
@@ -280,7 +283,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     if (raster && obs) {
-        hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS), 0, st, h->P, h->D, mask, obs);
+        hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e2, st));

@@ -508,43 +508,32 @@ __global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const Dev
 //   ch3 occupancy   skimage.draw.polygon of floes within 12 m, 25 px/m   occupancy_map.py:37-65,112-140
 // ------------------------------------------------------------------------------------------------------------
 #define OBS_THREADS 256
-#define OBS_MAXCAND 512
+#define OBS_MAXCAND 96      // floes whose pixel AABB meets the 150x150 window (6 m x 6 m; typically 15-40)
 
 // skimage._shared.geometry.point_in_polygon restated (third-party, unpinned): non-zero = inside / edge / vertex.
-// GETX/GETY fetch polygon vertex i in raster coordinates.
-#define BP_PIP_BODY(GETX, GETY)                                                                  \
-    const double eps = 1e-12;                                                                    \
-    unsigned l_cross = 0, r_cross = 0;                                                           \
-    double x1 = GETX(n - 1) - x, y1 = GETY(n - 1) - y;                                           \
-    for (int i = 0; i < n; i++) {                                                                \
-        const double x0 = GETX(i) - x, y0 = GETY(i) - y;                                         \
-        if ((-eps < x0 && x0 < eps) && (-eps < y0 && y0 < eps)) return true;                     \
-        if ((y0 > 0) != (y1 > 0)) {                                                              \
-            if (((x0 * y1 - x1 * y0) / (y1 - y0)) > 0) r_cross++;                                \
-        }                                                                                        \
-        if ((y0 < 0) != (y1 < 0)) {                                                              \
-            if (((x0 * y1 - x1 * y0) / (y1 - y0)) < 0) l_cross++;                                \
-        }                                                                                        \
-        x1 = x0; y1 = y0;                                                                        \
-    }                                                                                            \
-    if ((r_cross & 1) != (l_cross & 1)) return true;                                             \
-    return (r_cross & 1) != 0;
-
+// The crossing tests `(x0*y1 - x1*y0) / (y1 - y0) > 0` (`< 0`) are evaluated as sign tests: for the finite,
+// well-scaled raster coordinates here the quotient can neither overflow nor underflow, so it has the sign of
+// numerator * denominator (and is 0 exactly when the numerator is 0).  Bit-identical to the oracle's division.
 __device__ __forceinline__ bool pip_arrays(const double *xp, const double *yp, int n, double x, double y)
 {
-#define GX(i) xp[i]
-#define GY(i) yp[i]
-    BP_PIP_BODY(GX, GY)
-#undef GX
-#undef GY
-}
-__device__ __forceinline__ bool pip_scaled(const d2 *v, double scale, int n, double x, double y)
-{
-#define GX(i) (v[i].x * scale)
-#define GY(i) (v[i].y * scale)
-    BP_PIP_BODY(GX, GY)
-#undef GX
-#undef GY
+    const double eps = 1e-12;
+    unsigned l_cross = 0, r_cross = 0;
+    double x1 = xp[n - 1] - x, y1 = yp[n - 1] - y;
+    for (int i = 0; i < n; i++) {
+        const double x0 = xp[i] - x, y0 = yp[i] - y;
+        if ((-eps < x0 && x0 < eps) && (-eps < y0 && y0 < eps)) return true;
+        const bool up = (y0 > 0) != (y1 > 0), dn = (y0 < 0) != (y1 < 0);
+        if (up || dn) {
+            const double num = x0 * y1 - x1 * y0, den = y1 - y0;
+            const bool pos = (num > 0 && den > 0) || (num < 0 && den < 0);
+            const bool neg = (num > 0 && den < 0) || (num < 0 && den > 0);
+            if (up && pos) r_cross++;
+            if (dn && neg) l_cross++;
+        }
+        x1 = x0; y1 = y0;
+    }
+    if ((r_cross & 1) != (l_cross & 1)) return true;
+    return (r_cross & 1) != 0;
 }
 
 __device__ __forceinline__ long long to_u16(double v) { return ((long long)v) & 0xFFFF; }
@@ -631,27 +620,34 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
     const int nb = D.e_nb[env];
     const d2 *wv = D.wv + eb * BP_MAXV;
     const int *nv = D.sc_nv + (size_t)D.e_trial[env] * nbcap;
+    const int Hg = P.grid_h, Wg = P.grid_w, LH = P.obs_h, LW = P.obs_w;
+    const int npix = LH * LW;
 
+    extern __shared__ double2 obs_smem[];
+    // LDS: occupancy image [npix] u8 | goal-distance row table [LH] u8 | candidate polygons (raster coordinates)
+    unsigned char *s_occ = (unsigned char *)obs_smem;
+    unsigned char *s_edt = s_occ + ((npix + 15) & ~15);
+    double *s_px = (double *)(s_edt + ((LH + 15) & ~15));   // [OBS_MAXCAND][BP_MAXV]
+    double *s_py = s_px + OBS_MAXCAND * BP_MAXV;
     __shared__ int s_ncand;
-    __shared__ unsigned short s_cand[OBS_MAXCAND];
-    __shared__ int s_bbx[OBS_MAXCAND][4]; // minr, maxr, minc, maxc
+    __shared__ int s_bbx[OBS_MAXCAND][4]; // window-clipped pixel box: r0, r1, c0, c1 (global raster coordinates)
+    __shared__ unsigned char s_cn[OBS_MAXCAND];
     __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
     __shared__ int s_fcnt, s_fbb[4];
     if (tid == 0) s_ncand = 0;
+    for (int w = tid; w < (npix + 3) / 4; w += OBS_THREADS) ((unsigned *)s_occ)[w] = 0u;
     __syncthreads();
 
     const d2 sp = D.pxy[eb];
-    const double sa = D.ang[eb];
-    const d2 srot = D.rot[eb]; // (cos, sin) == bp_sincos(sa)
-    const int Hg = P.grid_h, Wg = P.grid_w, LH = P.obs_h, LW = P.obs_w;
+    const d2 srot = D.rot[eb]; // (cos, sin) == bp_sincos(angle)
     const double m2gx = (double)Wg / P.map_w, m2gy = (double)Hg / P.map_h;
-
-    // candidate floes: culling by |centroid| range (occupancy_map.py:44-49) + pixel bbox vs window
     const int wx = (int)(sp.x * m2gx);
     const int wy = (int)((sp.y + P.vshift) * m2gy);
+    // window rows/cols in global raster coordinates (occupancy_map.py:112-140): g = int(l + w - L/2)
     const int gi0 = (int)((double)(0 + wy) - ((double)LH / 2)), gj0 = (int)((double)(0 + wx) - ((double)LW / 2));
-    const int gi1 = (int)((double)(LH - 1 + wy) - ((double)LH / 2)), gj1 = (int)((double)(LW - 1 + wx) - ((double)LW / 2));
+    const int gi1 = gi0 + LH - 1, gj1 = gj0 + LW - 1;
     const int bh = (int)(P.map_h * P.m_to_pix), bw = (int)(P.map_w * P.m_to_pix);
+    // ---- candidate floes: |centroid| range culling (occupancy_map.py:44-49) + pixel box vs window ----
     for (int s = 1 + tid; s < nb; s += OBS_THREADS) {
         const int n = nv[s];
         const d2 *v = wv + (size_t)s * BP_MAXV;
@@ -670,11 +666,13 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
         if (maxr < gi0 || minr > gi1 || maxc < gj0 || minc > gj1 || maxr < minr || maxc < minc) continue;
         const int slot = atomicAdd(&s_ncand, 1);
         if (slot < OBS_MAXCAND) {
-            s_cand[slot] = (unsigned short)s;
-            s_bbx[slot][0] = (int)minr; s_bbx[slot][1] = (int)maxr; s_bbx[slot][2] = (int)minc; s_bbx[slot][3] = (int)maxc;
+            s_bbx[slot][0] = (int)max(minr, (long long)gi0); s_bbx[slot][1] = (int)min(maxr, (long long)gi1);
+            s_bbx[slot][2] = (int)max(minc, (long long)gj0); s_bbx[slot][3] = (int)min(maxc, (long long)gj1);
+            s_cn[slot] = (unsigned char)n;
+            for (int i = 0; i < n; i++) { s_px[slot * BP_MAXV + i] = v[i].x * P.m_to_pix; s_py[slot * BP_MAXV + i] = v[i].y * P.m_to_pix; }
         }
     }
-    // ship footprint polygon in grid coords (vertices outside the grid are dropped, occupancy_map.py:318-325)
+    // ---- ship footprint polygon in grid coordinates (vertices outside the grid are dropped, occupancy_map.py:318-325)
     LineSpec line;
     long long hpx, hpy;
     {
@@ -704,44 +702,61 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
         hpx = hpx < 0 ? 0 : (hpx > Wg - 1 ? Wg - 1 : hpx);
         hpy = hpy < 0 ? 0 : (hpy > Hg - 1 ? Hg - 1 : hpy);
     }
-    __syncthreads();
-    const int ncand = min(s_ncand, OBS_MAXCAND);
-    if (tid == 0 && s_ncand > OBS_MAXCAND) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+    // goal-distance value per window row (occupancy_map.py:413-433): max(0, goal - i*g2m)/goal, out of map -> 1
     const double g2m = P.map_h / (double)Hg;
-    const size_t plane = (size_t)LH * LW;
-    unsigned char *o = obs + (size_t)env * BP_OBS_C * plane;
-    (void)sa;
-    for (int px = tid; px < LH * LW; px += OBS_THREADS) {
-        const int li = px / LW, lj = px - li * LW;
-        const int gi = (int)((double)(li + wy) - ((double)LH / 2));
-        const int gj = (int)((double)(lj + wx) - ((double)LW / 2));
-        const bool inb = !(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg);
-        unsigned char f = 0, e = 255, orn = 0, oc = 0;
-        if (inb) {
-            // ch0
-            f = 127;
-            if (s_fcnt > 0 && gi >= s_fbb[0] && gi <= s_fbb[1] && gj >= s_fbb[2] && gj <= s_fbb[3]) {
-                if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) f = 255;
-            }
-            // ch1
+    for (int li = tid; li < LH; li += OBS_THREADS) {
+        const int gi = gi0 + li;
+        unsigned char e = 255;
+        if (gi >= 0 && gi < Hg) {
             double dd = P.goal_y - gi * g2m;
             if (dd < 0) dd = 0;
             e = (unsigned char)((dd / P.goal_y) * 255);
-            // ch2
-            if (on_line(line, gj, gi)) orn = 127;
-            if (gj == hpx && gi == hpy) orn = 255;
-            // ch3
-            for (int k = 0; k < ncand && !oc; k++) {
-                if (gi < s_bbx[k][0] || gi > s_bbx[k][1] || gj < s_bbx[k][2] || gj > s_bbx[k][3]) continue;
-                const int s = s_cand[k];
-                const int n = nv[s];
-                const d2 *v = wv + (size_t)s * BP_MAXV;
-                if (pip_scaled(v, P.m_to_pix, n, (double)gj, (double)gi)) oc = 255;
-            }
         }
-        o[0 * plane + px] = f;
-        o[1 * plane + px] = e;
-        o[2 * plane + px] = orn;
-        o[3 * plane + px] = oc;
+        s_edt[li] = e;
+    }
+    __syncthreads();
+    const int ncand = min(s_ncand, OBS_MAXCAND);
+    if (tid == 0 && s_ncand > OBS_MAXCAND) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+    // ---- occupancy: skimage.draw.polygon of each candidate over its (window-clipped) pixel box, into LDS ----
+    for (int k = 0; k < ncand; k++) {
+        const int r0 = s_bbx[k][0], r1 = s_bbx[k][1], c0 = s_bbx[k][2], c1 = s_bbx[k][3];
+        const int wbox = c1 - c0 + 1, npx = (r1 - r0 + 1) * wbox;
+        const int n = s_cn[k];
+        const double *xp = s_px + k * BP_MAXV, *yp = s_py + k * BP_MAXV;
+        for (int q = tid; q < npx; q += OBS_THREADS) {
+            const int rr = q / wbox, cc = q - rr * wbox;
+            const int gi = r0 + rr, gj = c0 + cc;
+            if (gi < 0 || gi >= Hg || gj < 0 || gj >= Wg) continue;
+            if (pip_arrays(xp, yp, n, (double)gj, (double)gi)) s_occ[(gi - gi0) * LW + (gj - gj0)] = 255;
+        }
+    }
+    __syncthreads();
+    // ---- compose the four channels, 4 pixels per 32-bit store ----
+    const size_t plane = (size_t)npix;
+    unsigned *o32 = (unsigned *)(obs + (size_t)env * BP_OBS_C * plane);
+    const int nwords = npix / 4; // 150*150 is a multiple of 4 (checked on the host)
+    for (int w = tid; w < nwords; w += OBS_THREADS) {
+        unsigned w0 = 0, w1 = 0, w2 = 0;
+        for (int b = 0; b < 4; b++) {
+            const int px = 4 * w + b;
+            const int li = px / LW, lj = px - li * LW;
+            const int gi = gi0 + li, gj = gj0 + lj;
+            const bool inb = !(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg);
+            unsigned f = 0, e = 255, orn = 0;
+            if (inb) {
+                f = 127;
+                if (s_fcnt > 0 && gi >= s_fbb[0] && gi <= s_fbb[1] && gj >= s_fbb[2] && gj <= s_fbb[3]) {
+                    if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) f = 255;
+                }
+                e = s_edt[li];
+                if (on_line(line, gj, gi)) orn = 127;
+                if (gj == hpx && gi == hpy) orn = 255;
+            }
+            w0 |= f << (8 * b); w1 |= e << (8 * b); w2 |= orn << (8 * b);
+        }
+        o32[w] = w0;
+        o32[nwords + w] = w1;
+        o32[2 * nwords + w] = w2;
+        o32[3 * nwords + w] = ((const unsigned *)s_occ)[w];
     }
 }
