@@ -363,7 +363,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                 const int nq = onA ? pnb : pna;
                 const d2 fn = E.wn[pbody * BP_MAXV + f], fp = E.wv[pbody * BP_MAXV + f];
                 double mn = BP_INF;
-#pragma unroll 5
+#pragma unroll 10
                 for (int q = 0; q < BP_MAXV; q++) { // slots >= nq repeat vertex 0, which cannot win the strict '<'
                     const double d = vdot(fn, E.wv[qbody * BP_MAXV + (q < nq ? q : 0)]);
                     if (d < mn) { mn = d; jm = q; }
