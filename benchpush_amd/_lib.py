@@ -9,12 +9,14 @@ from .build import LIB_PATH
 
 MAXV = 20
 MAX_SHIP_VERTS = 32
+MAX_WHEELS = 4
+ENV_SHIP_ICE, ENV_MAZE = 0, 1
 INFO_COUNT = 16
 INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scaled_collision_reward", "dist_reward",
              "trial_success", "boundary_violated", "yaw_violated", "total_ke", "total_impulse", "n_post_solve",
              "n_contact_pts", "n_first_contact"]
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
-EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_reset", "bp_step", "bp_step_physics",
+EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_load_maze", "bp_get_goal_map", "bp_reset", "bp_step", "bp_step_physics",
            "bp_observe", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_last_error"]
 
@@ -29,7 +31,10 @@ class BpConfig(C.Structure):
                 ("local_h", C.c_double), ("vshift", C.c_double), ("obs_range", C.c_double),
                 ("num_ship_verts", C.c_int32), ("_pad", C.c_int32),
                 ("ship_verts", (C.c_double * 2) * MAX_SHIP_VERTS), ("ship_head", C.c_double * 2),
-                ("ship_tail", C.c_double * 2)]
+                ("ship_tail", C.c_double * 2),
+                ("env_kind", C.c_int32), ("num_wheels", C.c_int32), ("wheel_verts", ((C.c_double * 2) * 4) * MAX_WHEELS),
+                ("goal_x", C.c_double), ("goal_reach", C.c_double), ("k_increment", C.c_double), ("wall_radius", C.c_double),
+                ("obstacle_size", C.c_double)]
 
 
 class BpError(RuntimeError):
@@ -59,6 +64,8 @@ def load():
     L.bp_create.argtypes = [C.POINTER(BpConfig), C.c_int32, C.c_int64, C.c_int32, C.POINTER(vp)]
     L.bp_destroy.argtypes = [vp]
     L.bp_load_scenarios.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp]
+    L.bp_load_maze.argtypes = [vp, C.c_int32, C.c_int32, vp, C.c_int32, vp, vp]
+    L.bp_get_goal_map.argtypes = [vp, vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.bp_reset.argtypes = [vp, vp, vp, vp, vp]
     L.bp_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.bp_step_physics.argtypes = [vp, vp, vp, vp, vp, vp, vp]
@@ -88,10 +95,24 @@ def check(L, h, rc, what):
         raise BpError("%s failed: %s (%d) %s" % (what, ERRORS.get(rc, "?"), rc, msg))
 
 
-def make_config(params, ship_vertices, head, tail):
+def make_config(params, ship_vertices, head, tail, env_kind=ENV_SHIP_ICE, wheel_vertices=None, obstacle_size=0.0):
     cfg = BpConfig()
+    fields = {f[0] for f in BpConfig._fields_}
     for k, v in params.items():
-        setattr(cfg, k, v)
+        if k in fields:
+            setattr(cfg, k, v)
+    cfg.env_kind = env_kind
+    cfg.obstacle_size = float(obstacle_size)
+    wheels = [] if wheel_vertices is None else wheel_vertices
+    if len(wheels) > MAX_WHEELS:
+        raise ValueError("too many wheels")
+    cfg.num_wheels = len(wheels)
+    for w, quad in enumerate(wheels):
+        if len(quad) != 4:
+            raise ValueError("wheel outlines must have 4 vertices")
+        for i, (x, y) in enumerate(quad):
+            cfg.wheel_verts[w][i][0] = float(x)
+            cfg.wheel_verts[w][i][1] = float(y)
     sv = [list(map(float, v)) for v in ship_vertices]
     if len(sv) > MAX_SHIP_VERTS:
         raise ValueError("too many ship vertices")

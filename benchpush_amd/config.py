@@ -98,3 +98,38 @@ def ship_ice_physics_params(cfg):
         vshift=2.0,                              # ship_ice_env.py:58
         obs_range=12.0,                          # ship_ice_env.py:383
     )
+
+
+def maze_physics_params(cfg):
+    """Flatten a maze-NAMO cfg (env1/env2 already selected into cfg.env, maze_NAMO_env.py:68-73) into C-ABI scalars."""
+    dt_sub = cfg.dt / cfg.sim.steps
+    collision_bias = math.pow(1.0 - 0.1, 60.0)
+    return dict(
+        dt=float(cfg.dt), steps=int(cfg.sim.steps), iterations=int(cfg.sim.iterations), persistence=3, settle_steps=1000,
+        damping_pow=math.pow(float(cfg.sim.damping), dt_sub), bias_coef=1.0 - math.pow(collision_bias, dt_sub), slop=0.1,
+        target_speed=float(cfg.target_speed),
+        max_yaw_rate=(math.pi / 2) / 15,          # maze_NAMO_env.py:101
+        map_w=float(cfg.env.width), map_h=float(cfg.env.length),
+        goal_y=float(cfg.env.goal_y), goal_x=float(cfg.env.goal_x),
+        goal_reach=float(cfg.goal_radius + cfg.robot.min_r),   # maze_NAMO_env.py:533
+        m_to_pix=float(cfg.occ.m_to_pix_scale), density=float(cfg.sim.obstacle_density), poly_radius=0.02,
+        elasticity=0.01, friction=1.0,
+        beta=1.5, k_increment=150.0,              # maze_NAMO_env.py:80-82
+        boundary_penalty=-50.0, terminal_reward=200.0,
+        local_w=float(cfg.occ.local_width), local_h=float(cfg.occ.local_height), vshift=0.0, obs_range=0.0,
+        wall_radius=0.5,                          # sim_utils.py:177
+    )
+
+
+def maze_walls(cfg):
+    """construct_maze_walls (maze_NAMO_env.py:357-375) as [[ax, ay, bx, by], ...]."""
+    L, W = cfg.env.length, cfg.env.width
+    if cfg.maze_version == 1:
+        w = [[(0, 0), (W, 0)], [(0, 0), (0, L)], [(W, 0), (W, L)], [(0, L), (W, L)], [(2 * W / 2, L), (2 * W / 2, 5)],
+             [(W / 2, 0), (W / 2, L - L / 3)]]
+    elif cfg.maze_version == 2:
+        w = [[(0, 0), (W, 0)], [(0, 0), (0, L)], [(W, 0), (W, L)], [(0, L), (W, L)], [(W / 3, 0), (W / 3, 2 * L / 3)],
+             [(2 * W / 3, L), (2 * W / 3, L / 3)]]
+    else:
+        raise Exception("Invalid Maze Version!")
+    return [[float(a[0]), float(a[1]), float(b[0]), float(b[1])] for a, b in w]

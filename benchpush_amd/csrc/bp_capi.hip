@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -27,6 +28,7 @@ struct bp_handle {
     std::vector<void *> allocs;
     size_t lds_bytes = 0, obs_lds_bytes = 0;
     std::string err;
+    std::vector<double> goal_raw; // maze: un-normalised wavefront map (info['goal_dt'])
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev; // triples: start, mid, stop
@@ -81,6 +83,8 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     if (cfg->damping_pow != 0.0) return BP_EINVAL;          // only the reference's damping: 0 is supported
     if (cfg->num_ship_verts < 3 || cfg->num_ship_verts > BP_MAX_SHIP_VERTS) return BP_EINVAL;
     if (cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
+    if (cfg->env_kind != BP_ENV_SHIP_ICE && cfg->env_kind != BP_ENV_MAZE) return BP_EINVAL;
+    if (cfg->env_kind == BP_ENV_MAZE && (cfg->num_wheels < 0 || cfg->num_wheels > BP_MAX_WHEELS)) return BP_EINVAL;
     bp_handle *h = new bp_handle();
     h->cfg = *cfg;
     h->num_envs = num_envs;
@@ -95,12 +99,12 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     P.damping_pow = cfg->damping_pow; P.bias_coef = cfg->bias_coef; P.slop = cfg->slop;
     P.target_speed = cfg->target_speed; P.max_yaw_rate = cfg->max_yaw_rate;
     P.map_w = cfg->map_w; P.map_h = cfg->map_h; P.goal_y = cfg->goal_y; P.m_to_pix = cfg->m_to_pix;
-    P.poly_radius = cfg->poly_radius;
-    P.arb_e = cfg->elasticity * cfg->elasticity;
-    P.arb_u = cfg->friction * cfg->friction;
     P.beta = cfg->beta; P.boundary_penalty = cfg->boundary_penalty; P.terminal_reward = cfg->terminal_reward;
     P.local_w = cfg->local_w; P.local_h = cfg->local_h; P.vshift = cfg->vshift; P.obs_range = cfg->obs_range;
     P.skin = 0.25;
+    P.env_kind = cfg->env_kind;
+    P.nkin = (cfg->env_kind == BP_ENV_MAZE) ? 1 + cfg->num_wheels : 1;
+    P.goal_x = cfg->goal_x; P.goal_reach = cfg->goal_reach; P.k_increment = cfg->k_increment;
     P.num_envs = num_envs; P.env_offset = env_id_offset;
     P.num_ship_verts = cfg->num_ship_verts;
     memcpy(P.ship_verts, cfg->ship_verts, sizeof(P.ship_verts));
@@ -113,8 +117,15 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     P.obs_h = (int)(cfg->local_h * cfg->m_to_pix);
     P.obs_w = (int)(cfg->local_w * cfg->m_to_pix);
     if ((P.obs_h * P.obs_w) % 4 != 0) { delete h; return BP_EINVAL; }
-    h->obs_lds_bytes = (size_t)((P.obs_h * P.obs_w + 15) & ~15) + (size_t)((P.obs_h + 15) & ~15) + sizeof(double) * 2 * OBS_MAXCAND * BP_MAXV;
-    if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
+    if (cfg->env_kind == BP_ENV_MAZE) {
+        const int infl = (P.obs_w > P.obs_h ? P.obs_w : P.obs_h) / 2;
+        const int nwords = ((P.obs_h + infl) * (P.obs_w + infl) + 31) / 32;
+        h->obs_lds_bytes = (size_t)4 * (nwords + ((nwords + 1) & ~1)) + sizeof(double) * 2 * MZ_MAXBOX * 4;
+        if (hipFuncSetAttribute((const void *)k_observe_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
+    } else {
+        h->obs_lds_bytes = (size_t)((P.obs_h * P.obs_w + 15) & ~15) + (size_t)((P.obs_h + 15) & ~15) + sizeof(double) * 2 * OBS_MAXCAND * BP_MAXV;
+        if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
+    }
     *out = h;
     return BP_OK;
 }
@@ -129,35 +140,14 @@ int bp_destroy(bp_handle *h)
     return BP_OK;
 }
 
-int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const double *verts, const int32_t *counts,
-                      const double *centres, const double *starts, const int32_t *nfloes)
+// Common tail of the scenario loaders: SoA upload of the per-trial bodies, per-env state allocation, and one settle of
+// every trial into its reset template (state slot num_envs + t).
+static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Shape>> &trials)
 {
-    if (!h || T <= 0 || F < 0 || V <= 0 || !starts || !nfloes) return BP_EINVAL;
-    if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
-    HIPCHK(h, hipSetDevice(h->device));
     using namespace bpgeom;
-    std::vector<std::vector<Shape>> trials(T);
+    const int T = (int)trials.size();
     int maxnb = 1;
-    for (int t = 0; t < T; t++) {
-        std::vector<Shape> &bodies = trials[t];
-        Shape ship;
-        build_ship(h->cfg.ship_verts, h->cfg.num_ship_verts, starts[3 * t], starts[3 * t + 1], starts[3 * t + 2], ship);
-        if ((int)ship.verts.size() > BP_MAXV) return fail(h, BP_EINVAL, "ship hull exceeds BP_MAXV");
-        bodies.push_back(ship);
-        if (nfloes[t] > F) return fail(h, BP_EINVAL, "nfloes > F");
-        for (int f = 0; f < nfloes[t]; f++) {
-            const int n = counts[(size_t)t * F + f];
-            if (n < 3) continue;
-            if (n > V) return fail(h, BP_EINVAL, "vertex count > V");
-            Shape s;
-            if (!build_floe(verts + ((size_t)t * F + f) * V * 2, n, centres[((size_t)t * F + f) * 2],
-                            centres[((size_t)t * F + f) * 2 + 1], h->cfg.density, h->cfg.poly_radius, s))
-                continue;
-            if ((int)s.verts.size() > BP_MAXV) return fail(h, BP_EINVAL, "floe hull exceeds BP_MAXV");
-            bodies.push_back(s);
-        }
-        if ((int)bodies.size() > maxnb) maxnb = (int)bodies.size();
-    }
+    for (const auto &b : trials) maxnb = std::max(maxnb, (int)b.size());
     if (maxnb > 60000) return fail(h, BP_EINVAL, "too many bodies");
     const int nbcap = (maxnb + 7) / 8 * 8;
     h->nbcap = nbcap;
@@ -168,18 +158,19 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     h->lds_bytes = lds_bytes_for(nbcap);
     if (h->lds_bytes > 160 * 1024) return fail(h, BP_EINVAL, "nb_cap too large for LDS");
 
-    // host SoA
-    std::vector<int> h_nb(T), h_nv((size_t)T * nbcap, 0);
+    std::vector<int> h_nb(T), h_nv((size_t)T * nbcap, 0), h_kind((size_t)T * nbcap, 0);
     std::vector<d2> h_lv((size_t)T * nbcap * BP_MAXV), h_ln((size_t)T * nbcap * BP_MAXV);
-    std::vector<double4> h_mass((size_t)T * nbcap), h_pose((size_t)T * nbcap);
+    std::vector<double4> h_mass((size_t)T * nbcap), h_pose((size_t)T * nbcap), h_prop((size_t)T * nbcap);
     memset(h_lv.data(), 0, h_lv.size() * sizeof(d2));
     memset(h_ln.data(), 0, h_ln.size() * sizeof(d2));
     memset(h_mass.data(), 0, h_mass.size() * sizeof(double4));
     memset(h_pose.data(), 0, h_pose.size() * sizeof(double4));
+    memset(h_prop.data(), 0, h_prop.size() * sizeof(double4));
     for (int t = 0; t < T; t++) {
         h_nb[t] = (int)trials[t].size();
         for (int b = 0; b < (int)trials[t].size(); b++) {
             const Shape &s = trials[t][b];
+            if ((int)s.verts.size() > BP_MAXV) return fail(h, BP_EINVAL, "hull exceeds BP_MAXV vertices");
             const size_t o = (size_t)t * nbcap + b;
             h_nv[o] = (int)s.verts.size();
             for (int i = 0; i < (int)s.verts.size(); i++) {
@@ -188,24 +179,31 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
             }
             h_mass[o].x = s.m_inv; h_mass[o].y = s.i_inv; h_mass[o].z = s.cog.x; h_mass[o].w = s.cog.y;
             h_pose[o].x = s.p.x; h_pose[o].y = s.p.y; h_pose[o].z = s.angle; h_pose[o].w = 0.0;
+            h_prop[o].x = s.radius; h_prop[o].y = s.e; h_prop[o].z = s.u; h_prop[o].w = 0.0;
+            h_kind[o] = s.kind;
         }
     }
     DevPtrs &D = h->D;
     int rc;
-    int *d_nb, *d_nv; d2 *d_lv, *d_ln; double4 *d_mass, *d_pose;
+    int *d_nb, *d_nv, *d_kind; d2 *d_lv, *d_ln; double4 *d_mass, *d_pose, *d_prop;
     if ((rc = dalloc(h, &d_nb, T))) return rc;
     if ((rc = dalloc(h, &d_nv, (size_t)T * nbcap))) return rc;
+    if ((rc = dalloc(h, &d_kind, (size_t)T * nbcap))) return rc;
     if ((rc = dalloc(h, &d_lv, (size_t)T * nbcap * BP_MAXV))) return rc;
     if ((rc = dalloc(h, &d_ln, (size_t)T * nbcap * BP_MAXV))) return rc;
     if ((rc = dalloc(h, &d_mass, (size_t)T * nbcap))) return rc;
     if ((rc = dalloc(h, &d_pose, (size_t)T * nbcap))) return rc;
+    if ((rc = dalloc(h, &d_prop, (size_t)T * nbcap))) return rc;
     HIPCHK(h, hipMemcpy(d_nb, h_nb.data(), sizeof(int) * T, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_nv, h_nv.data(), sizeof(int) * h_nv.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_kind, h_kind.data(), sizeof(int) * h_kind.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_lv, h_lv.data(), sizeof(d2) * h_lv.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_ln, h_ln.data(), sizeof(d2) * h_ln.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_mass, h_mass.data(), sizeof(double4) * h_mass.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_pose, h_pose.data(), sizeof(double4) * h_pose.size(), hipMemcpyHostToDevice));
-    D.sc_nb = d_nb; D.sc_nv = d_nv; D.sc_lv = d_lv; D.sc_ln = d_ln; D.sc_mass = d_mass; D.sc_pose = d_pose;
+    HIPCHK(h, hipMemcpy(d_prop, h_prop.data(), sizeof(double4) * h_prop.size(), hipMemcpyHostToDevice));
+    D.sc_nb = d_nb; D.sc_nv = d_nv; D.sc_kind = d_kind; D.sc_lv = d_lv; D.sc_ln = d_ln; D.sc_mass = d_mass; D.sc_pose = d_pose;
+    D.sc_prop = d_prop;
 
     // per-env state for the E envs plus T settled reset templates (slot E + t = trial t)
     const size_t E = (size_t)h->num_envs + (size_t)T, EB = E * nbcap;
@@ -213,6 +211,8 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     if ((rc = dalloc(h, &D.e_episode, E, 0xFF))) return rc; // -1
     if ((rc = dalloc(h, &D.e_nb, E))) return rc;
     if ((rc = dalloc(h, &D.e_err, E))) return rc;
+    if ((rc = dalloc(h, &D.e_flags, E))) return rc;
+    if ((rc = dalloc(h, &D.e_prevdist, E))) return rc;
     if ((rc = dalloc(h, &D.e_stamp, E))) return rc;
     if ((rc = dalloc(h, &D.e_currdt, E))) return rc;
     if ((rc = dalloc(h, &D.e_total_work, E))) return rc;
@@ -254,6 +254,103 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     return BP_OK;
 }
 
+static int kind_of(int ctype, int group, int btype) { return ctype | (group << 8) | (btype << 16); }
+
+int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const double *verts, const int32_t *counts,
+                      const double *centres, const double *starts, const int32_t *nfloes)
+{
+    if (!h || T <= 0 || F < 0 || V <= 0 || !starts || !nfloes) return BP_EINVAL;
+    if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
+    if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_ESTATE, "handle was created for another environment");
+    HIPCHK(h, hipSetDevice(h->device));
+    using namespace bpgeom;
+    std::vector<std::vector<Shape>> trials(T);
+    for (int t = 0; t < T; t++) {
+        std::vector<Shape> &bodies = trials[t];
+        Shape ship;
+        build_ship(h->cfg.ship_verts, h->cfg.num_ship_verts, starts[3 * t], starts[3 * t + 1], starts[3 * t + 2], ship);
+        ship.radius = h->cfg.poly_radius; ship.e = h->cfg.elasticity; ship.u = h->cfg.friction;
+        ship.kind = kind_of(1, 0, BODY_KINEMATIC); // ship_ice_env.py:214-215
+        bodies.push_back(ship);
+        if (nfloes[t] > F) return fail(h, BP_EINVAL, "nfloes > F");
+        for (int f = 0; f < nfloes[t]; f++) {
+            const int n = counts[(size_t)t * F + f];
+            if (n < 3) continue;
+            if (n > V) return fail(h, BP_EINVAL, "vertex count > V");
+            Shape s;
+            if (!build_floe(verts + ((size_t)t * F + f) * V * 2, n, centres[((size_t)t * F + f) * 2],
+                            centres[((size_t)t * F + f) * 2 + 1], h->cfg.density, h->cfg.poly_radius, s))
+                continue;
+            s.radius = h->cfg.poly_radius; s.e = h->cfg.elasticity; s.u = h->cfg.friction;
+            s.kind = kind_of(2, 0, BODY_DYNAMIC);  // ship_ice_env.py:211-212
+            bodies.push_back(s);
+        }
+    }
+    return upload_trials(h, trials);
+}
+
+int bp_load_maze(bp_handle *h, int32_t T, int32_t nbox, const double *centres, int32_t nwalls, const double *walls, const double *start)
+{
+    if (!h || T <= 0 || nbox < 0 || nwalls < 0 || nwalls > 16 || !walls || !start || (nbox > 0 && !centres)) return BP_EINVAL;
+    if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
+    if (h->P.env_kind != BP_ENV_MAZE) return fail(h, BP_ESTATE, "handle was created for another environment");
+    HIPCHK(h, hipSetDevice(h->device));
+    using namespace bpgeom;
+    const bp_config &cf = h->cfg;
+    std::vector<std::vector<Shape>> trials(T);
+    for (int t = 0; t < T; t++) {
+        std::vector<Shape> &bodies = trials[t];
+        // robot: one KINEMATIC body with the main outline (type 1) + the wheels (type 0); friction stays at pymunk's
+        // default 0 (Robot.sim sets mass and elasticity only, robot.py:90-105)
+        for (int k = 0; k <= cf.num_wheels; k++) {
+            Shape s;
+            if (k == 0) build_kinematic_part(cf.ship_verts, cf.num_ship_verts, start[0], start[1], start[2], s);
+            else build_kinematic_part(cf.wheel_verts[k - 1], 4, start[0], start[1], start[2], s);
+            s.radius = cf.poly_radius; s.e = cf.elasticity; s.u = 0.0;
+            s.kind = kind_of(k == 0 ? 1 : 0, 1, BODY_KINEMATIC);
+            bodies.push_back(s);
+        }
+        for (int b = 0; b < nbox; b++) {
+            const double ox = centres[((size_t)t * nbox + b) * 2], oy = centres[((size_t)t * nbox + b) * 2 + 1], sz = cf.obstacle_size;
+            const double raw[8] = {ox + sz, oy + sz, ox - sz, oy + sz, ox - sz, oy - sz, ox + sz, oy - sz}; // maze_NAMO_env.py:317-320
+            Shape s;
+            if (!build_floe(raw, 4, ox, oy, cf.density, cf.poly_radius, s)) continue;
+            s.radius = cf.poly_radius; s.e = cf.elasticity; s.u = cf.friction;
+            s.kind = kind_of(2, 0, BODY_DYNAMIC);
+            bodies.push_back(s);
+        }
+        for (int w = 0; w < nwalls; w++) {
+            Shape s;
+            build_wall(walls[4 * w], walls[4 * w + 1], walls[4 * w + 2], walls[4 * w + 3], s);
+            s.radius = cf.wall_radius; s.e = 0.5; s.u = 0.5;            // sim_utils.py:177-180
+            s.kind = kind_of(3, 0, BODY_STATIC);
+            bodies.push_back(s);
+        }
+    }
+    // static maps: wall raster + BFS goal map
+    std::vector<unsigned char> wall;
+    std::vector<double> norm;
+    maze_maps(walls, nwalls, cf.wall_radius, cf.map_w, cf.map_h, h->P.grid_h, h->P.grid_w, cf.goal_x, cf.goal_y, wall, norm, h->goal_raw);
+    double *d_norm; unsigned char *d_wall;
+    int rc;
+    if ((rc = dalloc(h, &d_norm, norm.size()))) return rc;
+    if ((rc = dalloc(h, &d_wall, wall.size()))) return rc;
+    HIPCHK(h, hipMemcpy(d_norm, norm.data(), sizeof(double) * norm.size(), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(d_wall, wall.data(), wall.size(), hipMemcpyHostToDevice));
+    h->D.dist_map = d_norm; h->D.wall_map = d_wall;
+    return upload_trials(h, trials);
+}
+
+int bp_get_goal_map(bp_handle *h, double *out_host, int32_t *grid_h, int32_t *grid_w)
+{
+    if (!h) return BP_EINVAL;
+    if (h->goal_raw.empty()) return fail(h, BP_ESTATE, "no goal map (not a maze handle or not loaded)");
+    if (out_host) memcpy(out_host, h->goal_raw.data(), sizeof(double) * h->goal_raw.size());
+    if (grid_h) *grid_h = h->P.grid_h;
+    if (grid_w) *grid_w = h->P.grid_w;
+    return BP_OK;
+}
+
 static int launch(bp_handle *h, int mode, const double *actions, const unsigned char *mask, unsigned char *obs, double *reward,
                   unsigned char *term, unsigned char *trunc, double *info, hipStream_t st, bool physics, bool raster)
 {
@@ -283,7 +380,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     if (raster && obs) {
-        hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
+        if (h->P.env_kind == BP_ENV_MAZE)
+            hipLaunchKernelGGL(k_observe_maze, dim3(h->num_envs), dim3(OBS_THREADS), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
+        else
+            hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e2, st));

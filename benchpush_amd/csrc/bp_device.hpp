@@ -12,6 +12,10 @@
 
 typedef double2 d2;
 
+enum { BODY_DYNAMIC = 0, BODY_KINEMATIC = 1, BODY_STATIC = 2 };
+__device__ __forceinline__ int kind_ctype(int k) { return k & 0xFF; }
+__device__ __forceinline__ int kind_group(int k) { return (k >> 8) & 0xFF; }
+__device__ __forceinline__ int kind_btype(int k) { return (k >> 16) & 3; }
 enum { ARB_FIRST = 0, ARB_NORMAL = 1, ARB_IGNORE = 2, ARB_CACHED = 3 };
 #define ARB_FREE_KEY 0xFFFFFFFFu
 
@@ -19,7 +23,10 @@ struct DevParams {
     double dt_sub;
     int steps, iterations, persistence, settle_steps;
     double damping_pow, bias_coef, slop, target_speed, max_yaw_rate, map_w, map_h, goal_y, m_to_pix;
-    double poly_radius, arb_e, arb_u, beta, boundary_penalty, terminal_reward, local_w, local_h, vshift, obs_range;
+    double beta, boundary_penalty, terminal_reward, local_w, local_h, vshift, obs_range;
+    double goal_x, goal_reach, k_increment;   // maze-NAMO-v0
+    int env_kind;                              // BP_ENV_SHIP_ICE / BP_ENV_MAZE
+    int nkin;                                  // bodies [0, nkin) are the parts of the kinematic agent (ship: 1, maze robot: 5)
     double skin;
     int nbcap, mvcap, num_envs, num_trials, num_ship_verts;
     long long env_offset;
@@ -37,8 +44,14 @@ struct DevPtrs {
     const d2 *sc_ln;         // [T][nbcap][MAXV] local plane normals
     const double4 *sc_mass;  // [T][nbcap] m_inv, i_inv, cog.x, cog.y
     const double4 *sc_pose;  // [T][nbcap] x, y, angle, -
+    const double4 *sc_prop;  // [T][nbcap] shape radius, elasticity, friction, -
+    const int *sc_kind;      // [T][nbcap] collision_type | group << 8 | body_type << 16 (group != 0: parts of one body)
+    const double *dist_map;  // maze: normalised BFS goal map [grid_h][grid_w]
+    const unsigned char *wall_map; // maze: wall raster [grid_h][grid_w]
     // env state
     int *e_trial, *e_episode, *e_nb, *e_err;
+    int *e_flags;            // [E] maze: bit0 wall_collision (sticky), bit1 prev_dist valid
+    double *e_prevdist;      // [E] maze: previous goal-map value
     unsigned *e_stamp;
     double *e_currdt, *e_total_work, *e_ke, *e_imp;
     unsigned *e_cnt;         // [E][4] n_post_solve, n_contact_pts, n_first_contact, -

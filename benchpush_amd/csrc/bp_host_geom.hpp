@@ -141,6 +141,8 @@ struct Shape {
     P2 cog{0, 0};
     P2 p{0, 0};              // world position of the centre of gravity
     double angle = 0;
+    double radius = 0, e = 0, u = 0; // shape radius / elasticity / friction
+    int kind = 0;            // collision_type | group << 8 | body_type << 16
 };
 
 static void set_planes(Shape &s)
@@ -199,6 +201,101 @@ static void build_ship(const double (*sv)[2], int n, double x, double y, double 
     out.cog = {0, 0};
     out.p = {x, y};
     out.angle = theta;
+}
+
+
+// ---- maze-NAMO-v0 host construction -------------------------------------------------------------------------------
+// kinematic part of the robot (Robot.sim, robot.py:77-118): Poly(body, verts, radius=0.02) -> convex hull, no recentring
+static void build_kinematic_part(const double (*v)[2], int n, double x, double y, double theta, Shape &out)
+{
+    std::vector<P2> loc(n);
+    for (int i = 0; i < n; ++i) loc[i] = {v[i][0], v[i][1]};
+    out.verts = convex_hull(loc);
+    set_planes(out);
+    out.m_inv = 0.0; out.i_inv = 0.0; out.cog = {0, 0}; out.p = {x, y}; out.angle = theta;
+}
+// static Segment(a, b, radius) (generate_sim_maze, sim_utils.py:174-181) as a 2-vertex hull: planes -n / +n with
+// n = rperp(normalize(b - a)) (cpSegmentShapeInit)
+static void build_wall(double ax, double ay, double bx, double by, Shape &out)
+{
+    out.verts = {P2{ax, ay}, P2{bx, by}};
+    const P2 d = sub(P2{bx, by}, P2{ax, ay});
+    const double inv = 1.0 / (len(d) + DBL_MIN);
+    const P2 u{d.x * inv, d.y * inv};
+    const P2 n{u.y, -u.x};
+    out.normals = {P2{-n.x, -n.y}, n};
+    out.m_inv = 0.0; out.i_inv = 0.0; out.cog = {0, 0}; out.p = {0, 0}; out.angle = 0.0;
+}
+
+// skimage.draw.polygon(r, c, shape) restated (point_in_polygon crossing rule incl. its 1e-12 vertex tolerance)
+static bool pip(const std::vector<double> &xp, const std::vector<double> &yp, double x, double y)
+{
+    const int n = (int)xp.size();
+    const double eps = 1e-12;
+    unsigned lc = 0, rc = 0;
+    double x1 = xp[n - 1] - x, y1 = yp[n - 1] - y;
+    for (int i = 0; i < n; ++i) {
+        const double x0 = xp[i] - x, y0 = yp[i] - y;
+        if ((-eps < x0 && x0 < eps) && (-eps < y0 && y0 < eps)) return true;
+        if ((y0 > 0) != (y1 > 0)) { if (((x0 * y1 - x1 * y0) / (y1 - y0)) > 0) rc++; }
+        if ((y0 < 0) != (y1 < 0)) { if (((x0 * y1 - x1 * y0) / (y1 - y0)) < 0) lc++; }
+        x1 = x0; y1 = y0;
+    }
+    if ((rc & 1) != (lc & 1)) return true;
+    return (rc & 1) != 0;
+}
+static void fill_polygon(const std::vector<double> &r, const std::vector<double> &c, int H, int W, std::vector<unsigned char> &img)
+{
+    double rmin = r[0], rmax = r[0], cmin = c[0], cmax = c[0];
+    for (size_t i = 1; i < r.size(); ++i) { rmin = std::fmin(rmin, r[i]); rmax = std::fmax(rmax, r[i]); cmin = std::fmin(cmin, c[i]); cmax = std::fmax(cmax, c[i]); }
+    long minr = (long)std::fmax(0.0, rmin), maxr = (long)std::ceil(rmax), minc = (long)std::fmax(0.0, cmin), maxc = (long)std::ceil(cmax);
+    if (maxr > H - 1) maxr = H - 1;
+    if (maxc > W - 1) maxc = W - 1;
+    for (long ri = minr; ri <= maxr; ++ri)
+        for (long ci = minc; ci <= maxc; ++ci)
+            if (pip(c, r, (double)ci, (double)ri)) img[(size_t)ri * W + ci] = 1;
+}
+// compute_occ_img_walls (occupancy_map.py:67-94) + global_goal_point_dist_transform (:435-485)
+static void maze_maps(const double *walls, int nwalls, double wall_radius, double map_w, double map_h, int H, int W, double goal_x,
+                      double goal_y, std::vector<unsigned char> &wall, std::vector<double> &norm, std::vector<double> &raw)
+{
+    wall.assign((size_t)H * W, 0);
+    const double m2p = (double)H / map_h;
+    for (int w = 0; w < nwalls; ++w) {
+        const P2 a{walls[4 * w], walls[4 * w + 1]}, b{walls[4 * w + 2], walls[4 * w + 3]};
+        const P2 d = sub(b, a);
+        const double l = std::sqrt(d.x * d.x + d.y * d.y);
+        const P2 u{d.x / l, d.y / l}, p{-u.y, u.x};
+        const double wr = wall_radius;
+        const double vx[4] = {(a.x + wr * p.x - wr * u.x), (a.x - wr * p.x - wr * u.x), (b.x - wr * p.x + wr * u.x), (b.x + wr * p.x + wr * u.x)};
+        const double vy[4] = {(a.y + wr * p.y - wr * u.y), (a.y - wr * p.y - wr * u.y), (b.y - wr * p.y + wr * u.y), (b.y + wr * p.y + wr * u.y)};
+        std::vector<double> r(4), c(4);
+        for (int i = 0; i < 4; ++i) { c[i] = vx[i] * m2p; r[i] = vy[i] * m2p; }
+        fill_polygon(r, c, H, W, wall);
+    }
+    const double g2m = map_w / (double)W;
+    const int gx = (int)(goal_x / g2m), gy = (int)(goal_y / g2m);
+    raw.assign((size_t)H * W, 0.0);
+    std::vector<unsigned char> vis((size_t)H * W, 0);
+    std::vector<int> q; q.reserve((size_t)H * W);
+    raw[(size_t)gy * W + gx] = 1.0; vis[(size_t)gy * W + gx] = 1; q.push_back(gy * W + gx);
+    static const int dy[8] = {0, 0, 1, -1, 1, 1, -1, -1}, dx[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+    double mx = 1.0;
+    for (size_t qh = 0; qh < q.size(); ++qh) {
+        const int cur = q[qh], y = cur / W, x = cur % W;
+        for (int k = 0; k < 8; ++k) {
+            const int ny = y + dy[k], nx = x + dx[k];
+            if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+            const size_t id = (size_t)ny * W + nx;
+            if (vis[id] || wall[id]) continue;
+            vis[id] = 1;
+            raw[id] = raw[cur] + 1;
+            if (raw[id] > mx) mx = raw[id];
+            q.push_back((int)id);
+        }
+    }
+    norm.assign((size_t)H * W, 0.0);
+    for (size_t i = 0; i < norm.size(); ++i) norm[i] = wall[i] ? 1.0 : raw[i] / mx;
 }
 
 } // namespace bpgeom

@@ -92,6 +92,8 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     E.lv = D.sc_lv + tb * BP_MAXV;
     E.ln = D.sc_ln + tb * BP_MAXV;
     E.mass = D.sc_mass + tb;
+    E.prop = D.sc_prop + tb;
+    E.kind = D.sc_kind + tb;
     E.pxy = D.pxy + eb; E.rot = D.rot + eb; E.ang = D.ang + eb;
     E.wv = D.wv + eb * BP_MAXV; E.wn = D.wn + eb * BP_MAXV; E.pv = D.pv + eb * BP_MAXV;
     E.bb = D.bb + eb; E.fat = D.fat + eb;
@@ -103,7 +105,8 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     for (int q = 0; q < 24; q++) S.prof[q] = 0;
     const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
-    S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0;
+    S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.wall_flag = 0;
+    A.e = 0.0; A.u = 0.0;
     S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
     A.level = 0; A.rank = 0;
     A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
@@ -116,8 +119,8 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             const int i = base + lane;
             if (i < nbcap) {
                 L.mvs[i] = 0u;
-                L.slot_of[i] = (i == 0) ? 0 : 255;
-                if (i == 0) { L.sv[0] = mk2(0.0, 0.0); L.sw[0] = mk2(0.0, 0.0); L.sb[0] = mk2(0.0, 0.0); }
+                L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255;
+                if (i < P.nkin) { L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, 0.0); L.sb[i] = mk2(0.0, 0.0); }
                 if (i < E.nb) {
                     const double4 ps = D.sc_pose[tb + i];
                     double sn, cs;
@@ -151,6 +154,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         __syncthreads();
         // neighbour lists for every body (all fat boxes are final here)
         for (int i = 0; i < E.nb; i++) {
+            if (kind_btype(E.kind[i]) == BODY_STATIC) { if (lane == 0) E.adjn[i] = 0; continue; } // never moves: list unused
             const double4 fi = E.fat[i];
             int cnt = 0;
             for (int base = 0; base < E.nb; base += 64) {
@@ -172,7 +176,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             const int i = base + lane;
             if (i < E.nb) L.mv[i] = (unsigned short)i;
         }
-        S.stamp = 0; S.curr_dt = 0.0; S.nmv = E.nb; S.nslots = 1;
+        S.stamp = 0; S.curr_dt = 0.0; S.nmv = E.nb; S.nslots = P.nkin;
         A.slotA = A.slotB = 0;
         S.total_ke = 0.0; S.total_imp = 0.0; S.n_post = S.n_contact = S.n_first = 0;
         __syncthreads();
@@ -180,10 +184,11 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         // ---- load persistent state ----
         for (int base = 0; base < nbcap; base += 64) {
             const int i = base + lane;
-            if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i == 0) ? 0 : 255; }
+            if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
         }
-        if (lane == 0) { L.sv[0] = D.velv[eb]; L.sw[0] = D.velw[eb]; L.sb[0] = D.velb[eb]; }
-        S.nslots = 1;
+        if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; }
+        S.nslots = P.nkin;
+        S.wall_flag = (P.env_kind == BP_ENV_MAZE) ? (D.e_flags[env] & 1) : 0;
         const size_t ab = (size_t)env * BP_ACAP + lane;
         A.key = D.a_key[ab]; A.stamp = D.a_stamp[ab];
         { const unsigned sc = D.a_sc[ab]; A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
@@ -196,17 +201,19 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         if (A.key != ARB_FREE_KEY) {
             const double4 m1 = E.mass[A.key >> 16], m2 = E.mass[A.key & 0xFFFFu];
             A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+            const double4 q1 = E.prop[A.key >> 16], q2 = E.prop[A.key & 0xFFFFu];
+            A.e = q1.y * q2.y; A.u = q1.z * q2.z;
         }
         S.stamp = D.e_stamp[env]; S.curr_dt = D.e_currdt[env];
         S.total_ke = D.e_ke[env]; S.total_imp = D.e_imp[env];
         S.n_post = D.e_cnt[env * 4 + 0]; S.n_contact = D.e_cnt[env * 4 + 1]; S.n_first = D.e_cnt[env * 4 + 2];
         __syncthreads();
         // ship control (ship_ice_env.py:265-274): set once per env step
-        if (lane == 0) {
+        if (lane < P.nkin) { // every part of the kinematic agent carries the same velocity
             const double act = actions[env] * P.max_yaw_rate;
             const d2 r = E.rot[0];
-            L.sv[0] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
-            L.sw[0] = mk2(act, L.sw[0].y);
+            L.sv[lane] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
+            L.sw[lane] = mk2(act, L.sw[lane].y);
         }
         __syncthreads();
         // moving list: every body with a non-zero velocity gets a velocity slot (the ship owns slot 0)
@@ -216,14 +223,14 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             bool mvg = false;
             d2 v = mk2(0.0, 0.0), w2 = v, vb = v;
             if (i < E.nb) {
-                if (i == 0) { v = L.sv[0]; w2 = L.sw[0]; vb = L.sb[0]; }
+                if (i < P.nkin) { v = L.sv[i]; w2 = L.sw[i]; vb = L.sb[i]; }
                 else { v = D.velv[eb + i]; w2 = D.velw[eb + i]; vb = D.velb[eb + i]; }
                 mvg = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
             }
             const unsigned long long m = ballot(mvg);
-            const unsigned long long ms = ballot(mvg && i != 0);
+            const unsigned long long ms = ballot(mvg && i >= P.nkin);
             if (mvg) { const int pos = n + popc_below(m, lane); if (pos < P.mvcap) L.mv[pos] = (unsigned short)i; }
-            if (mvg && i != 0) {
+            if (mvg && i >= P.nkin) {
                 int sl = S.nslots + popc_below(ms, lane);
                 if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
                 L.slot_of[i] = (unsigned char)sl;
@@ -287,7 +294,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     if (mode == MODE_STEP) {
         for (int base = 0; base < E.nb; base += 64) {
             const int i = base + lane;
-            const bool mvd = (i >= 1) && (i < E.nb) && (L.mvs[i] > stamp_start);
+            const bool mvd = (i < E.nb) && (L.mvs[i] > stamp_start) && (kind_ctype(E.kind[i]) == 2); // floes / boxes only
             double contrib = 0.0;
             if (mvd) {
                 const int n = E.nv[i];
@@ -355,10 +362,48 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             D.e_trial[env] = trial; D.e_episode[env] = episode; D.e_nb[env] = E.nb;
             total_work = 0.0;
             D.e_total_work[env] = 0.0;
+            D.e_flags[env] = 0; D.e_prevdist[env] = 0.0; // reset() clears wall_collision after the settle (maze_NAMO_env.py:338)
             if (info) {
                 double *o = info + (size_t)env * BP_INFO_COUNT;
                 for (int k = 0; k < BP_INFO_COUNT; k++) o[k] = 0.0;
                 o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa;
+                o[BP_I_KE] = S.total_ke; o[BP_I_IMPULSE] = S.total_imp;
+                o[BP_I_NPOST] = (double)S.n_post; o[BP_I_NCONTACT] = (double)S.n_contact; o[BP_I_NFIRST] = (double)S.n_first;
+            }
+        } else if (P.env_kind == BP_ENV_MAZE) {
+            // MazeNAMO.step tail (maze_NAMO_env.py:421-474)
+            total_work = D.e_total_work[env] + work;
+            D.e_total_work[env] = total_work;
+            const double gdx = sp.x - P.goal_x, gdy = sp.y - P.goal_y;
+            const double gd = __builtin_sqrt(gdx * gdx + gdy * gdy);
+            const int goal = gd <= P.goal_reach;
+            const int wall = S.wall_flag;
+            const int term = goal || wall;
+            int px = (int)(sp.x * P.m_to_pix), py = (int)(sp.y * P.m_to_pix);
+            px = px < 0 ? 0 : (px > P.grid_w - 1 ? P.grid_w - 1 : px);
+            py = py < 0 ? 0 : (py > P.grid_h - 1 ? P.grid_h - 1 : py);
+            const double dist_value = D.dist_map[(size_t)py * P.grid_w + px];
+            int fl = D.e_flags[env];
+            double dinc = 0.0;
+            if (sp.x != P.goal_x || sp.y != P.goal_y) {
+                if (fl & 2) dinc = (D.e_prevdist[env] - dist_value) * P.k_increment;
+                D.e_prevdist[env] = dist_value;
+                fl |= 2;
+            }
+            D.e_flags[env] = (fl & ~1) | (wall ? 1 : 0);
+            const double coll = -work;
+            double rwd = P.beta * coll + dinc;
+            if (S.boundary_violated || wall) rwd += P.boundary_penalty;
+            int success = 0;
+            if (term && !wall) { rwd += P.terminal_reward; success = 1; }
+            if (reward) reward[env] = rwd;
+            if (terminated) terminated[env] = (unsigned char)term;
+            if (truncated) truncated[env] = 0;
+            if (info) {
+                double *o = info + (size_t)env * BP_INFO_COUNT;
+                o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa; o[BP_I_TOTAL_WORK] = total_work; o[BP_I_WORK] = work;
+                o[BP_I_COLL_REWARD] = coll; o[BP_I_SCALED_COLL] = coll * P.beta; o[BP_I_DIST_REWARD] = dinc;
+                o[BP_I_SUCCESS] = success; o[BP_I_BOUNDARY] = S.boundary_violated; o[BP_I_YAW] = wall;
                 o[BP_I_KE] = S.total_ke; o[BP_I_IMPULSE] = S.total_imp;
                 o[BP_I_NPOST] = (double)S.n_post; o[BP_I_NCONTACT] = (double)S.n_contact; o[BP_I_NFIRST] = (double)S.n_first;
             }
@@ -486,6 +531,7 @@ __global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const Dev
         D.e_trial[env] = trial; D.e_episode[env] = episode; D.e_nb[env] = D.e_nb[se];
         D.e_stamp[env] = D.e_stamp[se]; D.e_currdt[env] = D.e_currdt[se];
         D.e_total_work[env] = 0.0; D.e_ke[env] = D.e_ke[se]; D.e_imp[env] = D.e_imp[se];
+        D.e_flags[env] = 0; D.e_prevdist[env] = 0.0;
         for (int q = 0; q < 4; q++) D.e_cnt[env * 4 + q] = D.e_cnt[se * 4 + q];
         if (D.e_err[se]) atomicOr(&D.e_err[env], D.e_err[se]);
         if (info) {
@@ -758,5 +804,177 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
         o32[nwords + w] = w1;
         o32[2 * nwords + w] = w2;
         o32[3 * nwords + w] = ((const unsigned *)s_occ)[w];
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// k_observe_maze: maze-NAMO-v0 observation, uint8 [4][192][192] per env (maze_NAMO_env.py:514-525 ->
+// OccupancyGrid.ego_view_map_maze, occupancy_map.py:142-202): channels [robot footprint, boxes, walls, goal map];
+// a 288x288 axis-aligned window around the robot is rotated by (heading - pi/2) with scipy.ndimage.rotate
+// (order 1, reshape=False, cval 0/0/0/1) and its centre 192x192 kept.
+// The boxes and the footprint are rasterised (skimage.draw.polygon rule) into two LDS bit-images of the window; the
+// static wall / goal maps are read from HBM; every output pixel then evaluates the order-1 spline of
+// NI_GeometricTransform on its 2x2 source cells.
+// ------------------------------------------------------------------------------------------------------------
+#define MZ_MAXBOX 64
+__global__ __launch_bounds__(OBS_THREADS) void k_observe_maze(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                              unsigned char *__restrict__ obs)
+{
+    const int env = blockIdx.x;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int tid = threadIdx.x;
+    const int nbcap = P.nbcap;
+    const size_t eb = (size_t)env * nbcap;
+    const int nb = D.e_nb[env];
+    const size_t tb = (size_t)D.e_trial[env] * nbcap;
+    const d2 *wv = D.wv + eb * BP_MAXV;
+    const int *nv = D.sc_nv + tb;
+    const int *kind = D.sc_kind + tb;
+    const int Hg = P.grid_h, Wg = P.grid_w, LH = P.obs_h, LW = P.obs_w;
+    const int infl = (LW > LH ? LW : LH) / 2;
+    const int IH = LH + infl, IW = LW + infl;
+    const int nwords = (IH * IW + 31) / 32;
+
+    extern __shared__ double2 obs_smem[];
+    unsigned *s_box = (unsigned *)obs_smem;          // bit-image of the window: boxes
+    unsigned *s_foot = s_box + nwords;               // bit-image of the window: robot footprint
+    double *s_px = (double *)(s_foot + ((nwords + 1) & ~1));  // [MZ_MAXBOX][4] box vertices in raster coordinates
+    double *s_py = s_px + MZ_MAXBOX * 4;
+    __shared__ int s_nbox;
+    __shared__ int s_bbx[MZ_MAXBOX][4];
+    __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
+    __shared__ int s_fcnt, s_fbb[4];
+    if (tid == 0) s_nbox = 0;
+    for (int w = tid; w < nwords; w += OBS_THREADS) { s_box[w] = 0u; s_foot[w] = 0u; }
+    __syncthreads();
+
+    const d2 sp = D.pxy[eb];
+    const double sa = D.ang[eb];
+    const d2 srot = D.rot[eb];
+    const int wx = (int)(sp.x * P.m_to_pix), wy = (int)(sp.y * P.m_to_pix);
+    const int gi0 = (int)((double)(0 + wy) - ((double)IH / 2)), gj0 = (int)((double)(0 + wx) - ((double)IW / 2));
+    const int gi1 = gi0 + IH - 1, gj1 = gj0 + IW - 1;
+    // boxes (collision type 2): compute_occ_img without range culling (occupancy_map.py:37-65)
+    for (int s = tid; s < nb; s += OBS_THREADS) {
+        if (kind_ctype(kind[s]) != 2) continue;
+        const int n = nv[s];
+        const d2 *v = wv + (size_t)s * BP_MAXV;
+        double rmin = v[0].y * P.m_to_pix, rmax = rmin, cmin = v[0].x * P.m_to_pix, cmax = cmin;
+        for (int i = 1; i < n; i++) {
+            const double r = v[i].y * P.m_to_pix, cc = v[i].x * P.m_to_pix;
+            rmin = fmin(rmin, r); rmax = fmax(rmax, r); cmin = fmin(cmin, cc); cmax = fmax(cmax, cc);
+        }
+        long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
+        long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
+        if (maxr > Hg - 1) maxr = Hg - 1;
+        if (maxc > Wg - 1) maxc = Wg - 1;
+        if (maxr < gi0 || minr > gi1 || maxc < gj0 || minc > gj1 || maxr < minr || maxc < minc) continue;
+        const int slot = atomicAdd(&s_nbox, 1);
+        if (slot < MZ_MAXBOX && n <= 4) {
+            s_bbx[slot][0] = (int)max(minr, (long long)gi0); s_bbx[slot][1] = (int)min(maxr, (long long)gi1);
+            s_bbx[slot][2] = (int)max(minc, (long long)gj0); s_bbx[slot][3] = (int)min(maxc, (long long)gj1);
+            for (int i = 0; i < 4; i++) { s_px[slot * 4 + i] = v[i].x * P.m_to_pix; s_py[slot * 4 + i] = v[i].y * P.m_to_pix; }
+        }
+    }
+    // robot footprint polygon (_compute_global_footprint_maze, occupancy_map.py:340-376)
+    if (tid == 0) {
+        const double ch = srot.x, sh = srot.y;
+        const double m2gx = (double)Wg / P.map_w, m2gy = (double)Hg / P.map_h;
+        int cnt = 0;
+        double rmin = BP_INF, rmax = -BP_INF, cmin = BP_INF, cmax = -BP_INF;
+        for (int i = 0; i < P.num_ship_verts; i++) {
+            const double vx = P.ship_verts[i][0] * ch + P.ship_verts[i][1] * -sh + sp.x;
+            const double vy = P.ship_verts[i][0] * sh + P.ship_verts[i][1] * ch + sp.y;
+            const double gx = vx * m2gx, gy = vy * m2gy;
+            if (gy < 0 || gy >= Hg || gx < 0 || gx >= Wg) continue;
+            s_fr[cnt] = gy; s_fc[cnt] = gx; cnt++;
+            rmin = fmin(rmin, gy); rmax = fmax(rmax, gy); cmin = fmin(cmin, gx); cmax = fmax(cmax, gx);
+        }
+        s_fcnt = cnt;
+        if (cnt > 0) {
+            s_fbb[0] = max((int)(long long)fmax(0.0, rmin), gi0); s_fbb[1] = min((int)(long long)__builtin_ceil(rmax), gi1);
+            s_fbb[2] = max((int)(long long)fmax(0.0, cmin), gj0); s_fbb[3] = min((int)(long long)__builtin_ceil(cmax), gj1);
+        }
+    }
+    __syncthreads();
+    const int nbox = min(s_nbox, MZ_MAXBOX);
+    if (tid == 0 && s_nbox > MZ_MAXBOX) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+    for (int kx = 0; kx < nbox; kx++) {
+        const int r0 = s_bbx[kx][0], r1 = s_bbx[kx][1], c0 = s_bbx[kx][2], c1 = s_bbx[kx][3];
+        const int wbox = c1 - c0 + 1, npx = (r1 - r0 + 1) * wbox;
+        for (int q = tid; q < npx; q += OBS_THREADS) {
+            const int rr = q / wbox, cc = q - rr * wbox;
+            const int gi = r0 + rr, gj = c0 + cc;
+            if (gi < 0 || gi >= Hg || gj < 0 || gj >= Wg) continue;
+            if (pip_arrays(s_px + kx * 4, s_py + kx * 4, 4, (double)gj, (double)gi)) {
+                const int bit = (gi - gi0) * IW + (gj - gj0);
+                atomicOr(&s_box[bit >> 5], 1u << (bit & 31));
+            }
+        }
+    }
+    if (s_fcnt > 0) {
+        const int r0 = s_fbb[0], r1 = s_fbb[1], c0 = s_fbb[2], c1 = s_fbb[3];
+        const int wbox = c1 - c0 + 1, npx = (r1 >= r0 && c1 >= c0) ? (r1 - r0 + 1) * wbox : 0;
+        for (int q = tid; q < npx; q += OBS_THREADS) {
+            const int rr = q / wbox, cc = q - rr * wbox;
+            const int gi = r0 + rr, gj = c0 + cc;
+            if (gi < 0 || gi >= Hg || gj < 0 || gj >= Wg) continue;
+            if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) {
+                const int bit = (gi - gi0) * IW + (gj - gj0);
+                atomicOr(&s_foot[bit >> 5], 1u << (bit & 31));
+            }
+        }
+    }
+    __syncthreads();
+    // rotation (scipy.ndimage.rotate, reshape=False, order=1): input = rot @ output + offset, rot = [[c, s], [-s, c]]
+    double rs, rc;
+    bp_sincos(sa - BP_PI / 2, rs, rc);
+    const double ctr = ((double)IH - 1) / 2;
+    const double oc0 = rc * ctr + rs * ctr, oc1 = -rs * ctr + rc * ctr;
+    const double off0 = ctr - oc0, off1 = ctr - oc1;
+    const int half = infl / 2;
+    const size_t plane = (size_t)LH * LW;
+    unsigned char *o = obs + (size_t)env * BP_OBS_C * plane;
+    for (int px = tid; px < LH * LW; px += OBS_THREADS) {
+        const int oi = px / LW, oj = px - oi * LW;
+        const int i = half + oi, j = half + oj;
+        double c0 = 0.0, c1 = 0.0;
+        c0 += (double)i * rc; c0 += (double)j * rs; c0 += off0;
+        c1 += (double)i * -rs; c1 += (double)j * rc; c1 += off1;
+        double t0, t1, t2, t3;
+        if (c0 < 0 || c0 > IH - 1 || c1 < 0 || c1 > IW - 1) { t0 = 0.0; t1 = 0.0; t2 = 0.0; t3 = 1.0; }
+        else {
+            const int s0 = (int)__builtin_floor(c0), s1 = (int)__builtin_floor(c1);
+            const double x0 = c0 - s0, x1 = c1 - s1;
+            const double w0[2] = {1.0 - x0, x0}, w1[2] = {1.0 - x1, x1};
+            t0 = t1 = t2 = t3 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++) {
+                    const int ii = s0 + a, jj = s1 + b;
+                    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 1.0; // cval of the four channels
+                    if (!(ii > IH - 1 || jj > IW - 1)) {
+                        const int gi = gi0 + ii, gj = gj0 + jj;
+                        if (!(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg)) { // outside the map the window keeps its initial values
+                            const int bit = ii * IW + jj;
+                            v0 = ((s_foot[bit >> 5] >> (bit & 31)) & 1u) ? 1.0 : 0.0;
+                            v1 = ((s_box[bit >> 5] >> (bit & 31)) & 1u) ? 1.0 : 0.0;
+                            v2 = D.wall_map[(size_t)gi * Wg + gj] ? 1.0 : 0.0;
+                            v3 = D.dist_map[(size_t)gi * Wg + gj];
+                        }
+                    }
+                    double q0 = v0, q1 = v1, q2 = v2, q3 = v3;
+                    q0 *= w0[a]; q0 *= w1[b]; t0 += q0;
+                    q1 *= w0[a]; q1 *= w1[b]; t1 += q1;
+                    q2 *= w0[a]; q2 *= w1[b]; t2 += q2;
+                    q3 *= w0[a]; q3 *= w1[b]; t3 += q3;
+                }
+        }
+        o[0 * plane + px] = (unsigned char)(t0 * 255);
+        o[1 * plane + px] = (unsigned char)(t1 * 255);
+        o[2 * plane + px] = (unsigned char)(t2 * 255);
+        o[3 * plane + px] = (unsigned char)(t3 * 255);
     }
 }

@@ -34,6 +34,7 @@ struct ArbReg {
     double nMass0, tMass0, bias0, bounce0, jBias0;
     double nMass1, tMass1, bias1, bounce1, jBias1;
     double ma, ia, mb, ib;
+    double e, u;               // elasticity / friction products of the two shapes (cpArbiterUpdate)
     int slotA, slotB;          // velocity slots of the two bodies
 };
 
@@ -42,6 +43,8 @@ struct EnvCtx {
     const int *nv;
     const d2 *lv, *ln;
     const double4 *mass;
+    const double4 *prop;
+    const int *kind;
     d2 *pxy, *rot, *wv, *wn, *pv;
     double *ang;
     double4 *bb, *fat;
@@ -79,6 +82,7 @@ struct SubState {
     unsigned n_post, n_contact, n_first;
     int err;
     int yaw_violated, boundary_violated;
+    int wall_flag;             // maze: robot body touched a wall (pre_solve of the (1,3) handler)
     int quiescent;             // set by substep(): nothing moves and no arbiter is warm -> later sub-steps are no-ops
     unsigned ship_post, ship_contacts; // per-sub-step bookkeeping increments of the (cold) ship arbiters
 #ifdef BP_PROF
@@ -129,7 +133,7 @@ __device__ __forceinline__ void refresh_body(const DevParams &P, const EnvCtx &E
         const int pos = cnt + popc_below(m, lane);
         if (ov && pos < BP_KADJ) { E.adj[i * BP_KADJ + pos] = (unsigned short)j; E.hint[i * BP_KADJ + pos] = 0; }
         cnt += __popcll(m);
-        if (ov) {
+        if (ov && kind_btype(E.kind[j]) != BODY_STATIC) { // static shapes never move: their own lists are never read
             int nj = E.adjn[j];
             bool found = false;
             for (int s2 = 0; s2 < nj; s2++) found = found || (E.adj[j * BP_KADJ + s2] == (unsigned short)i);
@@ -184,7 +188,8 @@ __device__ __forceinline__ void world_from_pose(const DevParams &P, const EnvCtx
     const double r = half_max(valid ? vx : -BP_INF);
     const double bo = half_min(valid ? vy : BP_INF);
     const double tp = half_max(valid ? vy : -BP_INF);
-    outbb.x = l - P.poly_radius; outbb.y = bo - P.poly_radius; outbb.z = r + P.poly_radius; outbb.w = tp + P.poly_radius;
+    const double rad = E.prop[i].x;
+    outbb.x = l - rad; outbb.y = bo - rad; outbb.z = r + rad; outbb.w = tp + rad;
 }
 
 __device__ __forceinline__ void apply_contact_impulses(const ArbReg &A, int c, d2 &va, double &wa, d2 &vb, double &wb, d2 j)
@@ -269,7 +274,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     __syncthreads();
 
     // ---- 3./4. candidate pairs of moving bodies ----------------------------------------------------------------
-    const double rsum = P.poly_radius + P.poly_radius;
     int kmax = 0; // largest neighbour count among the moving bodies (wave-uniform, found with 5 ballots per chunk)
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {
         const int k = k0 + lane;
@@ -292,8 +296,19 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             j = E.adj[i * BP_KADJ + s];
             if (L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
         }
+        bool flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
+        if (valid) {
+            const int ki = E.kind[i], kj = E.kind[j];
+            if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
+            else if (E.mass[i].x == 0.0 && E.mass[j].x == 0.0) {
+                const int ci = kind_ctype(ki), cj = kind_ctype(kj);
+                flagonly = (ci == 1 && cj == 3) || (ci == 3 && cj == 1);
+                valid = flagonly;
+            }
+        }
         if (valid) valid = bb_overlap(E.bb[i], E.bb[j]);
         int sa = min(i, j), sb = max(i, j);
+        const double rsum = valid ? (E.prop[sa].x + E.prop[sb].x) : 0.0;
         if (valid) {
             const int h = E.hint[i * BP_KADJ + s];
             if (h != 255) {
@@ -462,7 +477,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                     if (vdot(nn, Bn[i1B]) > vdot(nn, Bn[i2])) { e2a = Bv[i0]; e2ia = i0; e2b = Bv[i1B]; e2ib = i1B; }
                     else { e2a = Bv[i1B]; e2ia = i1B; e2b = Bv[i2]; e2ib = i2; }
                 }
-                const double r1 = P.poly_radius, r2 = P.poly_radius;
+                const double r1 = E.prop[sa].x, r2 = E.prop[sb].x;
                 const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
                 const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
                 const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
@@ -489,12 +504,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         }
         PROF_ACC(10)
         // ---- 4c. cpArbiterUpdate: hand each manifold to the lane that owns the pair's arbiter slot ---------------------
-        const unsigned long long dm = ballot(valid && M.count > 0);
+        if (ballot(valid && flagonly && M.count > 0)) S.wall_flag = 1;
+        const unsigned long long dm = ballot(valid && !flagonly && M.count > 0);
         const int drank = popc_below(dm, lane);
         const int ndel = __popcll(dm);
         lds_sync(); // the mailbox aliases the plane-search scratch: all reads of it are done
         for (int dbase = 0; dbase < ndel; dbase += BP_MBOX) {
-            const bool mine = valid && M.count > 0 && drank >= dbase && drank < dbase + BP_MBOX;
+            const bool mine = valid && !flagonly && M.count > 0 && drank >= dbase && drank < dbase + BP_MBOX;
             if (mine) {
                 d2 *mb = L.mbox + (drank - dbase) * 6;
                 mb[0] = M.n; mb[1] = M.p1_0; mb[2] = M.p2_0; mb[3] = M.p1_1; mb[4] = M.p2_1;
@@ -551,6 +567,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                 A.stamp = now;
                 const double4 m1 = E.mass[usa], m2 = E.mass[usb];
                 A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+                const double4 q1 = E.prop[usa], q2 = E.prop[usb];
+                A.e = q1.y * q2.y; A.u = q1.z * q2.z;
             }
             lds_sync();
         }
@@ -592,7 +610,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             A.jBias0 = 0.0;
             const d2 v1 = vadd(va, vmul(vperp(A.r1_0), wa));
             const d2 v2 = vadd(vb, vmul(vperp(A.r2_0), wb));
-            A.bounce0 = vdot(vsub(v2, v1), n) * P.arb_e;
+            A.bounce0 = vdot(vsub(v2, v1), n) * A.e;
         }
         if (A.count > 1) {
             const double rcn1 = vcross(A.r1_1, n), rcn2 = vcross(A.r2_1, n);
@@ -604,7 +622,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             A.jBias1 = 0.0;
             const d2 v1 = vadd(va, vmul(vperp(A.r1_1), wa));
             const d2 v2 = vadd(vb, vmul(vperp(A.r2_1), wb));
-            A.bounce1 = vdot(vsub(v2, v1), n) * P.arb_e;
+            A.bounce1 = vdot(vsub(v2, v1), n) * A.e;
         }
     }
     // ---- warm set: arbiters that can produce a non-zero impulse this sub-step ------------------------------------
@@ -739,7 +757,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
                         const double jn = -(bounce + vrn) * nMass;
                         const double jnOld = c ? A.jn1 : A.jn0;
                         const double jnAcc = fmax(jnOld + jn, 0.0);
-                        const double jtMax = P.arb_u * jnAcc;
+                        const double jtMax = A.u * jnAcc;
                         const double jt = -vrt * tMass;
                         const double jtOld = c ? A.jt1 : A.jt0;
                         const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
@@ -782,7 +800,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             const bool ws = shiparb && warm;
             const unsigned long long wsm = ballot(ws);
             if (wsm) {
-                const double eCoef = (1 - P.arb_e) / (1 + P.arb_e);
+                const double eCoef = (1 - A.e) / (1 + A.e);
                 double ke = 0.0;
                 d2 js = mk2(0.0, 0.0);
                 if (ws) {
@@ -805,12 +823,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
             }
         }
     }
-    // ---- ship rules of ShipIceEnv.step (ship_ice_env.py:284-290) ------------------------------------------------
+    // ---- agent rules applied after every sub-step: yaw limits + channel boundary (ship_ice_env.py:284-290),
+    //      boundary only for the maze robot (maze_NAMO_env.py:417-419) ------------------------------------------------
     if (ship_rules) {
         const double a0 = E.ang[0];
         const double x0 = E.pxy[0].x;
-        if (a0 <= 0.0 || a0 >= BP_PI) {
-            if (lane == 0) L.sw[0] = mk2(0.0, L.sw[0].y);
+        if (P.env_kind == BP_ENV_SHIP_ICE && (a0 <= 0.0 || a0 >= BP_PI)) {
+            if (lane < P.nkin) L.sw[lane] = mk2(0.0, L.sw[lane].y);
             S.yaw_violated = 1;
         }
         if (x0 < 0.0 || x0 > P.map_w) S.boundary_violated = 1;
@@ -836,10 +855,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         const bool gotA = wantA && L.owner[ba] == (unsigned short)(lane * 2);
         const bool gotB = wantB && L.owner[bbi] == (unsigned short)(lane * 2 + 1);
         const d2 v0 = L.sv[0], w0 = L.sw[0];
-        const int shipmv = (v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? 1 : 0;
+        const int shipmv = (v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? P.nkin : 0; // every part of the kinematic agent
         const unsigned long long mA = ballot(gotA), mB = ballot(gotB);
         const int nA_ = __popcll(mA);
-        if (lane == 0 && shipmv) L.mv[0] = 0;
+        if (lane < shipmv) L.mv[lane] = (unsigned short)lane;
         if (gotA) L.mv[shipmv + popc_below(mA, lane)] = (unsigned short)ba;
         if (gotB) L.mv[shipmv + nA_ + popc_below(mB, lane)] = (unsigned short)bbi;
         S.nmv = shipmv + nA_ + __popcll(mB);

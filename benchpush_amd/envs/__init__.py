@@ -6,3 +6,9 @@ register(
     entry_point="benchpush_amd.envs.ship_ice:ShipIceEnv",
     max_episode_steps=300,
 )
+
+register(
+    id="maze-NAMO-v0",
+    entry_point="benchpush_amd.envs.maze_namo:MazeNAMO",
+    max_episode_steps=400,
+)

@@ -36,7 +36,22 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-class BatchedShipIceEnv:
+class _BatchedBase:
+    """Tensor-in / tensor-out wrapper of one bp_handle (shared by the ship-ice and maze environments)."""
+
+    def _alloc_io(self):
+        self.nb_cap = self.L.bp_nb_cap(self.h)
+        self.obs_shape = (4, self.L.bp_obs_height(self.h), self.L.bp_obs_width(self.h))
+        E, dv = self.num_envs, self.device
+        self.obs = torch.zeros((E,) + self.obs_shape, dtype=torch.uint8, device=dv)
+        self.reward = torch.zeros(E, dtype=torch.float64, device=dv)
+        self.terminated = torch.zeros(E, dtype=torch.uint8, device=dv)
+        self.truncated = torch.zeros(E, dtype=torch.uint8, device=dv)
+        self.info = torch.zeros((E, _lib.INFO_COUNT), dtype=torch.float64, device=dv)
+        self._actions = torch.zeros(E, dtype=torch.float64, device=dv)
+
+
+class BatchedShipIceEnv(_BatchedBase):
     """E independent ship-ice environments on one GPU.
 
     reset(mask) / step(actions) follow ShipIceEnv.reset / .step (ship_ice_env.py:223-355) for every env at once.
@@ -71,15 +86,7 @@ class BatchedShipIceEnv:
             self.h, T, F, V, pk["verts"].ctypes.data_as(C.c_void_p), pk["counts"].ctypes.data_as(C.c_void_p),
             pk["centres"].ctypes.data_as(C.c_void_p), pk["starts"].ctypes.data_as(C.c_void_p),
             pk["nfloes"].ctypes.data_as(C.c_void_p)), "bp_load_scenarios")
-        self.nb_cap = self.L.bp_nb_cap(self.h)
-        self.obs_shape = (4, self.L.bp_obs_height(self.h), self.L.bp_obs_width(self.h))
-        E, dv = self.num_envs, self.device
-        self.obs = torch.zeros((E,) + self.obs_shape, dtype=torch.uint8, device=dv)
-        self.reward = torch.zeros(E, dtype=torch.float64, device=dv)
-        self.terminated = torch.zeros(E, dtype=torch.uint8, device=dv)
-        self.truncated = torch.zeros(E, dtype=torch.uint8, device=dv)
-        self.info = torch.zeros((E, _lib.INFO_COUNT), dtype=torch.float64, device=dv)
-        self._actions = torch.zeros(E, dtype=torch.float64, device=dv)
+        self._alloc_io()
 
     # -- helpers -----------------------------------------------------------------------------------------
     def _stream(self):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 1
+#define BP_ABI_VERSION 2
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -37,6 +37,9 @@ enum {
     BP_ESTATE = -5,      /* call order violated (e.g. step before load/reset) */
     BP_ECAPACITY = -6    /* an in-kernel capacity (neighbour list / arbiter slots) overflowed */
 };
+
+enum { BP_ENV_SHIP_ICE = 0, BP_ENV_MAZE = 1 };
+#define BP_MAX_WHEELS 4
 
 /* per-env error bits reported by bp_check_errors */
 enum { BP_ERR_ADJ_OVERFLOW = 1, BP_ERR_ARB_OVERFLOW = 2, BP_ERR_LEVEL_OVERFLOW = 4 };
@@ -79,6 +82,16 @@ typedef struct bp_config {
     int32_t _pad;
     double ship_verts[BP_MAX_SHIP_VERTS][2];  /* cfg.ship.vertices */
     double ship_head[2], ship_tail[2];
+    /* ---- maze-NAMO-v0 (benchpush/environments/maze_NAMO/maze_NAMO_env.py, config.yaml); ignored for ship-ice ---- */
+    int32_t env_kind;        /* BP_ENV_SHIP_ICE | BP_ENV_MAZE; for the maze ship_verts holds cfg.robot.vertices and map_w/map_h
+                                hold cfg.env.width/length, goal_y cfg.env.goal_y */
+    int32_t num_wheels;      /* cfg.robot.wheel_vertices (4 quads) */
+    double wheel_verts[BP_MAX_WHEELS][4][2];
+    double goal_x;           /* cfg.env.goal_x */
+    double goal_reach;       /* cfg.goal_radius + cfg.robot.min_r, maze_NAMO_env.py:528-536 */
+    double k_increment;      /* 150, maze_NAMO_env.py:82 */
+    double wall_radius;      /* 0.5, sim_utils.py:177 */
+    double obstacle_size;    /* cfg.obstacle_size */
 } bp_config;
 
 typedef struct bp_handle bp_handle;
@@ -96,6 +109,15 @@ int bp_destroy(bp_handle *h);
  * copies SoA arrays to the device.  Replaces the pickle load of ship_ice_env.py:76-80 and init_ship_ice_env :186-216. */
 int bp_load_scenarios(bp_handle *h, int32_t num_trials, int32_t F, int32_t V, const double *verts,
                       const int32_t *counts, const double *centres, const double *starts, const int32_t *nfloes);
+
+/* maze-NAMO-v0 counterpart of bp_load_scenarios: `num_layouts` box layouts (host pointers), centres[T][nbox][2], the wall
+ * segments walls[nwalls][4] = ax, ay, bx, by (construct_maze_walls, maze_NAMO_env.py:357-375) and the start pose.  Builds the
+ * KINEMATIC robot (body + wheels, robot.py:77-118), the boxes (sim_utils.py:136-163), the static Segment(radius 0.5) walls
+ * (sim_utils.py:174-181) and the BFS goal map (occupancy_map.py:435-485) on the host.  Replaces init_maze_NAMO_env (:221-269). */
+int bp_load_maze(bp_handle *h, int32_t num_layouts, int32_t nbox, const double *centres, int32_t nwalls, const double *walls,
+                 const double *start);
+/* maze: goal map as the reference returns it in info['goal_dt'] (un-normalised wavefront distances), host double [grid_h][grid_w] */
+int bp_get_goal_map(bp_handle *h, double *out_host, int32_t *grid_h, int32_t *grid_w);
 
 /* reset() for the envs whose env_mask byte is non-zero (device pointer; NULL = all envs): next trial
  * ((global_env_id + episode_idx) % num_trials), new space, 1000 settle sub-steps, first observation.

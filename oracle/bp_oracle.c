@@ -168,6 +168,11 @@ typedef struct orc_params {
     double local_w, local_h; /* 6, 6 (ship_ice_env.py:91) */
     double vshift;           /* local_window_v_shift 2 */
     double obs_range;        /* local_range 12 (ship_ice_env.py:383) */
+    /* maze-NAMO-v0 only (maze_NAMO_env.py; appended so that the ship-ice prefix keeps its layout) */
+    double goal_x;           /* cfg.env.goal_x (goal_y above) */
+    double goal_reach;       /* cfg.goal_radius + cfg.robot.min_r, maze_NAMO_env.py:528-536 */
+    double k_increment;      /* 150, maze_NAMO_env.py:82 */
+    double wall_radius;      /* 0.5, sim_utils.py:177 */
 } orc_params;
 
 typedef struct orc_env {
@@ -195,6 +200,13 @@ typedef struct orc_env {
     /* stats for design studies */
     long stat_pairs_bb, stat_narrow, stat_arb_sum, stat_moving_sum, stat_arb_max, stat_substeps;
     long stat_hot_sum;
+    /* maze-NAMO-v0 */
+    int wall_collision;        /* sticky flag set by the (1,3) pre_solve handler, maze_NAMO_env.py:203-205 */
+    int nwalls; double walls[16][4];
+    int robot_nv; vec robot_verts[ORC_MAXV];
+    double *dist_map, *wall_map; int map_h, map_w; /* normalised BFS goal map, wall raster */
+    double *dist_raw;
+    int have_prev_dist; double prev_dist;
 } orc_env;
 
 /* ---- Chipmunk geometry helpers (cpPolyline.c cpConvexHull / cpChipmunk.c) restated ---- */
@@ -489,6 +501,7 @@ static void collide_pair(orc_env *E, int sa, int sb)
     /* QueryReject */
     if (!(A->bl <= B->br && B->bl <= A->br && A->bb <= B->bt && B->bb <= A->bt)) return;
     if (A->body == B->body) return;
+    if (E->bodies[A->body].type == BODY_STATIC && E->bodies[B->body].type == BODY_STATIC) return; /* never queried by Chipmunk */
     E->stat_pairs_bb++;
     manifold_t m;
     collide_poly_poly(A, B, &m);
@@ -515,7 +528,9 @@ static void collide_pair(orc_env *E, int sa, int sb)
     arb->e = A->e * B->e;
     arb->u = A->u * B->u;
     if (arb->state == ARB_CACHED) arb->state = ARB_FIRST;
-    /* begin/pre_solve handlers of the reference always return True (ship_ice_env.py:150-153) */
+    /* begin/pre_solve handlers of the reference always return True (ship_ice_env.py:150-153);
+     * the maze's (1,3) robot x wall pre_solve additionally raises a flag (maze_NAMO_env.py:203-205) */
+    if ((A->ctype == 1 && B->ctype == 3) || (A->ctype == 3 && B->ctype == 1)) E->wall_collision = 1;
     if (!(a->m_inv == 0.0 && b->m_inv == 0.0)) {
         if (E->nactive == E->capactive) {
             E->capactive = E->capactive ? E->capactive * 2 : 64;
@@ -803,7 +818,7 @@ void orc_destroy(orc_env *E)
 {
     if (!E) return;
     free(E->bodies); free(E->shapes); free(E->arbs); free(E->active); free(E->order); free(E->prev_wv);
-    free(E->solve); free(E->color); free(E->used);
+    free(E->solve); free(E->color); free(E->used); free(E->dist_map); free(E->wall_map); free(E->dist_raw);
     free(E);
 }
 
@@ -1334,4 +1349,342 @@ double orc_bench(const orc_params *P, int T, int F, int V, const double *verts, 
     free(envs);
     if (out_steps) *out_steps = total;
     return t1 - t0;
+}
+
+/* =============================================================================================================== */
+/* maze-NAMO-v0 (benchpush/environments/maze_NAMO/maze_NAMO_env.py), on the same restated Chipmunk step.            */
+/* Shapes: 0 = robot body (type 1), 1..4 = wheels (type 0), all on the KINEMATIC body 0 (robot.py:77-118);            */
+/*         5..4+nbox = boxes (type 2, create_polygon); then one static Segment(radius 0.5) per wall (type 3,          */
+/*         sim_utils.py:174-181), represented as a 2-vertex hull whose two planes are +-seg.n.                        */
+/* =============================================================================================================== */
+static void draw_polygon(int n, const double *r, const double *c, int H, int W, int clip, double *img, double val);
+
+/* compute_occ_img_walls (occupancy_map.py:67-94) */
+static void maze_wall_raster(orc_env *E, double *img, int H, int W)
+{
+    double m2p = (double)H / E->P.map_h;
+    double wr = E->P.wall_radius;
+    for (int w = 0; w < E->nwalls; w++) {
+        vec a = V(E->walls[w][0], E->walls[w][1]), b = V(E->walls[w][2], E->walls[w][3]);
+        vec d = vsub(b, a);
+        double len = sqrt(d.x * d.x + d.y * d.y);
+        vec u = V(d.x / len, d.y / len);
+        vec p = V(-u.y, u.x);
+        double vx[4], vy[4];
+        vx[0] = (a.x + wr * p.x - wr * u.x); vy[0] = (a.y + wr * p.y - wr * u.y);
+        vx[1] = (a.x - wr * p.x - wr * u.x); vy[1] = (a.y - wr * p.y - wr * u.y);
+        vx[2] = (b.x - wr * p.x + wr * u.x); vy[2] = (b.y - wr * p.y + wr * u.y);
+        vx[3] = (b.x + wr * p.x + wr * u.x); vy[3] = (b.y + wr * p.y + wr * u.y);
+        double r[4], c[4];
+        for (int i = 0; i < 4; i++) { c[i] = vx[i] * m2p; r[i] = vy[i] * m2p; }
+        draw_polygon(4, r, c, H, W, 1, img, 1.0);
+    }
+}
+/* global_goal_point_dist_transform (occupancy_map.py:435-485): 8-connected wavefront, +1 per hop, goal = 1 */
+static void maze_goal_map(orc_env *E)
+{
+    int H = E->map_h, W = E->map_w;
+    double g2m = E->P.map_w / (double)W;
+    int gx = (int)(E->P.goal_x / g2m), gy = (int)(E->P.goal_y / g2m);
+    double *edt = E->dist_raw;
+    memset(edt, 0, sizeof(double) * (size_t)H * W);
+    memset(E->wall_map, 0, sizeof(double) * (size_t)H * W);
+    maze_wall_raster(E, E->wall_map, H, W);
+    unsigned char *vis = (unsigned char *)calloc((size_t)H * W, 1);
+    int *q = (int *)malloc(sizeof(int) * (size_t)H * W);
+    int qh = 0, qt = 0;
+    edt[gy * W + gx] = 1.0; vis[gy * W + gx] = 1; q[qt++] = gy * W + gx;
+    static const int dy[8] = {0, 0, 1, -1, 1, 1, -1, -1}, dx[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+    double mx = 1.0;
+    while (qh < qt) {
+        int cur = q[qh++];
+        int y = cur / W, x = cur % W;
+        for (int k = 0; k < 8; k++) {
+            int ny = y + dy[k], nx = x + dx[k];
+            if (ny < 0 || ny >= H || nx < 0 || nx >= W) continue;
+            if (vis[ny * W + nx]) continue;
+            if (E->wall_map[ny * W + nx] == 1.0) continue;
+            vis[ny * W + nx] = 1;
+            edt[ny * W + nx] = edt[cur] + 1;
+            if (edt[ny * W + nx] > mx) mx = edt[ny * W + nx];
+            q[qt++] = ny * W + nx;
+        }
+    }
+    for (int i = 0; i < H * W; i++) {
+        E->dist_map[i] = edt[i] / mx;
+        if (E->wall_map[i] == 1.0) E->dist_map[i] = 1.0;
+    }
+    free(vis); free(q);
+}
+
+/* reset(): boxes given by centre (squares +-size), robot verts (8) + 4 wheels x 4 verts, walls [nw][4] = ax, ay, bx, by */
+int orc_maze_reset(orc_env *E, int nbox, const double *centres, double size, const double *robot_verts, int nrv,
+                   const double *wheel_verts, int nwheels, const double *walls, int nwalls, const double *start)
+{
+    free(E->bodies); free(E->shapes); free(E->order); free(E->prev_wv); free(E->used); E->used = NULL;
+    int nb = 1 + nbox + nwalls, ns = 1 + nwheels + nbox + nwalls;
+    E->bodies = (body_t *)calloc((size_t)nb, sizeof(body_t));
+    E->shapes = (shape_t *)calloc((size_t)ns, sizeof(shape_t));
+    E->order = (int *)calloc((size_t)ns, sizeof(int));
+    E->prev_wv = (double *)calloc((size_t)ns * ORC_MAXV * 2, sizeof(double));
+    E->narb = 0; E->nactive = 0; E->stamp = 0; E->curr_dt = 0.0;
+    E->total_work = 0.0; E->total_ke = 0.0; E->total_impulse = 0.0;
+    E->n_post_solve = E->n_contact_pts = E->n_first_contact = 0;
+    E->wall_collision = 0; E->have_prev_dist = 0; E->prev_dist = 0.0;
+    E->nwalls = nwalls;
+    for (int w = 0; w < nwalls; w++) for (int k = 0; k < 4; k++) E->walls[w][k] = walls[4 * w + k];
+    E->robot_nv = nrv;
+    for (int i = 0; i < nrv; i++) E->robot_verts[i] = V(robot_verts[2 * i], robot_verts[2 * i + 1]);
+    /* robot: KINEMATIC body with 5 Poly(radius 0.02) shapes; friction left at pymunk's default 0, elasticity 0.01 */
+    {
+        body_t *b = &E->bodies[0];
+        b->type = BODY_KINEMATIC; b->m = b->i = INFINITY; b->m_inv = b->i_inv = 0.0;
+        b->p = V(start[0], start[1]); b->a = start[2]; b->cog = V(0, 0);
+        body_set_transform(b);
+        for (int k = 0; k <= nwheels; k++) {
+            vec tmp[ORC_MAXV], hull[ORC_MAXV];
+            int n = (k == 0) ? nrv : 4;
+            const double *src = (k == 0) ? robot_verts : wheel_verts + 8 * (k - 1);
+            for (int i = 0; i < n; i++) tmp[i] = V(src[2 * i], src[2 * i + 1]);
+            int hn = convex_hull(n, tmp, hull);
+            shape_t *s = &E->shapes[k];
+            s->body = 0; s->r = E->P.poly_radius; s->e = E->P.elasticity; s->u = 0.0; s->ctype = (k == 0) ? 1 : 0;
+            shape_set_verts(s, hn, hull);
+        }
+    }
+    /* boxes: generate_obstacles + generate_sim_obs (maze_NAMO_env.py:313-321, sim_utils.py:136-163) */
+    for (int k = 0; k < nbox; k++) {
+        double ox = centres[2 * k], oy = centres[2 * k + 1];
+        double raw[8] = {ox + size, oy + size, ox - size, oy + size, ox - size, oy - size, ox + size, oy - size};
+        vec tmp[4], hull[4];
+        for (int i = 0; i < 4; i++) tmp[i] = V(raw[2 * i] - ox, raw[2 * i + 1] - oy);
+        int hn = convex_hull(4, tmp, hull);
+        vec cog = centroid_for_poly(hn, hull);
+        for (int i = 0; i < 4; i++) tmp[i] = V(tmp[i].x - cog.x, tmp[i].y - cog.y);
+        hn = convex_hull(4, tmp, hull);
+        int bi = 1 + k, si = 1 + nwheels + k;
+        shape_t *s = &E->shapes[si];
+        body_t *b = &E->bodies[bi];
+        s->body = bi; s->r = E->P.poly_radius; s->e = E->P.elasticity; s->u = E->P.friction; s->ctype = 2;
+        shape_set_verts(s, hn, hull);
+        vec scog = centroid_for_poly(hn, hull);
+        double area = area_for_poly(hn, hull, s->r);
+        double m = E->P.density * area;
+        double ipm = moment_for_poly(1.0, hn, hull, vneg(scog));
+        b->type = BODY_DYNAMIC;
+        double bm = 0.0, bI = 0.0; vec bc = V(0, 0);
+        double msum = bm + m;
+        bI += m * ipm + vdot(vsub(bc, scog), vsub(bc, scog)) * (m * bm) / msum;
+        bc = vlerp(bc, scog, m / msum);
+        bm = msum;
+        b->m = bm; b->i = bI; b->cog = bc; b->m_inv = 1.0 / bm; b->i_inv = 1.0 / bI;
+        b->a = 0.0;
+        b->p = vadd(V(bc.x * 1.0 - bc.y * 0.0, bc.x * 0.0 + bc.y * 1.0), V(ox, oy));
+        body_set_transform(b);
+    }
+    /* walls: STATIC body + Segment(a, b, 0.5), elasticity 0.5, friction 0.5, type 3 */
+    for (int w = 0; w < nwalls; w++) {
+        int bi = 1 + nbox + w, si = 1 + nwheels + nbox + w;
+        body_t *b = &E->bodies[bi];
+        b->type = BODY_STATIC; b->m = b->i = INFINITY; b->m_inv = b->i_inv = 0.0; b->p = V(0, 0); b->a = 0.0; b->cog = V(0, 0);
+        body_set_transform(b);
+        shape_t *s = &E->shapes[si];
+        s->body = bi; s->r = E->P.wall_radius; s->e = 0.5; s->u = 0.5; s->ctype = 3; s->n = 2;
+        vec a = V(walls[4 * w], walls[4 * w + 1]), bb = V(walls[4 * w + 2], walls[4 * w + 3]);
+        vec sn = vrperp(vnormalize(vsub(bb, a))); /* cpSegmentShapeInit: n = rperp(normalize(b - a)) */
+        s->lv[0] = a; s->lv[1] = bb; s->ln[0] = vneg(sn); s->ln[1] = sn;
+    }
+    E->nb = nb; E->ns = ns;
+    for (int i = 0; i < E->ns; i++) E->order[i] = i;
+    for (int s = 0; s < E->ns; s++) shape_cache_bb(&E->shapes[s], &E->bodies[E->shapes[s].body]);
+    /* global distance map (static per maze) */
+    int H = (int)(E->P.map_h * E->P.m_to_pix), W = (int)(E->P.map_w * E->P.m_to_pix);
+    if (E->map_h != H || E->map_w != W || !E->dist_map) {
+        free(E->dist_map); free(E->wall_map); free(E->dist_raw);
+        E->dist_map = (double *)calloc((size_t)H * W, sizeof(double));
+        E->wall_map = (double *)calloc((size_t)H * W, sizeof(double));
+        E->dist_raw = (double *)calloc((size_t)H * W, sizeof(double));
+        E->map_h = H; E->map_w = W;
+    }
+    maze_goal_map(E);
+    double dts = E->P.dt / E->P.steps;
+    for (int k = 0; k < E->P.settle_steps; k++) space_step(E, dts);
+    E->wall_collision = 0; /* reset() clears the flag after init (maze_NAMO_env.py:338) */
+    /* prev_obs snapshot of the box shapes */
+    for (int s = 0; s < E->ns; s++) {
+        const shape_t *sh = &E->shapes[s];
+        double *dst = E->prev_wv + (size_t)s * ORC_MAXV * 2;
+        for (int i = 0; i < sh->n; i++) { dst[2 * i] = sh->wv[i].x; dst[2 * i + 1] = sh->wv[i].y; }
+    }
+    return ns;
+}
+
+/* scipy.ndimage.rotate(img, deg, reshape=False, order=1, mode='constant', cval) restated (affine_transform ->
+ * NI_GeometricTransform, spline order 1); angle passed as (cos, sin) of the rotation. img, out: [n][n] doubles. */
+static void nd_rotate_order1(const double *img, int n, double c, double s, double cval, double *out)
+{
+    double ctr = ((double)n - 1) / 2;
+    /* rot_matrix = [[c, s], [-s, c]]; offset = in_center - rot_matrix @ out_center */
+    double oc0 = c * ctr + s * ctr, oc1 = -s * ctr + c * ctr;
+    double off0 = ctr - oc0, off1 = ctr - oc1;
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double c0 = 0.0, c1 = 0.0;
+            c0 += (double)i * c; c0 += (double)j * s; c0 += off0;
+            c1 += (double)i * -s; c1 += (double)j * c; c1 += off1;
+            double t;
+            if (c0 < 0 || c0 > n - 1 || c1 < 0 || c1 > n - 1) t = cval;
+            else {
+                int s0 = (int)floor(c0), s1 = (int)floor(c1);
+                double x0 = c0 - s0, x1 = c1 - s1;
+                double w0[2] = {1.0 - x0, x0}, w1[2] = {1.0 - x1, x1};
+                t = 0.0;
+                for (int a = 0; a < 2; a++)
+                    for (int b = 0; b < 2; b++) {
+                        int ii = s0 + a, jj = s1 + b;
+                        double coeff = (ii > n - 1 || jj > n - 1) ? cval : img[ii * n + jj];
+                        coeff *= w0[a];
+                        coeff *= w1[b];
+                        t += coeff;
+                    }
+            }
+            out[i * n + j] = t;
+        }
+}
+void orc_nd_rotate(const double *img, int n, double c, double s, double cval, double *out) { nd_rotate_order1(img, n, c, s, cval, out); }
+
+/* generate_observation -> OccupancyGrid.ego_view_map_maze (occupancy_map.py:142-202): u8 [4][LH][LW] */
+void orc_maze_observe(orc_env *E, uint8_t *obs)
+{
+    const orc_params *P = &E->P;
+    const body_t *rb = &E->bodies[0];
+    int H = E->map_h, W = E->map_w;
+    int LH = (int)(P->local_h * P->m_to_pix), LW = (int)(P->local_w * P->m_to_pix);
+    double *gobs = (double *)calloc((size_t)H * W, sizeof(double));
+    double *gfoot = (double *)calloc((size_t)H * W, sizeof(double));
+    /* compute_occ_img over every box (no range culling), occupancy_map.py:37-65 */
+    for (int s = 0; s < E->ns; s++) {
+        const shape_t *sh = &E->shapes[s];
+        if (sh->ctype != 2) continue;
+        double r[ORC_MAXV], c[ORC_MAXV];
+        for (int i = 0; i < sh->n; i++) { c[i] = sh->wv[i].x * P->m_to_pix; r[i] = sh->wv[i].y * P->m_to_pix; }
+        draw_polygon(sh->n, r, c, H, W, 1, gobs, 1.0);
+    }
+    /* _compute_global_footprint_maze (occupancy_map.py:340-376): robot body outline, vertices outside dropped */
+    double sx = rb->p.x, sy = rb->p.y, sa = rb->a;
+    {
+        double ch, shh;
+        bp_sincos(sa, &shh, &ch);
+        double m2gx = (double)W / P->map_w, m2gy = (double)H / P->map_h;
+        double r[ORC_MAXV], c[ORC_MAXV]; int cnt = 0;
+        for (int i = 0; i < E->robot_nv; i++) {
+            double vx = E->robot_verts[i].x * ch + E->robot_verts[i].y * -shh + sx;
+            double vy = E->robot_verts[i].x * shh + E->robot_verts[i].y * ch + sy;
+            double gx = vx * m2gx, gy = vy * m2gy;
+            if (gy < 0 || gy >= H || gx < 0 || gx >= W) continue;
+            r[cnt] = gy; c[cnt] = gx; cnt++;
+        }
+        if (cnt > 0) draw_polygon(cnt, r, c, H, W, 0, gfoot, 1.0);
+    }
+    int wx = (int)(sx * P->m_to_pix), wy = (int)(sy * P->m_to_pix);
+    int infl = (LW > LH ? LW : LH) / 2;
+    int IH = LH + infl, IW = LW + infl; /* 288 x 288 */
+    size_t ip = (size_t)IH * IW;
+    double *loc = (double *)malloc(sizeof(double) * ip * 4), *rot = (double *)malloc(sizeof(double) * ip);
+    for (size_t i = 0; i < ip; i++) { loc[i] = 0.0; loc[ip + i] = 0.0; loc[2 * ip + i] = 0.0; loc[3 * ip + i] = 1.0; }
+    for (int li = 0; li < IH; li++)
+        for (int lj = 0; lj < IW; lj++) {
+            int gi = (int)((double)(li + wy) - ((double)IH / 2));
+            int gj = (int)((double)(lj + wx) - ((double)IW / 2));
+            if (gi < 0 || gi >= H || gj < 0 || gj >= W) continue;
+            size_t l = (size_t)li * IW + lj, g = (size_t)gi * W + gj;
+            loc[l] = gfoot[g]; loc[ip + l] = gobs[g]; loc[2 * ip + l] = E->wall_map[g]; loc[3 * ip + l] = E->dist_map[g];
+        }
+    /* rotate by (heading - pi/2); cos/sin from the deterministic bp_sincos instead of scipy's cosdg/sindg */
+    double rs, rc;
+    bp_sincos(sa - M_PI / 2, &rs, &rc);
+    int half = infl / 2;
+    size_t pl = (size_t)LH * LW;
+    for (int ch = 0; ch < 4; ch++) {
+        nd_rotate_order1(loc + ip * ch, IH, rc, rs, ch == 3 ? 1.0 : 0.0, rot);
+        for (int i = 0; i < LH; i++)
+            for (int j = 0; j < LW; j++) obs[pl * ch + (size_t)i * LW + j] = (uint8_t)(rot[(size_t)(half + i) * IW + (half + j)] * 255);
+    }
+    free(gobs); free(gfoot); free(loc); free(rot);
+}
+
+enum { ORC_MI_X = 0, ORC_MI_Y, ORC_MI_THETA, ORC_MI_TOTAL_WORK, ORC_MI_WORK, ORC_MI_COLL_REWARD, ORC_MI_SCALED_COLL, ORC_MI_DIST_INC,
+       ORC_MI_SUCCESS, ORC_MI_BOUNDARY, ORC_MI_WALL, ORC_MI_KE, ORC_MI_IMPULSE, ORC_MI_NPOST, ORC_MI_NCONTACT, ORC_MI_NFIRST, ORC_MI_COUNT };
+
+/* MazeNAMO.step (maze_NAMO_env.py:402-485) */
+void orc_maze_step(orc_env *E, double action, uint8_t *obs, double *reward, int *terminated, double *info)
+{
+    const orc_params *P = &E->P;
+    body_t *rb = &E->bodies[0];
+    double sn, cs;
+    bp_sincos(rb->a, &sn, &cs);
+    rb->v = V(cs * P->target_speed + -sn * 0.0, sn * P->target_speed + cs * 0.0);
+    rb->w = action * P->max_yaw_rate;
+    int boundary = 0;
+    double dts = P->dt / P->steps;
+    for (int k = 0; k < P->steps; k++) {
+        space_step(E, dts);
+        if (rb->p.x < 0.0 || rb->p.x > P->map_w) boundary = 1;
+    }
+    double work = 0.0;
+    for (int s = 0; s < E->ns; s++) {
+        const shape_t *sh = &E->shapes[s];
+        if (sh->ctype != 2) continue;
+        double now[ORC_MAXV * 2];
+        for (int i = 0; i < sh->n; i++) { now[2 * i] = sh->wv[i].x; now[2 * i + 1] = sh->wv[i].y; }
+        double *prev = E->prev_wv + (size_t)s * ORC_MAXV * 2;
+        double area = poly_area_np(sh->n, prev);
+        double ax, ay, bx, by;
+        poly_centroid_np(sh->n, prev, &ax, &ay);
+        poly_centroid_np(sh->n, now, &bx, &by);
+        work += sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) * area;
+        memcpy(prev, now, sizeof(double) * 2 * (size_t)sh->n);
+    }
+    E->total_work += work;
+    double gd = sqrt((rb->p.x - P->goal_x) * (rb->p.x - P->goal_x) + (rb->p.y - P->goal_y) * (rb->p.y - P->goal_y));
+    int goal = gd <= P->goal_reach;
+    int term = goal || E->wall_collision;
+    int px = (int)(rb->p.x * P->m_to_pix), py = (int)(rb->p.y * P->m_to_pix);
+    if (px < 0) px = 0; if (px > E->map_w - 1) px = E->map_w - 1; if (py < 0) py = 0; if (py > E->map_h - 1) py = E->map_h - 1;
+    double dist_value = E->dist_map[(size_t)py * E->map_w + px];
+    double dinc = 0.0;
+    if (rb->p.x != P->goal_x || rb->p.y != P->goal_y) {
+        if (E->have_prev_dist) dinc = (E->prev_dist - dist_value) * P->k_increment;
+        E->prev_dist = dist_value; E->have_prev_dist = 1;
+    }
+    double coll = -work;
+    double r = P->beta * coll + dinc;
+    if (boundary || E->wall_collision) r += P->boundary_penalty;
+    int success = 0;
+    if (term && !E->wall_collision) { r += P->terminal_reward; success = 1; }
+    *reward = r; *terminated = term;
+    if (info) {
+        info[ORC_MI_X] = rb->p.x; info[ORC_MI_Y] = rb->p.y; info[ORC_MI_THETA] = rb->a; info[ORC_MI_TOTAL_WORK] = E->total_work;
+        info[ORC_MI_WORK] = work; info[ORC_MI_COLL_REWARD] = coll; info[ORC_MI_SCALED_COLL] = coll * P->beta; info[ORC_MI_DIST_INC] = dinc;
+        info[ORC_MI_SUCCESS] = success; info[ORC_MI_BOUNDARY] = boundary; info[ORC_MI_WALL] = E->wall_collision;
+        info[ORC_MI_KE] = E->total_ke; info[ORC_MI_IMPULSE] = E->total_impulse;
+        info[ORC_MI_NPOST] = (double)E->n_post_solve; info[ORC_MI_NCONTACT] = (double)E->n_contact_pts; info[ORC_MI_NFIRST] = (double)E->n_first_contact;
+    }
+    if (obs) orc_maze_observe(E, obs);
+}
+/* per-shape pose/velocity of the owning body: [ns][9] */
+void orc_get_shape_states(const orc_env *E, double *out)
+{
+    for (int s = 0; s < E->ns; s++) {
+        const body_t *b = &E->bodies[E->shapes[s].body];
+        double *o = out + 9 * (size_t)s;
+        o[0] = b->p.x; o[1] = b->p.y; o[2] = b->a; o[3] = b->v.x; o[4] = b->v.y; o[5] = b->w; o[6] = b->vb.x; o[7] = b->vb.y; o[8] = b->wb;
+    }
+}
+void orc_maze_maps(const orc_env *E, double *dist_norm, double *dist_raw, double *wall)
+{
+    size_t n = (size_t)E->map_h * E->map_w;
+    if (dist_norm) memcpy(dist_norm, E->dist_map, n * sizeof(double));
+    if (dist_raw) memcpy(dist_raw, E->dist_raw, n * sizeof(double));
+    if (wall) memcpy(wall, E->wall_map, n * sizeof(double));
 }

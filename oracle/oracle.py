@@ -26,7 +26,8 @@ class OrcParams(C.Structure):
                 ("m_to_pix", C.c_double), ("density", C.c_double), ("poly_radius", C.c_double),
                 ("elasticity", C.c_double), ("friction", C.c_double), ("beta", C.c_double),
                 ("boundary_penalty", C.c_double), ("terminal_reward", C.c_double), ("local_w", C.c_double),
-                ("local_h", C.c_double), ("vshift", C.c_double), ("obs_range", C.c_double)]
+                ("local_h", C.c_double), ("vshift", C.c_double), ("obs_range", C.c_double),
+                ("goal_x", C.c_double), ("goal_reach", C.c_double), ("k_increment", C.c_double), ("wall_radius", C.c_double)]
 
 
 def build(force=False):
@@ -69,6 +70,14 @@ def lib():
         L.orc_total_work.restype = C.c_double
         L.orc_total_work.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_crop.argtypes = [C.POINTER(OrcParams), C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_maze_reset.restype = C.c_int
+        L.orc_maze_reset.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p,
+                                     C.c_int, C.c_void_p]
+        L.orc_maze_step.argtypes = [C.c_void_p, C.c_double, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]
+        L.orc_maze_observe.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_get_shape_states.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_maze_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_nd_rotate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_bench.restype = C.c_double
         L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -232,3 +241,76 @@ def bench(params, ship_vertices, head, tail, packed, nenv, nsteps, nthreads, wit
                           _p(packed["starts"]), _p(packed["nfloes"]), len(sv), _p(sv), _p(hd), _p(tl), int(nenv), int(nsteps),
                           int(nthreads), int(with_obs), C.byref(n))
     return n.value, sec
+
+
+MAZE_INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scaled_collision_reward", "dist_increment_reward",
+                  "trial_success", "boundary_violated", "wall_collision", "total_ke", "total_impulse", "n_post_solve",
+                  "n_contact_pts", "n_first_contact"]
+
+
+class OracleMaze:
+    """Single-env oracle of maze-NAMO-v0 (maze_NAMO_env.py:325-485). `layout` = dict(centres [n,2], walls [w,4], start (x,y,th))."""
+
+    def __init__(self, params, robot_vertices, wheel_vertices, obstacle_size, brute_force=False):
+        self.L = lib()
+        p = OrcParams()
+        for k, v in params.items():
+            setattr(p, k, v)
+        p.brute_force = int(brute_force)
+        self.params = dict(params)
+        self.h = self.L.orc_create(C.byref(p))
+        self.rv = np.ascontiguousarray(robot_vertices, np.float64)
+        self.wv = np.ascontiguousarray(wheel_vertices, np.float64).reshape(-1, 4, 2)
+        self.size = float(obstacle_size)
+        self.obs_shape = (4, int(params["local_h"] * params["m_to_pix"]), int(params["local_w"] * params["m_to_pix"]))
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.L.orc_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def reset(self, layout, observe=True):
+        c = np.ascontiguousarray(layout["centres"], np.float64).reshape(-1, 2)
+        w = np.ascontiguousarray(layout["walls"], np.float64).reshape(-1, 4)
+        st = np.ascontiguousarray(layout["start"], np.float64)
+        self.ns = self.L.orc_maze_reset(self.h, len(c), _p(c), self.size, _p(self.rv), len(self.rv), _p(self.wv), len(self.wv),
+                                        _p(w), len(w), _p(st))
+        obs = None
+        if observe:
+            obs = np.zeros(self.obs_shape, np.uint8)
+            self.L.orc_maze_observe(self.h, _p(obs))
+        return obs
+
+    def step(self, action, observe=True):
+        obs = np.zeros(self.obs_shape, np.uint8) if observe else None
+        r, t = C.c_double(), C.c_int()
+        info = np.zeros(len(MAZE_INFO_KEYS), np.float64)
+        self.L.orc_maze_step(self.h, float(action), _p(obs) if observe else None, C.byref(r), C.byref(t), _p(info))
+        return obs, r.value, bool(t.value), dict(zip(MAZE_INFO_KEYS, info.tolist()))
+
+    def shape_states(self):
+        out = np.zeros((self.ns, 9), np.float64)
+        self.L.orc_get_shape_states(self.h, _p(out))
+        return out
+
+    def maps(self):
+        H, W = int(self.params["map_h"] * self.params["m_to_pix"]), int(self.params["map_w"] * self.params["m_to_pix"])
+        a, b, c = np.zeros((H, W)), np.zeros((H, W)), np.zeros((H, W))
+        self.L.orc_maze_maps(self.h, _p(a), _p(b), _p(c))
+        return a, b, c
+
+    def world_polys(self):
+        out = np.zeros((self.ns, MAXV, 2), np.float64)
+        cnt = np.zeros(self.ns, np.int32)
+        self.L.orc_get_world_polys(self.h, _p(out), _p(cnt))
+        return out, cnt
+
+
+def nd_rotate(img, c, s, cval):
+    img = np.ascontiguousarray(img, np.float64)
+    out = np.zeros_like(img)
+    lib().orc_nd_rotate(_p(img), img.shape[0], float(c), float(s), float(cval), _p(out))
+    return out
