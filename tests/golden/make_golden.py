@@ -20,6 +20,7 @@ for m in ["shapely", "shapely.geometry", "skimage", "skimage.draw", "skimage.mea
 
 from benchpush.common.evaluation.metrics import euclid_dist, total_work_done  # noqa: E402
 from benchpush.common.geometry.polygon import generate_polygon, poly_area, poly_centroid  # noqa: E402
+from benchpush.common.metrics.maze_namo_metric import MazeNamoMetric  # noqa: E402
 from benchpush.common.metrics.ship_ice_metric import ShipIceMetric  # noqa: E402
 from benchpush.common.occupancy_grid import occupancy_map as om  # noqa: E402
 from benchpush.common.utils.utils import DotDict  # noqa: E402
@@ -113,6 +114,30 @@ for ep in range(4):
     metric_cases.append({"reset_info": {"state": list(infos[0]["state"]), "total_work": 0.0}, "steps": steps,
                          "efficiency": m.efficiency_scores, "effort": m.effort_scores, "rewards": m.rewards})
 
+# 4b. maze metric ------------------------------------------------------------------------------------------
+maze_metric_cases = []
+rs = np.random.RandomState(5)
+goal_dt = (np.arange(240 * 240, dtype=np.float64).reshape(240, 240) % 977) + 1.0
+for ep in range(3):
+    m = MazeNamoMetric("alg", robot_mass=1)
+    x, y = 11.25, 3.75
+    info0 = {"state": (round(x, 2), round(y, 2), 1.57), "total_work": 0.0, "goal_dt": goal_dt, "m_to_pix_scale": 16}
+    m.reset(info0)
+    tw = 0.0
+    steps = []
+    n = 20 + 5 * ep
+    for t in range(n):
+        x += rs.uniform(-0.03, 0.03)
+        y += 0.12
+        tw += max(0.0, rs.uniform(-0.05, 0.1))
+        done = t == n - 1
+        info = {"state": (round(x, 2), round(y, 2), 1.57), "total_work": tw, "trial_success": bool(done and ep != 1)}
+        r = float(rs.uniform(-2, 1))
+        m.update(info, r, done)
+        steps.append({"info": {"state": list(info["state"]), "total_work": tw, "trial_success": info["trial_success"]}, "reward": r, "done": done})
+    maze_metric_cases.append({"reset_state": list(info0["state"]), "steps": steps, "efficiency": m.efficiency_scores,
+                              "effort": m.effort_scores, "rewards": m.rewards})
+
 # 5. configs -----------------------------------------------------------------------------------------------
 def jsonable(d):
     if isinstance(d, dict):
@@ -126,6 +151,6 @@ cfgs = {name: jsonable(DotDict.to_dict(DotDict.load_from_file(os.path.join(REF, 
         for name in ["ship_ice_nav", "maze_NAMO", "box_delivery"]}
 
 with open(os.path.join(HERE, "reference_golden.json"), "w") as f:
-    json.dump({"polygons": polys, "work": work_cases, "grid_dims": dims, "metrics": metric_cases, "configs": cfgs,
+    json.dump({"polygons": polys, "work": work_cases, "grid_dims": dims, "metrics": metric_cases, "maze_metrics": maze_metric_cases, "configs": cfgs,
                "euclid": float(euclid_dist((1.0, 2.0), (4.0, 6.0)))}, f)
 print("wrote golden fixtures")
