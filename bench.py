@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
+    ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze"],
+                    help="ship-ice = BASELINE.json configs[1] (the headline); maze = configs[2], informational")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -88,10 +90,16 @@ def main():
     from benchpush_amd.parallel import allgather_episode_metrics
 
     E = args.envs_per_gpu
-    trials = default_trials(args.concentration, args.trials, base_seed=0)
-    env = BatchedShipIceEnv(E, cfg={"concentration": args.concentration}, trials=trials, device=device,
-                            env_id_offset=rank * E)
-    nf_mean = float(np.mean([len(t["obstacles"]) for t in trials]))
+    if args.env == "maze":
+        from benchpush_amd.envs.maze_namo import BatchedMazeEnv
+        env = BatchedMazeEnv(E, cfg={"num_obstacles": 20}, num_layouts=args.trials, base_seed=0, device=device, env_id_offset=rank * E)
+        trials = env.layouts
+        nf_mean = 20.0
+    else:
+        trials = default_trials(args.concentration, args.trials, base_seed=0)
+        env = BatchedShipIceEnv(E, cfg={"concentration": args.concentration}, trials=trials, device=device,
+                                env_id_offset=rank * E)
+        nf_mean = float(np.mean([len(t["obstacles"]) for t in trials]))
     K, W = args.steps, args.warmup
     # actions ~ U(-1,1), counter-style: a generator keyed by (seed, rank); resident in HBM before timing
     g = torch.Generator(device=device)
@@ -139,8 +147,8 @@ def main():
     value = total_envs * K / tmax
 
     if rank == 0:
-        nb = int(round(nf_mean)) + 1
-        a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1)
+        nb = int(round(nf_mean)) + (11 if args.env == "maze" else 1)
+        a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         roof = {
             "bound": "hbm",
             "kernel": "k_physics_step",
@@ -161,19 +169,23 @@ def main():
             except Exception:
                 pass
         out = {
-            "metric": "env-steps/sec at N=4096 envs (ship-ice-v0), 1/2/4/8 MI355X",
+            "metric": "env-steps/sec at N=4096 envs (ship-ice-v0), 1/2/4/8 MI355X" if args.env == "ship-ice"
+                      else "env-steps/sec at N=4096 envs (maze-NAMO-v0), informational",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "ship-ice-v0, %d envs per GPU, %.0f%% concentration (mean %.1f floes), 400 sub-steps x 10 "
-                                   "solver iterations per env.step, 4x150x150 u8 obs, auto-reset" % (E, args.concentration * 100, nf_mean),
+            "config": {"workload": ("ship-ice-v0, %d envs per GPU, %.0f%% concentration (mean %.1f floes), 400 sub-steps x 10 "
+                                    "solver iterations per env.step, 4x150x150 u8 obs, auto-reset" % (E, args.concentration * 100, nf_mean))
+                                   if args.env == "ship-ice" else
+                                   ("maze-NAMO-v0, %d envs per GPU, 20 boxes, 400 sub-steps x 10 solver iterations per env.step, "
+                                    "4x192x192 u8 rotated obs, auto-reset" % E),
                        "envs_per_gpu": E, "total_envs": total_envs, "concentration": args.concentration,
                        "substeps_per_step": env.params["steps"], "auto_reset": not args.no_auto_reset,
                        "episodes_finished": int(allm[:, 0].sum().item()), "episodes_success": int(allm[:, 1].sum().item())},
             "substeps_per_s": value * env.params["steps"],
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.env == "ship-ice":
             out["cpu_baseline"] = cpu_baseline(env, trials)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
