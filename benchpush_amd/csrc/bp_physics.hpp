@@ -286,46 +286,47 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     for (int base = 0; base < ncand_slots; base += 64) {
         const int idx = base + lane;
         const int k = idx / kmax, s = idx - k * kmax;
-        bool valid = k < S.nmv;
-        int i = 0, j = 0;
-        if (valid) {
-            i = L.mv[k];
-            valid = s < (int)E.adjn[i];
-        }
-        if (valid) {
-            j = E.adj[i * BP_KADJ + s];
-            if (L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
-        }
+        // Loads are issued unconditionally on clamped (always valid) addresses so that independent ones travel together:
+        // round trip 1: neighbour id / count / hint / own AABB; 2: partner AABB, kinds, masses, radii, vertex counts;
+        // 3: the hinted plane; 4: the partner's vertices.
+        const bool inlist = k < S.nmv;
+        const int i = inlist ? (int)L.mv[k] : 0;
+        const int sc = min(s, BP_KADJ - 1);
+        const int adjn_i = E.adjn[i];
+        const int j = E.adj[i * BP_KADJ + sc] < E.nb ? (int)E.adj[i * BP_KADJ + sc] : 0;
+        const int h = E.hint[i * BP_KADJ + sc];
+        const double4 bbi = E.bb[i];
+        bool valid = inlist && (s < adjn_i);
+        if (valid && L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
+        const double4 bbj = E.bb[j];
+        const int ki = E.kind[i], kj = E.kind[j];
+        const double mi = E.mass[i].x, mj = E.mass[j].x;
+        const int sa = min(i, j), sb = max(i, j);
+        const double rsum = E.prop[sa].x + E.prop[sb].x;
+        const int nA_h = E.nv[sa], nB_h = E.nv[sb];
         bool flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
         if (valid) {
-            const int ki = E.kind[i], kj = E.kind[j];
             if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
-            else if (E.mass[i].x == 0.0 && E.mass[j].x == 0.0) {
+            else if (mi == 0.0 && mj == 0.0) {
                 const int ci = kind_ctype(ki), cj = kind_ctype(kj);
                 flagonly = (ci == 1 && cj == 3) || (ci == 3 && cj == 1);
                 valid = flagonly;
             }
         }
-        if (valid) valid = bb_overlap(E.bb[i], E.bb[j]);
-        int sa = min(i, j), sb = max(i, j);
-        const double rsum = valid ? (E.prop[sa].x + E.prop[sb].x) : 0.0;
-        if (valid) {
-            const int h = E.hint[i * BP_KADJ + s];
-            if (h != 255) {
-                const int nA = E.nv[sa], nB = E.nv[sb];
-                int pb, qb, fi;
-                if (h < nA) { pb = sa; qb = sb; fi = h; } else { pb = sb; qb = sa; fi = min(h - nA, nB - 1); }
-                const d2 fn = E.wn[pb * BP_MAXV + fi], fp = E.wv[pb * BP_MAXV + fi];
-                const int nq = E.nv[qb];
-                double mn = BP_INF;
-#pragma unroll 5
-                for (int q = 0; q < BP_MAXV; q++) { // several loads in flight at once; slots >= nq repeat vertex 0
-                    const double d = vdot(fn, E.wv[qb * BP_MAXV + (q < nq ? q : 0)]);
-                    if (d < mn) mn = d;
-                }
-                const double sep = mn - vdot(fn, fp);
-                if (sep > rsum) valid = false;
+        if (valid) valid = bb_overlap(bbi, bbj);
+        if (valid && h != 255) {
+            int pb, qb, fi;
+            if (h < nA_h) { pb = sa; qb = sb; fi = h; } else { pb = sb; qb = sa; fi = min(h - nA_h, nB_h - 1); }
+            const d2 fn = E.wn[pb * BP_MAXV + fi], fp = E.wv[pb * BP_MAXV + fi];
+            const int nq = (qb == sa) ? nA_h : nB_h;
+            double mn = BP_INF;
+#pragma unroll 10
+            for (int q = 0; q < BP_MAXV; q++) { // several loads in flight at once; slots >= nq repeat vertex 0
+                const double d = vdot(fn, E.wv[qb * BP_MAXV + (q < nq ? q : 0)]);
+                if (d < mn) mn = d;
             }
+            const double sep = mn - vdot(fn, fp);
+            if (sep > rsum) valid = false;
         }
         const unsigned long long cm = ballot(valid);
         PROF_ACC(2)
@@ -336,7 +337,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         // per-round LDS atomics see all planes of a pair together.
         const int nc = __popcll(cm);
         const int myr = popc_below(cm, lane); // rank of this lane's pair among the survivors
-        const int nA_l = valid ? E.nv[sa] : 0, nB_l = valid ? E.nv[sb] : 0;
+        const int nA_l = valid ? nA_h : 0, nB_l = valid ? nB_h : 0;
         int total = 0;
         {
             unsigned long long m = cm;
