@@ -8,7 +8,6 @@
 
 #define BP_KADJ 24   // Verlet neighbour slots per body
 #define BP_ACAP 64   // arbiter (contact pair) slots per env: one per lane
-#define BP_WAVE 64
 
 typedef double2 d2;
 

@@ -259,7 +259,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     const unsigned stamp_start = S.stamp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     for (int it = 0; it < nsub; it++) {
-        substep(P, D, E, L, A, S, P.dt_sub, mode == MODE_STEP);
+        substep(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
         if (S.quiescent && D.dbg == nullptr) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active

@@ -1,17 +1,16 @@
-// k_physics: one 64-lane wavefront per environment, persistent over all sub-steps of one env.step() / reset().
-//
-// Restates one pymunk.Space.step (Chipmunk2D 7.0.3 cpSpaceStep; reference call sites ship_ice_env.py:219,281)
-// per sub-step, wave-synchronously:
+// substep(): one pymunk.Space.step (Chipmunk2D 7.0.3 cpSpaceStep; reference call sites ship_ice_env.py:219,281,
+// maze_NAMO_env.py:268,415) for one environment, executed wave-synchronously by the 64 lanes of its wavefront:
 //   1  position integrate + world vertices + AABB of the bodies that move      (cpBodyUpdatePosition, cpPolyShapeCacheData)
 //   2  Verlet neighbour-list refresh for bodies that left their fat AABB          (any exact broadphase == cpBBTree)
-//   3  candidate pairs of moving bodies -> AABB test -> cached-axis early out     (cpSpaceCollideShapes / QueryReject)
-//   4  exact closest-feature query, 64 lanes per pair, + Chipmunk ContactPoints   (cpCollide PolyToPoly)
-//   5  arbiter slots (one per lane): hash-matched impulse carry-over, persistence  (cpArbiterUpdate, cpSpaceArbiterSetFilter)
-//   6  prestep, velocity integrate (damping 0), warm start, 10 sequential-impulse iterations scheduled by
-//      dependency level so that the result equals the sequential sweep in ascending (shapeA, shapeB) order
-//   7  ship x floe bookkeeping (ship_ice_env.py:155-173)
+//   3  candidate pairs of moving bodies -> AABB test -> cached-plane early out    (cpSpaceCollideShapes / QueryReject)
+//   4a plane separations of the surviving pairs, one (pair, plane) item per lane  (cpCollide: GJK/EPA closest features)
+//   4b normal + Chipmunk support edges + ContactPoints, one pair per lane
+//   4c manifolds handed to the arbiter slots (one per lane): impulse carry-over    (cpArbiterUpdate, cpSpaceArbiterSetFilter)
+//   5  prestep; warm set; velocity integrate (damping 0); warm start; sequential impulses colour by colour so that the
+//      result equals the sequential sweep in ascending (colour, shapeA, shapeB) order; exact fixed-point early exit
+//   6  agent x obstacle bookkeeping (ship_ice_env.py:155-173), agent rules, next moving list
 // Bodies that do not move and arbiters none of whose bodies moved produce exactly the results of the previous
-// sub-step, so they are carried over instead of recomputed (exactness argument in DESIGN.md).
+// sub-step, so they are carried over instead of recomputed (exactness argument in DESIGN.md section 4).
 #pragma once
 #include "bp_device.hpp"
 
@@ -203,8 +202,8 @@ __device__ __forceinline__ void apply_contact_impulses(const ArbReg &A, int c, d
 }
 
 // One sub-step.  ship_rules: apply the yaw / boundary rules of ShipIceEnv.step after the sub-step.
-__device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, const EnvCtx &E, const LdsCtx &L, ArbReg &A,
-                                        SubState &S, const double dt, const bool ship_rules)
+__device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, const LdsCtx &L, ArbReg &A, SubState &S,
+                                        const double dt, const bool ship_rules)
 {
     const int lane = lane_id();
     S.stamp += 1u;
@@ -216,7 +215,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     PROF_CNT(16, S.nmv)
 
     // ---- 1. integrate positions of the moving bodies; world geometry; AABBs ----------------------------------
-    unsigned long long refresh_any = 0;
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {
         const int k = k0 + lane;
         if (k < S.nmv) {
@@ -262,7 +260,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
         PROF_ACC(0)
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
         unsigned long long rm = ballot((lane < cnt) && L.rf[lane < cnt ? lane : 0]);
-        refresh_any |= rm;
         while (rm) {
             const int kk = __ffsll((long long)rm) - 1;
             rm &= rm - 1;
@@ -867,6 +864,4 @@ __device__ __forceinline__ void substep(const DevParams &P, const DevPtrs &D, co
     S.quiescent = (S.nmv == 0) && (wmask == 0);
     __syncthreads();
     PROF_ACC(9)
-    (void)refresh_any;
-    (void)D;
 }
