@@ -231,3 +231,33 @@ def test_cabi_call_order_errors():
     h2 = C.c_void_p()
     assert L.bp_create(C.byref(bad), 2, 0, 0, C.byref(h2)) == -1                              # BP_EINVAL
     assert L.bp_destroy(h) == 0
+
+
+def test_vec_env_protocol_autoreset_and_timelimit():
+    """SB3-shaped VecEnv over the batched env: shapes, auto-reset with terminal_observation, TimeLimit truncation."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    from benchpush_amd.envs.vec_env import make_ship_ice_vec_env
+    trials = default_trials(0.1, 3, base_seed=2)
+    venv = make_ship_ice_vec_env(6, cfg={"concentration": 0.1}, trials=trials)
+    venv.max_episode_steps = 20
+    obs = venv.reset()
+    assert obs.shape == (6, 4, 150, 150) and obs.dtype == np.uint8 and venv.num_envs == 6
+    first = obs.copy()
+    saw_trunc = saw_term = False
+    for t in range(45):
+        a = np.zeros(6, np.float32)
+        a[0] = 1.0                                   # env 0 steers into the channel boundary: terminated, not truncated
+        obs, rew, done, infos = venv.step(a)
+        assert obs.shape == (6, 4, 150, 150) and rew.shape == (6,) and done.shape == (6,) and len(infos) == 6
+        for e in range(6):
+            if done[e]:
+                assert infos[e]["terminal_observation"].shape == (4, 150, 150)
+                saw_trunc |= infos[e]["TimeLimit.truncated"]
+                saw_term |= not infos[e]["TimeLimit.truncated"]
+            else:
+                assert "terminal_observation" not in infos[e]
+        if t == 19:
+            assert done[1:].all()                    # TimeLimit after 20 steps for the envs still running
+    assert saw_trunc and saw_term
+    assert set(infos[0]) >= {"x", "y", "theta", "total_work", "trial_success"}
+    venv.close()
