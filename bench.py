@@ -41,14 +41,33 @@ def algorithmic_bytes_per_env_step(nb, nf, maxv=20, obs_bytes=4 * 150 * 150):
     return a_min, a_stream, state + geom + scal
 
 
+def effective_cores():
+    """Host cores this process may actually use: the cgroup CPU quota when it is below the visible CPU count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:           # cgroup v2: "<quota> <period>" or "max <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) // int(p))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(env, trials):
     """Oracle (CPU restatement, oracle/bp_oracle.c) timed on the host cores of this box, OpenMP over envs, on a bounded
     sample of the same workload: same trials, same 400 sub-steps x 10 iterations + observation raster per env.step()."""
     from benchpush_amd.scenario import pack_trials
     from oracle import oracle as orc
 
-    cores = os.cpu_count() or 1
-    nenv, steps = 2 * cores, 10
+    cores = effective_cores()
+    nenv, steps = 8 * cores, 10
     pk = pack_trials(trials[: min(len(trials), nenv)], max_verts=24)
     cfg = env.cfg
     orc.bench(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail, pk, min(nenv, 4), 1, cores)  # warm the library

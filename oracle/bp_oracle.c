@@ -207,6 +207,7 @@ typedef struct orc_env {
     double *dist_map, *wall_map; int map_h, map_w; /* normalised BFS goal map, wall raster */
     double *dist_raw;
     int have_prev_dist; double prev_dist;
+    double *ras_occ, *ras_foot, *ras_orient; size_t ras_n; /* raster scratch */
 } orc_env;
 
 /* ---- Chipmunk geometry helpers (cpPolyline.c cpConvexHull / cpChipmunk.c) restated ---- */
@@ -819,6 +820,7 @@ void orc_destroy(orc_env *E)
     if (!E) return;
     free(E->bodies); free(E->shapes); free(E->arbs); free(E->active); free(E->order); free(E->prev_wv);
     free(E->solve); free(E->color); free(E->used); free(E->dist_map); free(E->wall_map); free(E->dist_raw);
+    free(E->ras_occ); free(E->ras_foot); free(E->ras_orient);
     free(E);
 }
 
@@ -1191,9 +1193,16 @@ void orc_observe(orc_env *E, uint8_t *obs)
     int LH = (int)(P->local_h * P->m_to_pix), LW = (int)(P->local_w * P->m_to_pix);
     int bw = (int)(P->map_w * P->m_to_pix), bh = (int)(P->map_h * P->m_to_pix); /* ice_binary_w/h */
     size_t npx = (size_t)Hg * Wg;
-    double *occ = (double *)calloc((size_t)bh * bw, sizeof(double));
-    double *foot = (double *)malloc(npx * sizeof(double));
-    double *orient = (double *)calloc(npx, sizeof(double));
+    /* persistent per-env raster buffers (the reference allocates fresh numpy arrays; values are identical) */
+    if (E->ras_n < npx || (size_t)bh * bw > E->ras_n) {
+        size_t need = npx > (size_t)bh * bw ? npx : (size_t)bh * bw;
+        free(E->ras_occ); free(E->ras_foot); free(E->ras_orient);
+        E->ras_occ = (double *)malloc(need * sizeof(double)); E->ras_foot = (double *)malloc(need * sizeof(double));
+        E->ras_orient = (double *)malloc(need * sizeof(double)); E->ras_n = need;
+    }
+    double *occ = E->ras_occ, *foot = E->ras_foot, *orient = E->ras_orient;
+    memset(occ, 0, (size_t)bh * bw * sizeof(double));
+    memset(orient, 0, npx * sizeof(double));
     double sx = ship->p.x, sy = ship->p.y, sa = ship->a;
     /* compute_occ_img (occupancy_map.py:37-65) */
     for (int s = 1; s < E->ns; s++) {
@@ -1257,7 +1266,6 @@ void orc_observe(orc_env *E, uint8_t *obs)
             obs[2 * pl + px] = (uint8_t)(o * 255);
             obs[3 * pl + px] = (uint8_t)(oc * 255);
         }
-    free(occ); free(foot); free(orient);
 }
 
 /* ---- test hooks for the numpy-only golden vectors (tests/golden/) ------------------------------------- */
