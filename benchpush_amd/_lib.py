@@ -17,7 +17,7 @@ INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scale
              "n_contact_pts", "n_first_contact"]
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_load_maze", "bp_get_goal_map", "bp_reset", "bp_step", "bp_step_physics",
-           "bp_observe", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
+           "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_last_error"]
 
 
@@ -70,6 +70,7 @@ def load():
     L.bp_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.bp_step_physics.argtypes = [vp, vp, vp, vp, vp, vp, vp]
     L.bp_observe.argtypes = [vp, vp, vp, vp]
+    L.bp_observe_global.argtypes = [vp, vp, vp, vp]
     L.bp_get_world_polys.argtypes = [vp, vp, vp, vp]
     L.bp_get_body_state.argtypes = [vp, vp, vp]
     L.bp_get_low_dim_obs.argtypes = [vp, vp, vp]

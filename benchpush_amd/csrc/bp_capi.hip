@@ -429,6 +429,21 @@ int bp_observe(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream
     return launch(h, MODE_STEP, nullptr, env_mask, obs, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, false, true);
 }
 
+int bp_observe_global(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream)
+{
+    if (!h || !obs) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_observe_global before bp_load_scenarios/bp_reset");
+    if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_ESTATE, "global observation exists for ship-ice only");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int cell_px = (int)(0.2 * h->cfg.m_to_pix); // grid_width 0.2 m (ship_ice_env.py:97), block = int(0.2 * 25) = 5 px
+    if (cell_px <= 0 || h->P.grid_h % cell_px || h->P.grid_w % cell_px) return fail(h, BP_EINVAL, "raster is not a multiple of the cell");
+    const size_t lds = (size_t)4 * ((h->P.grid_h * h->P.grid_w + 31) / 32);
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_observe_global, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_observe_global, dim3(h->num_envs), dim3(OBS_THREADS), lds, (hipStream_t)stream, h->P, h->D, env_mask, obs, cell_px);
+    HIPCHK(h, hipGetLastError());
+    return BP_OK;
+}
+
 __global__ void k_export_polys(const DevParams P, const DevPtrs D, double *out, int *counts)
 {
     const int env = blockIdx.x;

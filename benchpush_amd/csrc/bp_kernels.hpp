@@ -978,3 +978,97 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe_maze(const DevParams P,
         o[3 * plane + px] = (unsigned char)(t3 * 255);
     }
 }
+
+
+// ------------------------------------------------------------------------------------------------------------
+// k_observe_global: planner observation of ship-ice (cfg.egocentric_obs: false, ship_ice_env.py:96-99,394-406):
+// uint8 [2][map_h/0.2][map_w/0.2]; ch0 = 5x5 block mean of the full 25 px/m occupancy raster (every floe, no range
+// culling; occupancy_map.py:37-65,97-109), ch1 = compute_ship_footprint_planner on the 0.2 m grid (:253-296).
+// The full 1000x300 raster lives as a bit-image in LDS (37.5 KB): floes are scattered into it polygon by polygon
+// with the skimage.draw.polygon rule, then each coarse cell counts its 25 bits.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(OBS_THREADS) void k_observe_global(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                                unsigned char *__restrict__ obs, const int cell_px)
+{
+    const int env = blockIdx.x;
+    if (mask != nullptr && mask[env] == 0) return;
+    const int tid = threadIdx.x;
+    const int nbcap = P.nbcap;
+    const size_t eb = (size_t)env * nbcap;
+    const int nb = D.e_nb[env];
+    const d2 *wv = D.wv + eb * BP_MAXV;
+    const int *nv = D.sc_nv + (size_t)D.e_trial[env] * nbcap;
+    const int bh = P.grid_h, bw = P.grid_w;              // fine raster (25 px/m)
+    const int Hc = bh / cell_px, Wc = bw / cell_px;      // coarse grid
+    const int nwords = (bh * bw + 31) / 32;
+    extern __shared__ double2 obs_smem[];
+    unsigned *s_bits = (unsigned *)obs_smem;
+    __shared__ double s_x[BP_MAXV], s_y[BP_MAXV];
+    __shared__ int s_box[4];
+    __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
+    __shared__ int s_fcnt;
+    for (int w = tid; w < nwords; w += OBS_THREADS) s_bits[w] = 0u;
+    __syncthreads();
+    for (int s = 1; s < nb; s++) {
+        const int n = nv[s];
+        if (tid < n) { const d2 v = wv[(size_t)s * BP_MAXV + tid]; s_x[tid] = v.x * P.m_to_pix; s_y[tid] = v.y * P.m_to_pix; }
+        __syncthreads();
+        if (tid == 0) {
+            double rmin = s_y[0], rmax = rmin, cmin = s_x[0], cmax = cmin;
+            for (int i = 1; i < n; i++) { rmin = fmin(rmin, s_y[i]); rmax = fmax(rmax, s_y[i]); cmin = fmin(cmin, s_x[i]); cmax = fmax(cmax, s_x[i]); }
+            long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
+            long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
+            if (maxr > bh - 1) maxr = bh - 1;
+            if (maxc > bw - 1) maxc = bw - 1;
+            s_box[0] = (int)minr; s_box[1] = (int)maxr; s_box[2] = (int)minc; s_box[3] = (int)maxc;
+        }
+        __syncthreads();
+        const int r0 = s_box[0], r1 = s_box[1], c0 = s_box[2], c1 = s_box[3];
+        if (r1 >= r0 && c1 >= c0) {
+            const int wbox = c1 - c0 + 1, npx = (r1 - r0 + 1) * wbox;
+            for (int q = tid; q < npx; q += OBS_THREADS) {
+                const int rr = q / wbox, cc = q - rr * wbox;
+                const int gi = r0 + rr, gj = c0 + cc;
+                if (pip_arrays(s_x, s_y, n, (double)gj, (double)gi)) {
+                    const int bit = gi * bw + gj;
+                    atomicOr(&s_bits[bit >> 5], 1u << (bit & 31));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ship footprint on the coarse grid
+    const d2 sp = D.pxy[eb];
+    const d2 srot = D.rot[eb];
+    if (tid == 0) {
+        const double ch = srot.x, sh = srot.y;
+        const double m2gx = (double)Wc / P.map_w, m2gy = (double)Hc / P.map_h;
+        int cnt = 0;
+        for (int i = 0; i < P.num_ship_verts; i++) {
+            const double vx = P.ship_verts[i][0] * ch + P.ship_verts[i][1] * -sh + sp.x;
+            const double vy = P.ship_verts[i][0] * sh + P.ship_verts[i][1] * ch + sp.y;
+            const double gx = vx * m2gx, gy = vy * m2gy;
+            if (gy < 0 || gy >= Hc || gx < 0 || gx >= Wc) continue;
+            s_fr[cnt] = gy; s_fc[cnt] = gx; cnt++;
+        }
+        s_fcnt = cnt;
+    }
+    __syncthreads();
+    const size_t plane = (size_t)Hc * Wc;
+    unsigned char *o = obs + (size_t)env * 2 * plane;
+    const double denom = (double)(cell_px * cell_px);
+    for (int cidx = tid; cidx < Hc * Wc; cidx += OBS_THREADS) {
+        const int gi = cidx / Wc, gj = cidx - gi * Wc;
+        int cnt = 0;
+        for (int a = 0; a < cell_px; a++)
+            for (int b = 0; b < cell_px; b++) {
+                const int bit = (gi * cell_px + a) * bw + (gj * cell_px + b);
+                cnt += (s_bits[bit >> 5] >> (bit & 31)) & 1u;
+            }
+        const double mean = (double)cnt / denom; // block sum is an exact integer; np.mean divides it by 25
+        o[cidx] = (unsigned char)(mean * 255);
+        unsigned char f = 0;
+        if (s_fcnt > 0 && pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) f = 255;
+        o[plane + cidx] = f;
+    }
+}

@@ -131,6 +131,15 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_observe(self.h, _ptr(m), _ptr(self.obs), self._stream()), "bp_observe")
         return self.obs
 
+    def observe_global(self, mask=None):
+        """Planner observation (cfg.egocentric_obs: false): uint8 [E, 2, map_h/0.2, map_w/0.2]."""
+        gh, gw = int(self.cfg.occ.map_height / 0.2), int(self.cfg.occ.map_width / 0.2)
+        if getattr(self, "_gobs", None) is None:
+            self._gobs = torch.zeros((self.num_envs, 2, gh, gw), dtype=torch.uint8, device=self.device)
+        m = None if mask is None else mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        _lib.check(self.L, self.h, self.L.bp_observe_global(self.h, _ptr(m), _ptr(self._gobs), self._stream()), "bp_observe_global")
+        return self._gobs
+
     def world_polys(self):
         """info['obs'] for every env: (verts [E, nb_cap, 20, 2] f64, counts [E, nb_cap] i32); index 0 is the ship."""
         out = torch.zeros((self.num_envs, self.nb_cap, _lib.MAXV, 2), dtype=torch.float64, device=self.device)
@@ -206,9 +215,11 @@ class ShipIceEnv(Env):
             n = len(self._b.trials[0]["obstacles"])
             self.observation_space = spaces.Box(low=-10, high=30, shape=(n * 2,), dtype=np.float64)
         else:
-            if not self.cfg.egocentric_obs:
-                raise NotImplementedError("global (planner) observation mode is outside the accelerated path")
-            self.observation_space = spaces.Box(low=0, high=255, shape=self._b.obs_shape, dtype=np.uint8)
+            if self.cfg.egocentric_obs:
+                obs_shape = self._b.obs_shape
+            else:  # planner observation (ship_ice_env.py:96-99)
+                obs_shape = (2, int(self.cfg.occ.map_height / 0.2), int(self.cfg.occ.map_width / 0.2))
+            self.observation_space = spaces.Box(low=0, high=255, shape=obs_shape, dtype=np.uint8)
         self.yaw_lim = (0, np.pi)
         self.boundary_violation_limit = 0.0
         self.total_work = [0, []]
@@ -225,6 +236,8 @@ class ShipIceEnv(Env):
         if self.low_dim_state:
             nb = int(self._b.num_bodies()[0])
             return self._b.low_dim_obs()[0, : nb - 1].reshape(-1).cpu().numpy()
+        if not self.cfg.egocentric_obs:
+            return self._b.observe_global()[0].cpu().numpy()
         return self._b.obs[0].cpu().numpy()
 
     def reset(self, seed=None, options=None):

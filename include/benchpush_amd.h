@@ -140,6 +140,10 @@ int bp_step_physics(bp_handle *h, const double *actions, double *reward, uint8_t
                     double *info, void *stream);
 int bp_observe(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream);
 
+/* Planner observation of ship-ice (cfg.egocentric_obs: false, ship_ice_env.py:96-99,394-406): device uint8
+ * [E][2][map_h/0.2][map_w/0.2] = [5x5 block-mean occupancy of every floe, ship footprint on the 0.2 m grid]. */
+int bp_observe_global(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream);
+
 /* info['obs'] (cost_map.py:275-281): world-space hull vertices of every shape, device double [E][nb_cap][BP_MAXV][2],
  * counts device int32 [E][nb_cap] (index 0 = ship, then floes in trial order). */
 int bp_get_world_polys(bp_handle *h, double *out, int32_t *counts, void *stream);

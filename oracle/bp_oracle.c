@@ -1696,3 +1696,48 @@ void orc_maze_maps(const orc_env *E, double *dist_norm, double *dist_raw, double
     if (dist_raw) memcpy(dist_raw, E->dist_raw, n * sizeof(double));
     if (wall) memcpy(wall, E->wall_map, n * sizeof(double));
 }
+
+/* ---- global (planner) observation, egocentric_obs: false (ship_ice_env.py:96-99,394-406): uint8 [2][H/5][W/5] ------- */
+/* ch0 = 5x5 block mean of the full 25 px/m occupancy raster (compute_occ_img without range culling + compute_con_gridmap,
+ * occupancy_map.py:37-65,97-109); ch1 = compute_ship_footprint_planner on the 0.2 m grid (:253-296). */
+void orc_observe_global(orc_env *E, double grid_m, uint8_t *obs)
+{
+    const orc_params *P = &E->P;
+    const body_t *ship = &E->bodies[0];
+    int Wg = (int)(P->map_w / grid_m), Hg = (int)(P->map_h / grid_m);
+    int bw = (int)(P->map_w * P->m_to_pix), bh = (int)(P->map_h * P->m_to_pix);
+    int by = (int)(grid_m * P->m_to_pix), bx = (int)(grid_m * P->m_to_pix);
+    double *occ = (double *)calloc((size_t)bh * bw, sizeof(double));
+    double *foot = (double *)calloc((size_t)Hg * Wg, sizeof(double));
+    for (int s = 1; s < E->ns; s++) {
+        const shape_t *sh = &E->shapes[s];
+        double r[ORC_MAXV], c[ORC_MAXV];
+        for (int i = 0; i < sh->n; i++) { c[i] = sh->wv[i].x * P->m_to_pix; r[i] = sh->wv[i].y * P->m_to_pix; }
+        draw_polygon(sh->n, r, c, bh, bw, 1, occ, 1.0);
+    }
+    {
+        double ch, shh;
+        bp_sincos(ship->a, &shh, &ch);
+        double m2gx = (double)Wg / P->map_w, m2gy = (double)Hg / P->map_h;
+        double r[ORC_MAXV + 8], c[ORC_MAXV + 8]; int cnt = 0;
+        for (int i = 0; i < E->ship_nv; i++) {
+            double vx = E->ship_verts[i].x * ch + E->ship_verts[i].y * -shh + ship->p.x;
+            double vy = E->ship_verts[i].x * shh + E->ship_verts[i].y * ch + ship->p.y;
+            double gx = vx * m2gx, gy = vy * m2gy;
+            if (gy < 0 || gy >= Hg || gx < 0 || gx >= Wg) continue;
+            r[cnt] = gy; c[cnt] = gx; cnt++;
+        }
+        if (cnt > 0) draw_polygon(cnt, r, c, Hg, Wg, 0, foot, 1.0);
+    }
+    size_t pl = (size_t)Hg * Wg;
+    for (int gi = 0; gi < Hg; gi++)
+        for (int gj = 0; gj < Wg; gj++) {
+            double sum = 0.0;
+            for (int a = 0; a < by; a++)
+                for (int b = 0; b < bx; b++) sum += occ[(size_t)(gi * by + a) * bw + (gj * bx + b)];
+            double mean = sum / (double)(by * bx);
+            obs[(size_t)gi * Wg + gj] = (uint8_t)(mean * 255);
+            obs[pl + (size_t)gi * Wg + gj] = (uint8_t)(foot[(size_t)gi * Wg + gj] * 255);
+        }
+    free(occ); free(foot);
+}

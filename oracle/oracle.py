@@ -78,6 +78,7 @@ def lib():
         L.orc_get_shape_states.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_maze_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_nd_rotate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
+        L.orc_observe_global.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.orc_bench.restype = C.c_double
         L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -135,6 +136,13 @@ class OracleShipIce:
         info = np.zeros(len(INFO_KEYS), np.float64)
         self.L.orc_step(self.h, float(action), _p(obs) if observe else None, C.byref(r), C.byref(t), _p(info))
         return obs, r.value, bool(t.value), dict(zip(INFO_KEYS, info.tolist()))
+
+    def observe_global(self, grid_m=0.2):
+        """Planner observation (egocentric_obs: false): uint8 [2, map_h/grid, map_w/grid]."""
+        shape = (2, int(self.params["map_h"] / grid_m), int(self.params["map_w"] / grid_m))
+        obs = np.zeros(shape, np.uint8)
+        self.L.orc_observe_global(self.h, float(grid_m), _p(obs))
+        return obs
 
     def info(self):
         info = np.zeros(len(INFO_KEYS), np.float64)

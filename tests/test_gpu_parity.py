@@ -261,3 +261,29 @@ def test_vec_env_protocol_autoreset_and_timelimit():
     assert saw_trunc and saw_term
     assert set(infos[0]) >= {"x", "y", "theta", "total_work", "trial_success"}
     venv.close()
+
+
+def test_global_planner_observation_matches_oracle():
+    """cfg.egocentric_obs: false -> uint8 [2, 200, 60] (5x5 block-mean occupancy + footprint), byte for byte."""
+    import benchpush_amd
+    from benchpush_amd.envs.ship_ice import default_trials
+    trials = default_trials(0.3, 2, base_seed=6)
+    env = _mk(2, 0.3, trials)
+    env.reset()
+    orcs = _oracles(env, 2)
+    for e, o in enumerate(orcs):
+        o.reset(trials[e % 2], observe=False)
+    for t in range(6):
+        a = np.array([0.3, -0.5], np.float32).astype(np.float64)
+        env.step(torch.from_numpy(a))
+        g = env.observe_global().cpu().numpy()
+        assert g.shape == (2, 2, 200, 60)
+        for e, o in enumerate(orcs):
+            o.step(float(a[e]), observe=False)
+            og = o.observe_global()
+            assert np.array_equal(g[e], og), (t, e)
+    assert 0.2 < g[0, 0].mean() / 255 < 0.4 and (g[0, 1] == 255).sum() > 5
+    single = benchpush_amd.make("ship-ice-v0", cfg={"concentration": 0.3, "egocentric_obs": False}, trials=trials).unwrapped
+    obs, info = single.reset()
+    assert obs.shape == (2, 200, 60) and single.observation_space.shape == (2, 200, 60)
+    single.close()
