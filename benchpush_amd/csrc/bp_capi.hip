@@ -549,6 +549,16 @@ int bp_check_errors(bp_handle *h, int32_t *out_host)
     return BP_OK;
 }
 
+int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
+{
+    if (!h || !out_host) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out_host, h->D.e_cost, sizeof(unsigned) * h->num_envs, hipMemcpyDeviceToHost));
+    return BP_OK;
+}
+
 int bp_enable_timing(bp_handle *h, int32_t on)
 {
     if (!h) return BP_EINVAL;

@@ -242,19 +242,42 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         __syncthreads();
         const int cnt = min(64, S.nmv - k0);
-        for (int g0 = 0; g0 < cnt; g0 += 2) {
-            const int kk = g0 + (lane >> 5);
-            const bool act = kk < cnt;
-            const int i = act ? L.mv[k0 + kk] : 0;
-            double4 t;
-            { const d2 t0 = L.tf[2 * (act ? kk : 0)], t1 = L.tf[2 * (act ? kk : 0) + 1]; t.x = t0.x; t.y = t0.y; t.z = t1.x; t.w = t1.y; }
-            double4 nbb;
-            world_from_pose(P, E, i, act, lane & 31, t, nbb);
-            if (act && (lane & 31) == 0) {
-                E.bb[i] = nbb;
-                const double4 f = E.fat[i];
-                L.rf[kk] = !(nbb.x >= f.x && nbb.y >= f.y && nbb.z <= f.z && nbb.w <= f.w);
+        // world vertices / normals, one (body, vertex) item per lane; AABB through LDS atomic min/max on order-preserving
+        // keys (min and max are exact, so the reduction order is irrelevant).  bbk aliases the narrow-phase scratch.
+        unsigned long long *bbk = L.res_smA; // [64][4] = min x, max x, min y, max y
+        if (lane < cnt) { bbk[lane * 4 + 0] = ~0ull; bbk[lane * 4 + 1] = 0ull; bbk[lane * 4 + 2] = ~0ull; bbk[lane * 4 + 3] = 0ull; }
+        lds_sync();
+        for (int t0 = 0; t0 < cnt * BP_MAXV; t0 += 64) {
+            const int t = t0 + lane;
+            const int kk = t / BP_MAXV, q = t - kk * BP_MAXV;
+            if (kk < cnt) {
+                const int i = L.mv[k0 + kk];
+                if (q < E.nv[i]) {
+                    const d2 t0_ = L.tf[2 * kk], t1_ = L.tf[2 * kk + 1];
+                    const double c = t0_.x, s = t0_.y;
+                    const d2 lv = E.lv[i * BP_MAXV + q], ln = E.ln[i * BP_MAXV + q];
+                    const double vx = (c * lv.x + (-s) * lv.y) + t1_.x;
+                    const double vy = (s * lv.x + c * lv.y) + t1_.y;
+                    const double nx = c * ln.x + (-s) * ln.y;
+                    const double ny = s * ln.x + c * ln.y;
+                    E.wv[i * BP_MAXV + q] = mk2(vx, vy);
+                    E.wn[i * BP_MAXV + q] = mk2(nx, ny);
+                    const unsigned long long kx = f64_key(vx), ky = f64_key(vy);
+                    atomicMin(&bbk[kk * 4 + 0], kx); atomicMax(&bbk[kk * 4 + 1], kx);
+                    atomicMin(&bbk[kk * 4 + 2], ky); atomicMax(&bbk[kk * 4 + 3], ky);
+                }
             }
+        }
+        lds_sync();
+        if (lane < cnt) {
+            const int i = L.mv[k0 + lane];
+            const double rad = E.prop[i].x;
+            double4 nbb;
+            nbb.x = key_f64(bbk[lane * 4 + 0]) - rad; nbb.y = key_f64(bbk[lane * 4 + 2]) - rad;
+            nbb.z = key_f64(bbk[lane * 4 + 1]) + rad; nbb.w = key_f64(bbk[lane * 4 + 3]) + rad;
+            E.bb[i] = nbb;
+            const double4 f = E.fat[i];
+            L.rf[lane] = !(nbb.x >= f.x && nbb.y >= f.y && nbb.z <= f.z && nbb.w <= f.w);
         }
         __syncthreads();
         PROF_ACC(0)

@@ -173,6 +173,12 @@ class BatchedShipIceEnv(_BatchedBase):
         """Re-run the 1000 settle sub-steps on every reset instead of copying the settled per-trial template."""
         self.L.bp_set_resettle(self.h, int(on))
 
+    def step_cycles(self):
+        """Shader cycles each env's wavefront spent in the last step (numpy uint64 [E])."""
+        out = np.zeros(self.num_envs, np.uint32)
+        _lib.check(self.L, self.h, self.L.bp_get_step_cycles(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_step_cycles")
+        return out.astype(np.uint64) << 8
+
     def enable_timing(self, on=True):
         self.L.bp_enable_timing(self.h, int(on))
 

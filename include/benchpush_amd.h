@@ -163,6 +163,8 @@ int bp_check_errors(bp_handle *h, int32_t *out_host);
  * measured with HIP events on the launch stream (synchronises). */
 int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32_t *launches);
 int bp_enable_timing(bp_handle *h, int32_t on);
+/* shader cycles >> 8 each env's wavefront spent in the last bp_step (the dispatch-order hint): host uint32 [E] (synchronises) */
+int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
 
 const char *bp_last_error(const bp_handle *h);
 int32_t bp_abi_version(void);
