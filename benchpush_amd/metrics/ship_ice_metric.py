@@ -1,53 +1,35 @@
-"""ShipIceMetric: efficiency / interaction-effort scores of one ship-ice episode.
+"""ShipIceMetric (reference: benchpush/common/metrics/ship_ice_metric.py:5-72): L = goal line - start y.
 
-Same arithmetic and call protocol as the reference's benchpush/common/metrics/ship_ice_metric.py:5-72
-(``reset(info)`` at episode start, ``update(info, reward, eps_complete)`` per step):
-efficiency = 1[success] * (goal_y - y0) / sum ||d(x, y)|| of the *rounded* info['state'];
-effort = m0*l0 / (m0*l0 + total_work).  ``BatchedShipIceMetric`` keeps the same quantities as device tensors for
-E envs and produces the fixed-shape block that crosses GPUs (benchpush_amd.parallel.allgather_episode_metrics).
+``BatchedShipIceMetric`` keeps the same quantities as device tensors for E envs and produces the fixed-shape block that
+crosses GPUs (benchpush_amd.parallel.allgather_episode_metrics).
 """
 import numpy as np
 import torch
 
-from .base_metric import BaseMetric
+from .interactive_nav import PathEffortMetric
 
 
-class ShipIceMetric(BaseMetric):
+class ShipIceMetric(PathEffortMetric):
     def __init__(self, alg_name, ship_mass, goal) -> None:
-        super().__init__(alg_name=alg_name)
-        self.eps_reward = 0
-        self.total_mass_dist = 0
+        super().__init__(alg_name, ship_mass)
         self.ship_mass = ship_mass
-        self.total_ship_dist = 0
         self.goal_line = goal[1]
 
-    def compute_efficiency_score(self):
-        if not self.trial_success:
-            return 0
-        return self.L / self.total_ship_dist
+    # names the reference exposes
+    @property
+    def total_ship_dist(self):
+        return self._l0
 
-    def compute_effort_score(self):
-        return (self.ship_mass * self.total_ship_dist) / (self.ship_mass * self.total_ship_dist + self.total_mass_dist)
+    @property
+    def total_mass_dist(self):
+        return self._work
 
-    def update(self, info, reward, eps_complete=False):
-        self.eps_reward += reward
-        self.total_mass_dist = info["total_work"]
-        self.trial_success = info["trial_success"]
-        ship_state = info["state"]
-        self.total_ship_dist += np.linalg.norm(np.array(self.ship_state[:2]) - np.array(ship_state[:2]))
-        self.ship_state = ship_state
-        if eps_complete:
-            self.rewards.append(self.eps_reward)
-            self.efficiency_scores.append(self.compute_efficiency_score())
-            self.effort_scores.append(self.compute_effort_score())
+    @property
+    def ship_state(self):
+        return self._state
 
-    def reset(self, info):
-        self.eps_reward = 0
-        self.total_mass_dist = 0
-        self.total_ship_dist = 0
-        self.trial_success = False
-        self.ship_state = info["state"]
-        self.L = self.goal_line - self.ship_state[1]
+    def _free_path_length(self, info):
+        return self.goal_line - info["state"][1]
 
 
 def _round2(t):
