@@ -208,6 +208,11 @@ typedef struct orc_env {
     double *dist_raw;
     int have_prev_dist; double prev_dist;
     double *ras_occ, *ras_foot, *ras_orient; size_t ras_n; /* raster scratch */
+    /* box-delivery-v0 (bp_oracle_bd.c) */
+    int kind;                  /* 0 = ship-ice / maze, 2 = box-delivery (collision handlers of box_delivery_env.py:208-229) */
+    unsigned char *removed;    /* per shape: space.remove(body, shape) was called (box_delivery_env.py:765-767) */
+    int robot_hit;             /* robot_hit_obstacle, written by the (1,3) pre_solve (box_delivery_env.py:208-210) */
+    struct { uint32_t key; } *events; int nevents, capevents; /* (1,3)/(2,3) pre_solve calls of this sub-step */
 } orc_env;
 
 /* ---- Chipmunk geometry helpers (cpPolyline.c cpConvexHull / cpChipmunk.c) restated ---- */
@@ -503,6 +508,7 @@ static void collide_pair(orc_env *E, int sa, int sb)
     if (!(A->bl <= B->br && B->bl <= A->br && A->bb <= B->bt && B->bb <= A->bt)) return;
     if (A->body == B->body) return;
     if (E->bodies[A->body].type == BODY_STATIC && E->bodies[B->body].type == BODY_STATIC) return; /* never queried by Chipmunk */
+    if (E->removed && (E->removed[sa] || E->removed[sb])) return;
     E->stat_pairs_bb++;
     manifold_t m;
     collide_poly_poly(A, B, &m);
@@ -532,7 +538,21 @@ static void collide_pair(orc_env *E, int sa, int sb)
     /* begin/pre_solve handlers of the reference always return True (ship_ice_env.py:150-153);
      * the maze's (1,3) robot x wall pre_solve additionally raises a flag (maze_NAMO_env.py:203-205) */
     if ((A->ctype == 1 && B->ctype == 3) || (A->ctype == 3 && B->ctype == 1)) E->wall_collision = 1;
-    if (!(a->m_inv == 0.0 && b->m_inv == 0.0)) {
+    int presolve_ok = 1;
+    if (E->kind == 2) {
+        /* box_delivery_env.py:208-229: (1,3) and (2,3) pre_solve -> prevent_boundary_intersection (deferred to the end of
+         * the collision phase and run in ascending key order, see space_step); (2,4) pre_solve returns False;
+         * (1,4) begin returns False (both bodies have infinite mass anyway).  Shape order: A is the robot/box, B the static. */
+        if ((A->ctype == 1 || A->ctype == 2) && B->ctype == 3) {
+            if (E->nevents == E->capevents) {
+                E->capevents = E->capevents ? E->capevents * 2 : 32;
+                E->events = realloc(E->events, (size_t)E->capevents * sizeof(*E->events));
+            }
+            E->events[E->nevents++].key = arb_key(sa, sb);
+        }
+        if (A->ctype == 2 && B->ctype == 4) presolve_ok = 0;
+    }
+    if (presolve_ok && !(a->m_inv == 0.0 && b->m_inv == 0.0)) {
         if (E->nactive == E->capactive) {
             E->capactive = E->capactive ? E->capactive * 2 : 64;
             E->active = (int *)realloc(E->active, (size_t)E->capactive * sizeof(int));
@@ -628,6 +648,34 @@ static void arb_apply_impulse(orc_env *E, arb_t *arb)
     }
 }
 
+/* BoxDeliveryEnv.prevent_boundary_intersection (box_delivery_env.py:294-311) for every (1,3)/(2,3) pair that touched in
+ * this sub-step.  pymunk calls it from inside the collision phase in BB-tree pair order; here the calls run after the
+ * collision phase in ascending (shapeA, shapeB) order (same documented choice as the solve order).  contact_point_set:
+ * cpArbiterGetContactPointSet (normal = n, distance = dot((b.p + r2) - (a.p + r1), n) with the bodies' current positions). */
+static void bd_run_presolve(orc_env *E)
+{
+    qsort(E->events, (size_t)E->nevents, sizeof(*E->events), cmp_u32);
+    for (int k = 0; k < E->nevents; k++) {
+        int pos;
+        if (!arb_find(E, E->events[k].key, &pos)) continue;
+        arb_t *arb = &E->arbs[pos];
+        if (arb->count == 0) continue;
+        body_t *a = &E->bodies[E->shapes[arb->sa].body], *b = &E->bodies[E->shapes[arb->sb].body];
+        vec n = arb->n;
+        vec v = a->v;
+        double f = 2 * (v.x * n.x + v.y * n.y);
+        vec refl = V(v.x - n.x * f, v.y - n.y * f);
+        vec nv = V(refl.x * 0.5, refl.y * 0.5);
+        vec p1 = vadd(a->p, arb->con[0].r1), p2 = vadd(b->p, arb->con[0].r2);
+        double depth = vdot(vsub(p2, p1), n);
+        if (E->shapes[arb->sa].ctype == 1) E->robot_hit = depth < 0;
+        a->p = V(a->p.x + n.x * depth, a->p.y + n.y * depth);
+        body_set_transform(a);
+        a->v = nv;
+    }
+    E->nevents = 0;
+}
+
 /* pymunk.Space.step(dt) == Chipmunk2D 7.0.3 cpSpaceStep (cpSpaceStep.c), restated */
 static void space_step(orc_env *E, double dt)
 {
@@ -681,6 +729,7 @@ static void space_step(orc_env *E, double dt)
         }
         qsort(E->active, (size_t)E->nactive, sizeof(int), cmp_u32);
     }
+    if (E->kind == 2 && E->nevents) bd_run_presolve(E);
     /* cpSpaceArbiterSetFilter over the cached arbiter set */
     {
         int w = 0;
@@ -820,7 +869,7 @@ void orc_destroy(orc_env *E)
     if (!E) return;
     free(E->bodies); free(E->shapes); free(E->arbs); free(E->active); free(E->order); free(E->prev_wv);
     free(E->solve); free(E->color); free(E->used); free(E->dist_map); free(E->wall_map); free(E->dist_raw);
-    free(E->ras_occ); free(E->ras_foot); free(E->ras_orient);
+    free(E->ras_occ); free(E->ras_foot); free(E->ras_orient); free(E->removed); free(E->events);
     free(E);
 }
 
@@ -1741,3 +1790,5 @@ void orc_observe_global(orc_env *E, double grid_m, uint8_t *obs)
         }
     free(occ); free(foot);
 }
+
+#include "bp_oracle_bd.c"

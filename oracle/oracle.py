@@ -31,7 +31,7 @@ class OrcParams(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "bp_oracle.c")):
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("bp_oracle.c", "bp_oracle_bd.c")):
         subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
     return _SO
 
