@@ -10,7 +10,10 @@ from .build import LIB_PATH
 MAXV = 20
 MAX_SHIP_VERTS = 32
 MAX_WHEELS = 4
-ENV_SHIP_ICE, ENV_MAZE = 0, 1
+ENV_SHIP_ICE, ENV_MAZE, ENV_BOX = 0, 1, 2
+BD_MAXBOX, BD_MAXWP = 24, 64
+BD_INFO_KEYS = ["x", "y", "theta", "cumulative_distance", "cumulative_boxes", "cumulative_reward", "total_work", "ministeps", "inactivity",
+                "robot_hit_obstacle", "substeps", "robot_distance", "boxes_distance", "num_waypoints", "num_boxes_left", "work"]
 INFO_COUNT = 16
 INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scaled_collision_reward", "dist_reward",
              "trial_success", "boundary_violated", "yaw_violated", "total_ke", "total_impulse", "n_post_solve",
@@ -18,7 +21,8 @@ INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scale
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_load_maze", "bp_get_goal_map", "bp_reset", "bp_step", "bp_step_physics",
            "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
-           "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_last_error"]
+           "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_last_error",
+           "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state"]
 
 
 class BpConfig(C.Structure):
@@ -35,6 +39,20 @@ class BpConfig(C.Structure):
                 ("env_kind", C.c_int32), ("num_wheels", C.c_int32), ("wheel_verts", ((C.c_double * 2) * 4) * MAX_WHEELS),
                 ("goal_x", C.c_double), ("goal_reach", C.c_double), ("k_increment", C.c_double), ("wall_radius", C.c_double),
                 ("obstacle_size", C.c_double)]
+
+
+class BpBdConfig(C.Structure):
+    _fields_ = [("ctrl_dt", C.c_double), ("steps", C.c_int32), ("iterations", C.c_int32), ("persistence", C.c_int32), ("settle_steps", C.c_int32),
+                ("damping_pow", C.c_double), ("bias_coef", C.c_double), ("slop", C.c_double),
+                ("room_length", C.c_double), ("room_width", C.c_double), ("recept_x", C.c_double), ("recept_y", C.c_double),
+                ("recept_size", C.c_double), ("ppm", C.c_double), ("local_w", C.c_double), ("local_px", C.c_int32),
+                ("use_correct_direction_reward", C.c_int32), ("robot_radius", C.c_double), ("robot_half_width", C.c_double),
+                ("step_size", C.c_double), ("target_speed", C.c_double), ("partial_rewards_scale", C.c_double), ("goal_reward", C.c_double),
+                ("collision_penalty", C.c_double), ("non_movement_penalty", C.c_double), ("correct_direction_reward_scale", C.c_double),
+                ("ministep_size", C.c_double), ("sp_channel_scale", C.c_double), ("inactivity_cutoff", C.c_int32),
+                ("invert_receptacle_map", C.c_int32), ("num_boxes", C.c_int32), ("step_limit", C.c_int32),
+                ("box_half", C.c_double), ("box_density", C.c_double), ("robot_verts", (C.c_double * 2) * 4),
+                ("wheel_verts", ((C.c_double * 2) * 4) * 4), ("bumper_verts", (C.c_double * 2) * 4)]
 
 
 class BpError(RuntimeError):
@@ -87,6 +105,13 @@ def load():
     L.bp_debug_trace.argtypes = [vp, vp, C.c_int32]
     L.bp_set_resettle.argtypes = [vp, C.c_int32]
     L.bp_debug_prof.argtypes = [vp, vp]
+    L.bp_bd_sizeof_config.restype = C.c_int32
+    if L.bp_bd_sizeof_config() != C.sizeof(BpBdConfig):
+        raise BpError("bp_bd_config layout mismatch between _lib.BpBdConfig and the library")
+    L.bp_bd_create.argtypes = [C.POINTER(BpBdConfig), C.c_int32, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.bp_bd_load.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, C.c_int32, vp, vp, vp, vp, vp]
+    L.bp_bd_get_maps.argtypes = [vp, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.bp_bd_get_state.argtypes = [vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -125,3 +150,24 @@ def make_config(params, ship_vertices, head, tail, env_kind=ENV_SHIP_ICE, wheel_
     cfg.ship_head[0], cfg.ship_head[1] = float(head[0]), float(head[1])
     cfg.ship_tail[0], cfg.ship_tail[1] = float(tail[0]), float(tail[1])
     return cfg
+
+
+def make_bd_config(phys, bd, cfg):
+    """bp_bd_config from box_delivery_scenario.box_delivery_physics_params / box_delivery_params and the merged cfg."""
+    c = BpBdConfig()
+    fields = {f[0] for f in BpBdConfig._fields_}
+    for src in (phys, bd):
+        for k, v in src.items():
+            if k in fields:
+                setattr(c, k, v)
+    c.ctrl_dt = float(phys["dt"])
+    c.box_half = float(cfg.boxes.box_size) / 2
+    c.box_density = float(cfg.boxes.box_density)
+    for i, (x, y) in enumerate(cfg.agent.vertices):
+        c.robot_verts[i][0], c.robot_verts[i][1] = float(x), float(y)
+    for w, quad in enumerate(cfg.agent.wheel_vertices):
+        for i, (x, y) in enumerate(quad):
+            c.wheel_verts[w][i][0], c.wheel_verts[w][i][1] = float(x), float(y)
+    for i, (x, y) in enumerate(cfg.agent.front_bumper_vertices):
+        c.bumper_verts[i][0], c.bumper_verts[i][1] = float(x), float(y)
+    return c

@@ -9,8 +9,8 @@
 #include <string>
 #include <vector>
 
-#include "bp_host_geom.hpp"
-#include "bp_kernels.hpp"
+#include "bp_host_bd.hpp"
+#include "bp_boxdelivery.hpp"
 
 struct bp_handle {
     bp_config cfg;
@@ -29,6 +29,13 @@ struct bp_handle {
     size_t lds_bytes = 0, obs_lds_bytes = 0;
     std::string err;
     std::vector<double> goal_raw; // maze: un-normalised wavefront map (info['goal_dt'])
+    // box-delivery
+    bp_bd_config bdcfg;
+    BdParams B;
+    BdPtrs Q;
+    size_t bd_lds = 0, bd_obs_lds = 0;
+    std::vector<bpgeom::BdMaps> bd_maps;
+    std::vector<int> bd_map_of_trial;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev; // triples: start, mid, stop
@@ -63,7 +70,7 @@ static int dalloc(bp_handle *h, T **p, size_t n, int fill_byte = 0)
 static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
 static size_t lds_bytes_for(int nbcap)
 {
-    return sizeof(d2) * BP_NSLOT * 3 + sizeof(d2) * 128 + 2560 + sizeof(unsigned) * nbcap + sizeof(unsigned short) * nbcap * 2 +
+    return sizeof(d2) * 3 * BP_EVCAP + sizeof(unsigned) * BP_EVCAP + 16 + sizeof(d2) * BP_NSLOT * 3 + sizeof(d2) * 128 + 2560 + sizeof(unsigned) * nbcap + sizeof(unsigned short) * nbcap * 2 +
            sizeof(unsigned short) * mvcap_for(nbcap) + (size_t)nbcap + 64 + 64;
 }
 
@@ -142,7 +149,7 @@ int bp_destroy(bp_handle *h)
 
 // Common tail of the scenario loaders: SoA upload of the per-trial bodies, per-env state allocation, and one settle of
 // every trial into its reset template (state slot num_envs + t).
-static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Shape>> &trials)
+static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Shape>> &trials, bool settle = true)
 {
     using namespace bpgeom;
     const int T = (int)trials.size();
@@ -246,6 +253,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    if (!settle) return BP_OK;
     // settle every trial once (new space + bodies + 1000 sub-steps, ship_ice_env.py:109-220); reset() copies from these
     hipLaunchKernelGGL(k_physics_reset, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
     HIPCHK(h, hipGetLastError());
@@ -362,6 +370,37 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         e0 = h->ev[h->ev_used]; e1 = h->ev[h->ev_used + 1]; e2 = h->ev[h->ev_used + 2];
         h->ev_used += 3;
         HIPCHK(h, hipEventRecord(e0, st));
+    }
+    if (h->P.env_kind == BP_ENV_BOX) {
+        const int E = h->num_envs;
+        if (physics) {
+            if (mode == MODE_STEP) {
+                if (h->steps_done) {
+                    hipLaunchKernelGGL(k_make_order, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->order_buf, E);
+                    HIPCHK(h, hipGetLastError());
+                    h->D.order = h->order_buf;
+                }
+                h->steps_done = true;
+                hipLaunchKernelGGL(k_bd_plan, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, actions);
+                HIPCHK(h, hipGetLastError());
+                hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
+                HIPCHK(h, hipGetLastError());
+                hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
+                HIPCHK(h, hipGetLastError());
+            } else {
+                hipLaunchKernelGGL(k_reset_copy, dim3(E), dim3(256), 0, st, h->P, h->D, mask, (double *)nullptr);
+                HIPCHK(h, hipGetLastError());
+                hipLaunchKernelGGL(k_bd_reset_copy, dim3(E), dim3(256), 0, st, h->P, h->D, h->B, h->Q, mask, info);
+                HIPCHK(h, hipGetLastError());
+            }
+        }
+        if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
+        if (raster && obs) {
+            hipLaunchKernelGGL(k_bd_observe, dim3(E), dim3(BDO_THREADS), h->bd_obs_lds, st, h->P, h->D, h->B, h->Q, mask, obs);
+            HIPCHK(h, hipGetLastError());
+        }
+        if (h->timing) HIPCHK(h, hipEventRecord(e2, st));
+        return BP_OK;
     }
     if (physics) {
         if (mode == MODE_STEP && h->steps_done) { // heaviest-first dispatch order from the previous step's per-env cycles
@@ -523,6 +562,243 @@ int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream)
 int32_t bp_nb_cap(const bp_handle *h) { return h ? h->nbcap : 0; }
 int32_t bp_obs_height(const bp_handle *h) { return h ? h->P.obs_h : 0; }
 int32_t bp_obs_width(const bp_handle *h) { return h ? h->P.obs_w : 0; }
+
+// ---- box-delivery-v0 ---------------------------------------------------------------------------------------------------
+int32_t bp_bd_sizeof_config(void) { return (int32_t)sizeof(bp_bd_config); }
+
+int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offset, int32_t device, bp_handle **out)
+{
+    if (!cfg || !out || num_envs <= 0) return BP_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BP_ENODEVICE;
+    if (cfg->damping_pow != 0.0 || cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
+    if (cfg->invert_receptacle_map) return BP_EINVAL;        // env.invert_receptacle_map: false only
+    if (cfg->num_boxes <= 0 || cfg->num_boxes > BD_MAXBOX || cfg->local_px <= 0 || (cfg->local_px & 1)) return BP_EINVAL;
+    bp_handle *h = new bp_handle();
+    memset(&h->cfg, 0, sizeof(h->cfg));
+    h->bdcfg = *cfg;
+    h->num_envs = num_envs; h->env_offset = env_id_offset; h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { delete h; return BP_ENODEVICE; }
+    memset(&h->D, 0, sizeof(h->D));
+    memset(&h->Q, 0, sizeof(h->Q));
+    DevParams &P = h->P;
+    memset(&P, 0, sizeof(P));
+    P.dt_sub = cfg->ctrl_dt / cfg->steps;
+    P.steps = cfg->steps; P.iterations = cfg->iterations; P.persistence = cfg->persistence; P.settle_steps = cfg->settle_steps;
+    P.damping_pow = cfg->damping_pow; P.bias_coef = cfg->bias_coef; P.slop = cfg->slop;
+    P.target_speed = cfg->target_speed;
+    P.skin = 0.25;
+    P.env_kind = BP_ENV_BOX;
+    P.nkin = 6;                                            // main shape + 4 wheels + front bumper on one KINEMATIC body
+    P.num_envs = num_envs; P.env_offset = env_id_offset;
+    P.obs_h = P.obs_w = cfg->local_px;
+    BdParams &B = h->B;
+    memset(&B, 0, sizeof(B));
+    B.room_length = cfg->room_length; B.room_width = cfg->room_width; B.recept_x = cfg->recept_x; B.recept_y = cfg->recept_y;
+    B.recept_size = cfg->recept_size; B.ppm = cfg->ppm; B.local_w = cfg->local_w; B.robot_radius = cfg->robot_radius;
+    B.step_size = cfg->step_size; B.target_speed = cfg->target_speed; B.ctrl_dt = cfg->ctrl_dt;
+    B.partial_rewards_scale = cfg->partial_rewards_scale; B.goal_reward = cfg->goal_reward; B.collision_penalty = cfg->collision_penalty;
+    B.non_movement_penalty = cfg->non_movement_penalty; B.correct_direction_reward_scale = cfg->correct_direction_reward_scale;
+    B.ministep_size = cfg->ministep_size; B.sp_channel_scale = cfg->sp_channel_scale;
+    B.local_px = cfg->local_px; B.use_correct_direction_reward = cfg->use_correct_direction_reward;
+    B.inactivity_cutoff = cfg->inactivity_cutoff; B.num_boxes = cfg->num_boxes; B.step_limit = cfg->step_limit;
+    B.first_box = 6;
+    *out = h;
+    return BP_OK;
+}
+
+int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, const double *boxes, int32_t ns, const double *sverts,
+               const int32_t *scount, const double *spose, const double *srad, const int32_t *stype)
+{
+    if (!h || T <= 0 || nbox <= 0 || nbox > BD_MAXBOX || ns <= 0 || !starts || !boxes || !sverts || !scount || !spose || !srad || !stype) return BP_EINVAL;
+    if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
+    if (h->P.env_kind != BP_ENV_BOX) return fail(h, BP_ESTATE, "handle was created for another environment");
+    HIPCHK(h, hipSetDevice(h->device));
+    using namespace bpgeom;
+    const bp_bd_config &cf = h->bdcfg;
+    std::vector<std::vector<Shape>> trials(T);
+    std::vector<Shape> recepts(T);
+    h->bd_map_of_trial.assign(T, 0);
+    std::vector<std::vector<std::vector<P2>>> map_keys; // obstacle polygons of each distinct layout
+    int nphys_static = -1;
+    for (int t = 0; t < T; t++) {
+        std::vector<Shape> &bodies = trials[t];
+        const double sx = starts[3 * t], sy = starts[3 * t + 1], sh = starts[3 * t + 2];
+        {   // create_agent (sim_utils.py:20-73): main shape radius 0 / friction 1, wheels + bumper radius 0.02 / friction 0
+            Shape s;
+            build_agent_main(cf.robot_verts, 4, sx, sy, sh, s);
+            s.radius = 0.0; s.e = 0.01; s.u = 1.0; s.kind = kind_of(1, 1, BODY_KINEMATIC);
+            bodies.push_back(s);
+            for (int k = 0; k < 5; k++) {
+                Shape w;
+                build_kinematic_part(k < 4 ? cf.wheel_verts[k] : cf.bumper_verts, 4, sx, sy, sh, w);
+                w.radius = 0.02; w.e = 0.01; w.u = 0.0; w.kind = kind_of(0, 1, BODY_KINEMATIC);
+                bodies.push_back(w);
+            }
+        }
+        for (int b = 0; b < nbox; b++) {
+            const double *bx = boxes + ((size_t)t * nbox + b) * 3;
+            Shape s;
+            if (!build_box(bx[0], bx[1], bx[2], cf.box_half, cf.box_density, 0.02, s)) return fail(h, BP_EINVAL, "degenerate box");
+            s.radius = 0.02; s.e = 0.01; s.u = 1.0; s.kind = kind_of(2, 0, BODY_DYNAMIC);
+            bodies.push_back(s);
+        }
+        std::vector<std::vector<P2>> obstacles;
+        int nrec = 0, nst = 0;
+        for (int k = 0; k < ns; k++) {
+            const size_t o = (size_t)t * ns + k;
+            const int n = scount[o];
+            if (n < 3 || n > 4) return fail(h, BP_EINVAL, "static polygons have 3 or 4 vertices");
+            Shape s;
+            build_static_poly(sverts + o * 8, n, spose[o * 3], spose[o * 3 + 1], spose[o * 3 + 2], s);
+            s.radius = srad[o]; s.e = 0.01; s.u = 1.0;
+            if (stype[o] == 4) {
+                if (s.verts.size() != 4) return fail(h, BP_EINVAL, "the receptacle must be a quadrilateral");
+                recepts[t] = s; nrec++;
+                continue;            // the receptacle never produces a collision response (handlers :216-229): not a physics slot
+            }
+            s.kind = kind_of(3, 0, BODY_STATIC);
+            bodies.push_back(s);
+            obstacles.push_back(world_verts(s));
+            nst++;
+        }
+        if (nrec != 1) return fail(h, BP_EINVAL, "exactly one receptacle polygon per trial is required");
+        if (nphys_static < 0) nphys_static = nst; else if (nphys_static != nst) return fail(h, BP_EINVAL, "trials differ in obstacle count");
+        int mi = -1;
+        for (size_t m = 0; m < map_keys.size() && mi < 0; m++) {
+            bool same = map_keys[m].size() == obstacles.size();
+            for (size_t q = 0; same && q < obstacles.size(); q++) {
+                same = map_keys[m][q].size() == obstacles[q].size();
+                for (size_t v = 0; same && v < obstacles[q].size(); v++) same = map_keys[m][q][v].x == obstacles[q][v].x && map_keys[m][q][v].y == obstacles[q][v].y;
+            }
+            if (same) mi = (int)m;
+        }
+        if (mi < 0) {
+            BdMaps M;
+            if (!bd_build_maps(obstacles, cf.room_length, cf.room_width, cf.ppm, cf.local_px, cf.local_w, cf.robot_radius, cf.robot_half_width,
+                               cf.recept_x, cf.recept_y, cf.sp_channel_scale, M))
+                return fail(h, BP_EINVAL, "free space does not fit the small-map window");
+            h->bd_maps.push_back(M);
+            map_keys.push_back(obstacles);
+            mi = (int)map_keys.size() - 1;
+        }
+        h->bd_map_of_trial[t] = mi;
+    }
+    int rc = upload_trials(h, trials, false);
+    if (rc) return rc;
+    if (h->nbcap > 64) return fail(h, BP_EINVAL, "box-delivery supports at most 64 shape slots per env");
+    BdParams &B = h->B;
+    const BdMaps &M0 = h->bd_maps[0];
+    B.H = M0.H; B.W = M0.W; B.SH = M0.SH; B.SW = M0.SW; B.si0 = M0.si0; B.sj0 = M0.sj0;
+    B.nbox = nbox; B.nrecept = 1;
+    const int NW = B.SH * B.SW, words = (NW + 31) / 32, nm = (int)h->bd_maps.size();
+    BdPtrs &Q = h->Q;
+    int *d_mot; unsigned *d_free, *d_thin; unsigned short *d_edt; float *d_rec; unsigned char *d_small, *d_rchan; d2 *d_rp, *d_rn;
+    if ((rc = dalloc(h, &d_mot, T))) return rc;
+    if ((rc = dalloc(h, &d_free, (size_t)nm * words))) return rc;
+    if ((rc = dalloc(h, &d_thin, (size_t)nm * words))) return rc;
+    if ((rc = dalloc(h, &d_edt, (size_t)nm * NW * 2))) return rc;
+    if ((rc = dalloc(h, &d_rec, (size_t)nm * NW))) return rc;
+    if ((rc = dalloc(h, &d_small, (size_t)nm * NW))) return rc;
+    if ((rc = dalloc(h, &d_rp, (size_t)nm * 4))) return rc;
+    if ((rc = dalloc(h, &d_rn, (size_t)nm * 4))) return rc;
+    if ((rc = dalloc(h, &d_rchan, (size_t)B.local_px * B.local_px))) return rc;
+    HIPCHK(h, hipMemcpy(d_mot, h->bd_map_of_trial.data(), sizeof(int) * T, hipMemcpyHostToDevice));
+    std::vector<int> first_trial_of_map(nm, -1);
+    for (int t = 0; t < T; t++) if (first_trial_of_map[h->bd_map_of_trial[t]] < 0) first_trial_of_map[h->bd_map_of_trial[t]] = t;
+    for (int m = 0; m < nm; m++) {
+        const BdMaps &M = h->bd_maps[m];
+        HIPCHK(h, hipMemcpy(d_free + (size_t)m * words, M.free_bits.data(), sizeof(unsigned) * words, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d_thin + (size_t)m * words, M.thin_bits.data(), sizeof(unsigned) * words, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d_edt + (size_t)m * NW * 2, M.edt.data(), sizeof(unsigned short) * NW * 2, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d_rec + (size_t)m * NW, M.recept.data(), sizeof(float) * NW, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d_small + (size_t)m * NW, M.small_free.data(), NW, hipMemcpyHostToDevice));
+        const Shape &r = recepts[first_trial_of_map[m]];
+        const std::vector<P2> wv = world_verts(r);
+        d2 hp[4], hn[4];
+        for (int i = 0; i < 4; i++) { hp[i].x = wv[i].x; hp[i].y = wv[i].y; hn[i].x = r.normals[i].x; hn[i].y = r.normals[i].y; }
+        HIPCHK(h, hipMemcpy(d_rp + (size_t)m * 4, hp, sizeof(hp), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(d_rn + (size_t)m * 4, hn, sizeof(hn), hipMemcpyHostToDevice));
+    }
+    {   // robot_state_channel (box_delivery_env.py:124-131) * 255
+        const int lp = B.local_px;
+        std::vector<unsigned char> rc_((size_t)lp * lp, 0);
+        const int rpw = (int)(2 * cf.robot_radius * cf.ppm);
+        const int start = (int)std::floor((double)lp / 2 - (double)rpw / 2);
+        for (int i = start; i < start + rpw; i++)
+            for (int j = start; j < start + rpw; j++) {
+                if (i < 0 || j < 0 || i >= lp || j >= lp) continue;
+                const double a = ((double)i + 0.5) - (double)lp / 2, b = ((double)j + 0.5) - (double)lp / 2;
+                if (std::sqrt(a * a + b * b) < (double)rpw / 2) rc_[(size_t)i * lp + j] = 255;
+            }
+        HIPCHK(h, hipMemcpy(d_rchan, rc_.data(), rc_.size(), hipMemcpyHostToDevice));
+    }
+    Q.map_of_trial = d_mot; Q.free_bits = d_free; Q.thin_bits = d_thin; Q.edt = d_edt; Q.recept = d_rec; Q.small_free = d_small;
+    Q.recept_poly = d_rp; Q.recept_n = d_rn; Q.robot_chan = d_rchan;
+    const size_t E = (size_t)h->num_envs + (size_t)T;
+    if ((rc = dalloc(h, &Q.alive, E * BD_MAXBOX))) return rc;
+    if ((rc = dalloc(h, &Q.order, E * BD_MAXBOX))) return rc;
+    if ((rc = dalloc(h, &Q.nalive, E))) return rc;
+    if ((rc = dalloc(h, &Q.nprev, E))) return rc;
+    if ((rc = dalloc(h, &Q.boxdist, E * BD_MAXBOX))) return rc;
+    if ((rc = dalloc(h, &Q.prev, E * BD_MAXBOX * 4))) return rc;
+    if ((rc = dalloc(h, &Q.cum, E * 4))) return rc;
+    if ((rc = dalloc(h, &Q.cnt, E * 4))) return rc;
+    if ((rc = dalloc(h, &Q.wp, E * BD_MAXWP * 3))) return rc;
+    if ((rc = dalloc(h, &Q.nwp, E))) return rc;
+    if ((rc = dalloc(h, &Q.stepf, E * 8))) return rc;
+    if ((rc = dalloc(h, &Q.dist, E * NW))) return rc;
+    if ((rc = dalloc(h, &Q.rmap, E * NW))) return rc;
+    h->bd_lds = (size_t)words * 8 + (size_t)3 * BD_QCAP * 2 + 16 + (size_t)BD_PATHCAP * 2 * 2 + BD_PATHCAP + (size_t)BD_PATHCAP * 4 + (size_t)BD_MAXWP * 16 + 64;
+    h->bd_obs_lds = (size_t)((NW + 15) & ~15);
+    if (h->bd_lds > 160 * 1024 || h->bd_obs_lds > 160 * 1024) return fail(h, BP_EINVAL, "map window too large for LDS");
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_settle, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_obs_lds));
+    // settle every trial once into its template slot, then the episode-start bookkeeping (box distances, robot map)
+    hipLaunchKernelGGL(k_bd_settle, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_bd_finish, dim3(T), dim3(64), h->bd_lds, 0, h->P, h->D, h->B, h->Q, 1, 1, (double *)nullptr, (unsigned char *)nullptr,
+                       (unsigned char *)nullptr, (double *)nullptr);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipDeviceSynchronize());
+    h->loaded = true;
+    return BP_OK;
+}
+
+int bp_bd_get_maps(bp_handle *h, int32_t trial, int32_t *dims, uint8_t *cspace, uint8_t *cspace_thin, uint16_t *edt, float *recept, uint8_t *small_free)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded || h->P.env_kind != BP_ENV_BOX) return fail(h, BP_ESTATE, "not a loaded box-delivery handle");
+    if (trial < 0 || trial >= h->num_trials) return BP_EINVAL;
+    const bpgeom::BdMaps &M = h->bd_maps[h->bd_map_of_trial[trial]];
+    if (dims) { dims[0] = M.H; dims[1] = M.W; dims[2] = M.SH; dims[3] = M.SW; dims[4] = M.si0; dims[5] = M.sj0; }
+    const int NW = M.SH * M.SW;
+    for (int w = 0; w < NW; w++) {
+        if (cspace) cspace[w] = (M.free_bits[w >> 5] >> (w & 31)) & 1u;
+        if (cspace_thin) cspace_thin[w] = (M.thin_bits[w >> 5] >> (w & 31)) & 1u;
+    }
+    if (edt) memcpy(edt, M.edt.data(), sizeof(uint16_t) * NW * 2);
+    if (recept) memcpy(recept, M.recept.data(), sizeof(float) * NW);
+    if (small_free) memcpy(small_free, M.small_free.data(), NW);
+    return BP_OK;
+}
+
+int bp_bd_get_state(bp_handle *h, uint8_t *alive, double *waypoints, int32_t *nwp)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded || h->P.env_kind != BP_ENV_BOX) return fail(h, BP_ESTATE, "not a loaded box-delivery handle");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t E = h->num_envs;
+    if (alive) HIPCHK(h, hipMemcpy(alive, h->Q.alive, E * BD_MAXBOX, hipMemcpyDeviceToHost));
+    if (waypoints) HIPCHK(h, hipMemcpy(waypoints, h->Q.wp, sizeof(double) * E * BD_MAXWP * 3, hipMemcpyDeviceToHost));
+    if (nwp) HIPCHK(h, hipMemcpy(nwp, h->Q.nwp, sizeof(int) * E, hipMemcpyDeviceToHost));
+    return BP_OK;
+}
 
 int bp_get_num_bodies(bp_handle *h, int32_t *out_host)
 {

@@ -31,7 +31,181 @@ __device__ __forceinline__ d2 poly_centroid_seq(const d2 *v, int n)
     return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
 }
 
-template <int mode>
+template <int KIND>
+__device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
+{
+    const int nbcap = P.nbcap;
+    char *p = (char *)bp_smem;
+    L.sv = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+    L.sw = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+    L.sb = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+    L.tf = (d2 *)p; p += sizeof(d2) * 128;
+    // scratch region shared by the plane search (res_*, pl_*) and, afterwards, the manifold mailbox
+    char *scr = p;
+    L.mbox = (d2 *)scr;
+    L.res_smA = (unsigned long long *)p; p += 8 * 64;
+    L.res_smB = (unsigned long long *)p; p += 8 * 64;
+    L.res_iA = (unsigned *)p; p += 4 * 64;
+    L.res_iB = (unsigned *)p; p += 4 * 64;
+    L.res_jA = (unsigned *)p; p += 4 * 64;
+    L.res_jB = (unsigned *)p; p += 4 * 64;
+    L.pl_off = (unsigned short *)p; p += 2 * 64;
+    L.pl_sa = (unsigned short *)p; p += 2 * 64;
+    L.pl_sb = (unsigned short *)p; p += 2 * 64;
+    L.pl_na = (unsigned char *)p; p += 64;
+    L.pl_nb = (unsigned char *)p; p += 64;   // scratch = 2560 B >= mailbox 16 * 96 B
+    L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
+    L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
+    L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
+    L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
+    L.slot_of = (unsigned char *)p; p += nbcap;
+    L.rf = (unsigned char *)p; p += 64;
+    L.ev_key = nullptr; L.ev_d = nullptr;
+    if (KIND == BP_ENV_BOX) {
+        p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+        L.ev_d = (d2 *)p; p += sizeof(d2) * 3 * BP_EVCAP;
+        L.ev_key = (unsigned *)p; p += sizeof(unsigned) * BP_EVCAP;
+    }
+}
+
+__device__ __forceinline__ void env_ctx(const DevParams &P, const DevPtrs &D, int env, int trial, EnvCtx &E)
+{
+    const int nbcap = P.nbcap;
+    const size_t eb = (size_t)env * nbcap, tb = (size_t)trial * nbcap;
+    E.nv = D.sc_nv + tb;
+    E.lv = D.sc_lv + tb * BP_MAXV;
+    E.ln = D.sc_ln + tb * BP_MAXV;
+    E.mass = D.sc_mass + tb;
+    E.prop = D.sc_prop + tb;
+    E.kind = D.sc_kind + tb;
+    E.pxy = D.pxy + eb; E.rot = D.rot + eb; E.ang = D.ang + eb;
+    E.wv = D.wv + eb * BP_MAXV; E.wn = D.wn + eb * BP_MAXV; E.pv = D.pv + eb * BP_MAXV;
+    E.bb = D.bb + eb; E.fat = D.fat + eb;
+    E.adj = D.adj + eb * BP_KADJ; E.adjn = D.adjn + eb; E.hint = D.hint + eb * BP_KADJ;
+}
+
+__device__ __forceinline__ void init_regs(ArbReg &A, SubState &S)
+{
+    S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.wall_flag = 0; S.nev = 0; S.robot_hit = 0; S.evmask = 0ull;
+    A.e = 0.0; A.u = 0.0;
+    S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
+    A.level = 0; A.rank = 0;
+    A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
+    A.nMass1 = A.tMass1 = A.bias1 = A.bounce1 = A.jBias1 = 0.0;
+    A.ma = A.ia = A.mb = A.ib = 0.0;
+
+}
+
+// persistent per-env state -> LDS / registers (first half: before the agent's control is written)
+template <int KIND>
+__device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &D, const EnvCtx &E, const LdsCtx &L, ArbReg &A,
+                                             SubState &S, int env)
+{
+    const int lane = lane_id();
+    const int nbcap = P.nbcap;
+    const size_t eb = (size_t)env * nbcap;
+    // ---- load persistent state ----
+    for (int base = 0; base < nbcap; base += 64) {
+        const int i = base + lane;
+        if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
+    }
+    if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; }
+    S.nslots = P.nkin;
+    S.wall_flag = (P.env_kind == BP_ENV_MAZE) ? (D.e_flags[env] & 1) : 0;
+    const size_t ab = (size_t)env * BP_ACAP + lane;
+    A.key = D.a_key[ab]; A.stamp = D.a_stamp[ab];
+    { const unsigned sc = D.a_sc[ab]; A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
+    A.h0 = D.a_h0[ab]; A.h1 = D.a_h1[ab];
+    const double *ad = D.a_d + ab * 14;
+    A.jn0 = ad[0]; A.jt0 = ad[1]; A.jn1 = ad[2]; A.jt1 = ad[3];
+    A.n = mk2(ad[4], ad[5]);
+    A.r1_0 = mk2(ad[6], ad[7]); A.r2_0 = mk2(ad[8], ad[9]); A.r1_1 = mk2(ad[10], ad[11]); A.r2_1 = mk2(ad[12], ad[13]);
+    A.slotA = A.slotB = 0;
+    if (A.key != ARB_FREE_KEY) {
+        const double4 m1 = E.mass[A.key >> 16], m2 = E.mass[A.key & 0xFFFFu];
+        A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+        const double4 q1 = E.prop[A.key >> 16], q2 = E.prop[A.key & 0xFFFFu];
+        A.e = q1.y * q2.y; A.u = q1.z * q2.z;
+    }
+    S.stamp = D.e_stamp[env]; S.curr_dt = D.e_currdt[env];
+    S.total_ke = D.e_ke[env]; S.total_imp = D.e_imp[env];
+    S.n_post = D.e_cnt[env * 4 + 0]; S.n_contact = D.e_cnt[env * 4 + 1]; S.n_first = D.e_cnt[env * 4 + 2];
+    __syncthreads();
+}
+// second half: moving list, velocity slots of moving bodies and of the persisted arbiters
+template <int KIND>
+__device__ __forceinline__ void load_state_b(const DevParams &P, const DevPtrs &D, const EnvCtx &E, const LdsCtx &L, ArbReg &A,
+                                             SubState &S, int env)
+{
+    const int lane = lane_id();
+    const size_t eb = (size_t)env * P.nbcap;
+    // moving list: every body with a non-zero velocity gets a velocity slot (the ship owns slot 0)
+    int n = 0;
+    for (int base = 0; base < E.nb; base += 64) {
+        const int i = base + lane;
+        bool mvg = false;
+        d2 v = mk2(0.0, 0.0), w2 = v, vb = v;
+        if (i < E.nb) {
+            if (i < P.nkin) { v = L.sv[i]; w2 = L.sw[i]; vb = L.sb[i]; }
+            else { v = D.velv[eb + i]; w2 = D.velw[eb + i]; vb = D.velb[eb + i]; }
+            mvg = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
+            if (KIND == BP_ENV_BOX && i < P.nkin) mvg = true; // the robot is re-cached every sub-step (see substep)
+        }
+        const unsigned long long m = ballot(mvg);
+        const unsigned long long ms = ballot(mvg && i >= P.nkin);
+        if (mvg) { const int pos = n + popc_below(m, lane); if (pos < P.mvcap) L.mv[pos] = (unsigned short)i; }
+        if (mvg && i >= P.nkin) {
+            int sl = S.nslots + popc_below(ms, lane);
+            if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
+            L.slot_of[i] = (unsigned char)sl;
+            L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb;
+        }
+        n += __popcll(m);
+        S.nslots = min(S.nslots + __popcll(ms), BP_NSLOT);
+    }
+    if (n > P.mvcap) { S.err |= BP_ERR_ARB_OVERFLOW; n = P.mvcap; }
+    S.nmv = n;
+    lds_sync();
+    // velocity slots for the bodies of the persisted arbiters
+    {
+        unsigned long long m = ballot(A.key != ARB_FREE_KEY);
+        while (m) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
+            const int s1 = slot_get(L, S, (int)(key >> 16)), s2 = slot_get(L, S, (int)(key & 0xFFFFu));
+            if (lane == l) { A.slotA = s1; A.slotB = s2; }
+        }
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void store_state(const DevParams &P, const DevPtrs &D, const LdsCtx &L, const ArbReg &A, int env)
+{
+    const int lane = lane_id();
+    const int nbcap = P.nbcap;
+    const size_t eb = (size_t)env * nbcap;
+    // ---- write back persistent state ----
+    for (int base = 0; base < nbcap; base += 64) {
+        const int i = base + lane;
+        if (i < nbcap) {
+            const int sl = L.slot_of[i];
+            const d2 z = mk2(0.0, 0.0);
+            D.velv[eb + i] = (sl != 255) ? L.sv[sl] : z; D.velw[eb + i] = (sl != 255) ? L.sw[sl] : z; D.velb[eb + i] = (sl != 255) ? L.sb[sl] : z;
+        }
+    }
+    {
+        const size_t ab = (size_t)env * BP_ACAP + lane;
+        D.a_key[ab] = A.key; D.a_stamp[ab] = A.stamp; D.a_sc[ab] = (unsigned)A.state | ((unsigned)A.count << 8);
+        D.a_h0[ab] = A.h0; D.a_h1[ab] = A.h1;
+        double *ad = D.a_d + ab * 14;
+        ad[0] = A.jn0; ad[1] = A.jt0; ad[2] = A.jn1; ad[3] = A.jt1; ad[4] = A.n.x; ad[5] = A.n.y;
+        ad[6] = A.r1_0.x; ad[7] = A.r1_0.y; ad[8] = A.r2_0.x; ad[9] = A.r2_0.y;
+        ad[10] = A.r1_1.x; ad[11] = A.r1_1.y; ad[12] = A.r2_1.x; ad[13] = A.r2_1.y;
+    }
+}
+
+template <int mode, int KIND>
 __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
@@ -47,33 +221,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
 
     // ---- carve LDS ----
     LdsCtx L;
-    {
-        char *p = (char *)bp_smem;
-        L.sv = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
-        L.sw = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
-        L.sb = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
-        L.tf = (d2 *)p; p += sizeof(d2) * 128;
-        // scratch region shared by the plane search (res_*, pl_*) and, afterwards, the manifold mailbox
-        char *scr = p;
-        L.mbox = (d2 *)scr;
-        L.res_smA = (unsigned long long *)p; p += 8 * 64;
-        L.res_smB = (unsigned long long *)p; p += 8 * 64;
-        L.res_iA = (unsigned *)p; p += 4 * 64;
-        L.res_iB = (unsigned *)p; p += 4 * 64;
-        L.res_jA = (unsigned *)p; p += 4 * 64;
-        L.res_jB = (unsigned *)p; p += 4 * 64;
-        L.pl_off = (unsigned short *)p; p += 2 * 64;
-        L.pl_sa = (unsigned short *)p; p += 2 * 64;
-        L.pl_sb = (unsigned short *)p; p += 2 * 64;
-        L.pl_na = (unsigned char *)p; p += 64;
-        L.pl_nb = (unsigned char *)p; p += 64;   // scratch = 2560 B >= mailbox 16 * 96 B
-        L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
-        L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
-        L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
-        L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
-        L.slot_of = (unsigned char *)p; p += nbcap;
-        L.rf = (unsigned char *)p; p += 64;
-    }
+    carve_lds<KIND>(P, L);
 
     // ---- env context ----
     const size_t eb = (size_t)env * nbcap;
@@ -88,16 +236,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     const size_t tb = (size_t)trial * nbcap;
     EnvCtx E;
     E.nb = (mode == MODE_RESET) ? D.sc_nb[trial] : D.e_nb[env];
-    E.nv = D.sc_nv + tb;
-    E.lv = D.sc_lv + tb * BP_MAXV;
-    E.ln = D.sc_ln + tb * BP_MAXV;
-    E.mass = D.sc_mass + tb;
-    E.prop = D.sc_prop + tb;
-    E.kind = D.sc_kind + tb;
-    E.pxy = D.pxy + eb; E.rot = D.rot + eb; E.ang = D.ang + eb;
-    E.wv = D.wv + eb * BP_MAXV; E.wn = D.wn + eb * BP_MAXV; E.pv = D.pv + eb * BP_MAXV;
-    E.bb = D.bb + eb; E.fat = D.fat + eb;
-    E.adj = D.adj + eb * BP_KADJ; E.adjn = D.adjn + eb; E.hint = D.hint + eb * BP_KADJ;
+    env_ctx(P, D, env, trial, E);
 
     ArbReg A;
     SubState S;
@@ -105,14 +244,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     for (int q = 0; q < 24; q++) S.prof[q] = 0;
     const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
-    S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.wall_flag = 0;
-    A.e = 0.0; A.u = 0.0;
-    S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
-    A.level = 0; A.rank = 0;
-    A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
-    A.nMass1 = A.tMass1 = A.bias1 = A.bounce1 = A.jBias1 = 0.0;
-    A.ma = A.ia = A.mb = A.ib = 0.0;
-
+    init_regs(A, S);
     if (mode == MODE_RESET) {
         // ---- new space + bodies from the trial (ship_ice_env.py:109-216) ----
         for (int base = 0; base < nbcap; base += 64) {
@@ -181,33 +313,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         S.total_ke = 0.0; S.total_imp = 0.0; S.n_post = S.n_contact = S.n_first = 0;
         __syncthreads();
     } else {
-        // ---- load persistent state ----
-        for (int base = 0; base < nbcap; base += 64) {
-            const int i = base + lane;
-            if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
-        }
-        if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; }
-        S.nslots = P.nkin;
-        S.wall_flag = (P.env_kind == BP_ENV_MAZE) ? (D.e_flags[env] & 1) : 0;
-        const size_t ab = (size_t)env * BP_ACAP + lane;
-        A.key = D.a_key[ab]; A.stamp = D.a_stamp[ab];
-        { const unsigned sc = D.a_sc[ab]; A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
-        A.h0 = D.a_h0[ab]; A.h1 = D.a_h1[ab];
-        const double *ad = D.a_d + ab * 14;
-        A.jn0 = ad[0]; A.jt0 = ad[1]; A.jn1 = ad[2]; A.jt1 = ad[3];
-        A.n = mk2(ad[4], ad[5]);
-        A.r1_0 = mk2(ad[6], ad[7]); A.r2_0 = mk2(ad[8], ad[9]); A.r1_1 = mk2(ad[10], ad[11]); A.r2_1 = mk2(ad[12], ad[13]);
-        A.slotA = A.slotB = 0;
-        if (A.key != ARB_FREE_KEY) {
-            const double4 m1 = E.mass[A.key >> 16], m2 = E.mass[A.key & 0xFFFFu];
-            A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
-            const double4 q1 = E.prop[A.key >> 16], q2 = E.prop[A.key & 0xFFFFu];
-            A.e = q1.y * q2.y; A.u = q1.z * q2.z;
-        }
-        S.stamp = D.e_stamp[env]; S.curr_dt = D.e_currdt[env];
-        S.total_ke = D.e_ke[env]; S.total_imp = D.e_imp[env];
-        S.n_post = D.e_cnt[env * 4 + 0]; S.n_contact = D.e_cnt[env * 4 + 1]; S.n_first = D.e_cnt[env * 4 + 2];
-        __syncthreads();
+        load_state_a<KIND>(P, D, E, L, A, S, env);
         // ship control (ship_ice_env.py:265-274): set once per env step
         if (lane < P.nkin) { // every part of the kinematic agent carries the same velocity
             const double act = actions[env] * P.max_yaw_rate;
@@ -216,50 +322,13 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             L.sw[lane] = mk2(act, L.sw[lane].y);
         }
         __syncthreads();
-        // moving list: every body with a non-zero velocity gets a velocity slot (the ship owns slot 0)
-        int n = 0;
-        for (int base = 0; base < E.nb; base += 64) {
-            const int i = base + lane;
-            bool mvg = false;
-            d2 v = mk2(0.0, 0.0), w2 = v, vb = v;
-            if (i < E.nb) {
-                if (i < P.nkin) { v = L.sv[i]; w2 = L.sw[i]; vb = L.sb[i]; }
-                else { v = D.velv[eb + i]; w2 = D.velw[eb + i]; vb = D.velb[eb + i]; }
-                mvg = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
-            }
-            const unsigned long long m = ballot(mvg);
-            const unsigned long long ms = ballot(mvg && i >= P.nkin);
-            if (mvg) { const int pos = n + popc_below(m, lane); if (pos < P.mvcap) L.mv[pos] = (unsigned short)i; }
-            if (mvg && i >= P.nkin) {
-                int sl = S.nslots + popc_below(ms, lane);
-                if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
-                L.slot_of[i] = (unsigned char)sl;
-                L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb;
-            }
-            n += __popcll(m);
-            S.nslots = min(S.nslots + __popcll(ms), BP_NSLOT);
-        }
-        if (n > P.mvcap) { S.err |= BP_ERR_ARB_OVERFLOW; n = P.mvcap; }
-        S.nmv = n;
-        lds_sync();
-        // velocity slots for the bodies of the persisted arbiters
-        {
-            unsigned long long m = ballot(A.key != ARB_FREE_KEY);
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
-                const int s1 = slot_get(L, S, (int)(key >> 16)), s2 = slot_get(L, S, (int)(key & 0xFFFFu));
-                if (lane == l) { A.slotA = s1; A.slotB = s2; }
-            }
-        }
-        __syncthreads();
+        load_state_b<KIND>(P, D, E, L, A, S, env);
     }
 
     const unsigned stamp_start = S.stamp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     for (int it = 0; it < nsub; it++) {
-        substep(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
+        substep<KIND>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
         if (S.quiescent && D.dbg == nullptr) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active
@@ -322,24 +391,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     }
     __syncthreads();
 
-    // ---- write back persistent state ----
-    for (int base = 0; base < nbcap; base += 64) {
-        const int i = base + lane;
-        if (i < nbcap) {
-            const int sl = L.slot_of[i];
-            const d2 z = mk2(0.0, 0.0);
-            D.velv[eb + i] = (sl != 255) ? L.sv[sl] : z; D.velw[eb + i] = (sl != 255) ? L.sw[sl] : z; D.velb[eb + i] = (sl != 255) ? L.sb[sl] : z;
-        }
-    }
-    {
-        const size_t ab = (size_t)env * BP_ACAP + lane;
-        D.a_key[ab] = A.key; D.a_stamp[ab] = A.stamp; D.a_sc[ab] = (unsigned)A.state | ((unsigned)A.count << 8);
-        D.a_h0[ab] = A.h0; D.a_h1[ab] = A.h1;
-        double *ad = D.a_d + ab * 14;
-        ad[0] = A.jn0; ad[1] = A.jt0; ad[2] = A.jn1; ad[3] = A.jt1; ad[4] = A.n.x; ad[5] = A.n.y;
-        ad[6] = A.r1_0.x; ad[7] = A.r1_0.y; ad[8] = A.r2_0.x; ad[9] = A.r2_0.y;
-        ad[10] = A.r1_1.x; ad[11] = A.r1_1.y; ad[12] = A.r2_1.x; ad[13] = A.r2_1.y;
-    }
+    store_state(P, D, L, A, env);
 #ifdef BP_PROF
     if (D.prof != nullptr && lane == 0) {
         S.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
@@ -447,13 +499,19 @@ __global__ __launch_bounds__(64) void k_physics_step(const DevParams P, const De
                                                      double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                      unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
-    physics_body<MODE_STEP>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
+    physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
 }
 // reset() of the masked envs: new space from the next trial + 1000 settle sub-steps
 __global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                       double *__restrict__ info, const int tmpl)
 {
-    physics_body<MODE_RESET>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+    physics_body<MODE_RESET, 0>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+}
+// box-delivery: new space + 1000 settle sub-steps with the boundary handlers (box_delivery_env.py:239-285)
+__global__ __launch_bounds__(64) void k_bd_settle(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                  double *__restrict__ info, const int tmpl)
+{
+    physics_body<MODE_RESET, BP_ENV_BOX>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
 }
 
 // Dispatch order for the next step: envs sorted by the cycles their last step took, heaviest first (bucket sort).

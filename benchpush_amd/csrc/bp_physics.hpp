@@ -66,7 +66,11 @@ struct LdsCtx {
     unsigned short *pl_off, *pl_sa, *pl_sb;      // [64]
     unsigned char *pl_na, *pl_nb;                // [64]
     d2 *mbox;                  // [BP_MBOX][6] manifold mailbox
+    // box-delivery only (substep<BP_ENV_BOX>): (1,3)/(2,3) pre_solve calls of the current sub-step
+    unsigned *ev_key;          // [BP_EVCAP] shapeA << 16 | shapeB
+    d2 *ev_d;                  // [BP_EVCAP][3] normal, r1, r2 of contact 0
 };
+#define BP_EVCAP 16
 #define BP_MBOX 16
 #define BP_NSLOT 96
 
@@ -84,6 +88,9 @@ struct SubState {
     int wall_flag;             // maze: robot body touched a wall (pre_solve of the (1,3) handler)
     int quiescent;             // set by substep(): nothing moves and no arbiter is warm -> later sub-steps are no-ops
     unsigned ship_post, ship_contacts; // per-sub-step bookkeeping increments of the (cold) ship arbiters
+    int nev;                   // box-delivery: recorded pre_solve events of this sub-step
+    int robot_hit;             // box-delivery: robot_hit_obstacle (box_delivery_env.py:208-210)
+    unsigned long long evmask; // box-delivery: bodies (index < 64) whose position a pre_solve changed in this sub-step
 #ifdef BP_PROF
     unsigned long long prof[24];
 #endif
@@ -202,10 +209,13 @@ __device__ __forceinline__ void apply_contact_impulses(const ArbReg &A, int c, d
 }
 
 // One sub-step.  ship_rules: apply the yaw / boundary rules of ShipIceEnv.step after the sub-step.
+// KIND == BP_ENV_BOX adds box-delivery's collision handlers (box_delivery_env.py:208-229,294-311); other values compile them out.
+template <int KIND>
 __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, const LdsCtx &L, ArbReg &A, SubState &S,
                                         const double dt, const bool ship_rules)
 {
     const int lane = lane_id();
+    if (KIND == BP_ENV_BOX) { S.nev = 0; S.evmask = 0ull; }
     S.stamp += 1u;
     const unsigned now = S.stamp;
     const double prev_dt = S.curr_dt;
@@ -524,6 +534,23 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             E.hint[i * BP_KADJ + s] = (unsigned char)M.newhint;
         }
         PROF_ACC(10)
+        if (KIND == BP_ENV_BOX) {
+            // (1,3) robot x boundary and (2,3) box x boundary pre_solve: remember normal and contact 0 (r1, r2 relative to the
+            // bodies' positions at collision time); they run after the collision phase in ascending key order
+            const bool ev = valid && M.count > 0 && (flagonly || (kind_ctype(E.kind[sa]) == 2 && kind_ctype(E.kind[sb]) == 3));
+            const unsigned long long em = ballot(ev);
+            if (em) {
+                const int pos = S.nev + popc_below(em, lane);
+                if (ev && pos < BP_EVCAP) {
+                    L.ev_key[pos] = ((unsigned)sa << 16) | (unsigned)sb;
+                    L.ev_d[pos * 3 + 0] = M.n;
+                    L.ev_d[pos * 3 + 1] = vsub(M.p1_0, E.pxy[sa]);
+                    L.ev_d[pos * 3 + 2] = vsub(M.p2_0, E.pxy[sb]);
+                }
+                S.nev += __popcll(em);
+                if (S.nev > BP_EVCAP) { S.nev = BP_EVCAP; S.err |= BP_ERR_ARB_OVERFLOW; }
+            }
+        }
         // ---- 4c. cpArbiterUpdate: hand each manifold to the lane that owns the pair's arbiter slot ---------------------
         if (ballot(valid && flagonly && M.count > 0)) S.wall_flag = 1;
         const unsigned long long dm = ballot(valid && !flagonly && M.count > 0);
@@ -599,6 +626,37 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
         const int a = (int)(A.key >> 16), b = (int)(A.key & 0xFFFFu);
         if (L.mvs[a] != now && L.mvs[b] != now) A.stamp = now;
+    }
+    if (KIND == BP_ENV_BOX && S.nev > 0) {
+        // prevent_boundary_intersection (box_delivery_env.py:294-311), ascending key order; every lane does the same arithmetic
+        __syncthreads();
+        unsigned last = 0u;
+        for (int e = 0; e < S.nev; e++) {
+            unsigned best = 0xFFFFFFFFu; int bi = 0;
+            for (int q = 0; q < S.nev; q++) { const unsigned k = L.ev_key[q]; if ((e == 0 || k > last) && k < best) { best = k; bi = q; } }
+            last = best;
+            const int a = (int)(best >> 16), b = (int)(best & 0xFFFFu);
+            const d2 n = L.ev_d[bi * 3 + 0], r1 = L.ev_d[bi * 3 + 1], r2 = L.ev_d[bi * 3 + 2];
+            const int sl = L.slot_of[a];
+            const d2 v = (sl != 255) ? L.sv[sl] : mk2(0.0, 0.0);
+            const double f = 2 * (v.x * n.x + v.y * n.y);
+            const d2 refl = mk2(v.x - n.x * f, v.y - n.y * f);
+            const d2 nv = mk2(refl.x * 0.5, refl.y * 0.5);
+            const d2 pa = E.pxy[a], pb = E.pxy[b];
+            const double depth = vdot(vsub(vadd(pb, r2), vadd(pa, r1)), n);
+            const d2 pn = mk2(pa.x + n.x * depth, pa.y + n.y * depth);
+            const bool robot = a < P.nkin;
+            if (robot) S.robot_hit = depth < 0;
+            __syncthreads(); // all lanes have read pa before it is overwritten
+            if (robot) {
+                if (lane < P.nkin) { E.pxy[lane] = pn; L.sv[lane] = nv; }
+                if (pn.x != pa.x || pn.y != pa.y) S.evmask |= 1ull;
+            } else {
+                if (lane == 0) { E.pxy[a] = pn; if (sl != 255) L.sv[sl] = nv; }
+                if (pn.x != pa.x || pn.y != pa.y) S.evmask |= 1ull << a;
+            }
+            __syncthreads();
+        }
     }
     // ---- 5. cpSpaceArbiterSetFilter ---------------------------------------------------------------------------
     if (A.key != ARB_FREE_KEY) {
@@ -868,6 +926,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 const d2 v = L.sv[A.slotB], w2 = L.sw[A.slotB], vb = L.sb[A.slotB];
                 wantB = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
             }
+            if (KIND == BP_ENV_BOX) { // a body moved by a pre_solve push-out must be re-cached next sub-step (it has an arbiter)
+                if (A.ma != 0.0 && ((S.evmask >> ba) & 1ull)) wantA = true;
+                if (A.mb != 0.0 && ((S.evmask >> bbi) & 1ull)) wantB = true;
+            }
         }
         if (wantA) L.owner[ba] = (unsigned short)(lane * 2);
         __syncthreads();
@@ -876,7 +938,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const bool gotA = wantA && L.owner[ba] == (unsigned short)(lane * 2);
         const bool gotB = wantB && L.owner[bbi] == (unsigned short)(lane * 2 + 1);
         const d2 v0 = L.sv[0], w0 = L.sw[0];
-        const int shipmv = (v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? P.nkin : 0; // every part of the kinematic agent
+        // every part of the kinematic agent; the box-delivery robot is re-cached every sub-step (its controller rewrites the
+        // velocity between sub-steps; re-evaluating an unmoved body reproduces the carried-over result exactly)
+        const int shipmv = (KIND == BP_ENV_BOX || v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? P.nkin : 0;
         const unsigned long long mA = ballot(gotA), mB = ballot(gotB);
         const int nA_ = __popcll(mA);
         if (lane < shipmv) L.mv[lane] = (unsigned short)lane;

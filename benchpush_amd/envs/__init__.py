@@ -12,3 +12,9 @@ register(
     entry_point="benchpush_amd.envs.maze_namo:MazeNAMO",
     max_episode_steps=400,
 )
+
+register(
+    id="box-delivery-v0",
+    entry_point="benchpush_amd.envs.box_delivery:BoxDeliveryEnv",
+    max_episode_steps=30000,
+)

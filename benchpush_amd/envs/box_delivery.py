@@ -1,0 +1,149 @@
+"""box-delivery-v0 on MI355X: batched tensor environment + the reference-shaped single-env adapter.
+
+Reference: benchpush/environments/box_delivery/box_delivery_env.py (BoxDeliveryEnv) with ``agent.action_type: 'heading'`` (what
+its PPO/SAC baselines use, config.yaml:170): one step = PositionController waypoints + execute_robot_path (a variable number
+of 2 ms sim steps under the DP controller) + step_simulation_until_still, rewards from spfa path-length deltas of every box,
+boxes inside the receptacle are removed, observation uint8 [224, 224, 4] (channels last).
+
+Episodes: the reference keeps one ``np.random.RandomState(cfg.misc.random_seed)`` per env and draws start pose / boxes at every
+reset; here the same stream generates ``num_trials`` consecutive episodes once and env e plays episode
+``(global_env_id + episode) % num_trials``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..box_delivery_scenario import box_delivery_params, box_delivery_physics_params, generate_trials
+from ..config import default_cfg, merge_user_cfg
+from ..gym_shim import Env, spaces
+from .ship_ice import BatchedShipIceEnv, _ptr
+
+__all__ = ["BatchedBoxDeliveryEnv", "BoxDeliveryEnv", "BD_INFO_KEYS"]
+BD_INFO_KEYS = _lib.BD_INFO_KEYS
+
+
+def _bd_cfg(cfg):
+    c = merge_user_cfg(default_cfg("box_delivery"), cfg)
+    if c.agent.action_type != "heading":
+        raise NotImplementedError("only agent.action_type == 'heading' is on the accelerated path")
+    if c.teleop_mode or c.low_dim_state:
+        raise NotImplementedError("teleop / low-dimensional modes are outside the accelerated path")
+    return c
+
+
+class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
+    """E independent box-delivery environments on one GPU: reset(mask) / step(actions) with device tensors."""
+
+    def __init__(self, num_envs, cfg=None, trials=None, device="cuda:0", env_id_offset=0, num_trials=32, seed=None):
+        if not torch.cuda.is_available():
+            raise _lib.BpError("BatchedBoxDeliveryEnv needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.L = _lib.load()
+        self.cfg = _bd_cfg(cfg)
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        self.params = box_delivery_physics_params(self.cfg)
+        self.bd_params = box_delivery_params(self.cfg)
+        if trials is None:
+            trials = generate_trials(self.cfg, num_trials, seed)
+        self.trials = trials
+        nbox = len(trials[0]["boxes"])
+        ns = len(trials[0]["statics"][1])
+        if any(len(t["boxes"]) != nbox or len(t["statics"][1]) != ns for t in trials):
+            raise ValueError("all trials must hold the same number of boxes and static shapes")
+        self.bd_params["num_boxes"] = nbox
+        self.nbox = nbox
+        bcfg = _lib.make_bd_config(self.params, self.bd_params, self.cfg)
+        self.h = C.c_void_p()
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self.L, None, self.L.bp_bd_create(C.byref(bcfg), self.num_envs, int(env_id_offset), dev_index, C.byref(self.h)), "bp_bd_create")
+        c = lambda a, dt: np.ascontiguousarray(a, dt)
+        starts = c(np.stack([t["start"] for t in trials]), np.float64)
+        boxes = c(np.stack([t["boxes"] for t in trials]), np.float64)
+        sv = c(np.stack([t["statics"][0] for t in trials]), np.float64)
+        sc = c(np.stack([t["statics"][1] for t in trials]), np.int32)
+        sp = c(np.stack([t["statics"][2] for t in trials]), np.float64)
+        sr = c(np.stack([t["statics"][3] for t in trials]), np.float64)
+        st = c(np.stack([t["statics"][4] for t in trials]), np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L, self.h, self.L.bp_bd_load(self.h, len(trials), nbox, p(starts), p(boxes), ns, p(sv), p(sc), p(sp), p(sr), p(st)), "bp_bd_load")
+        self._alloc_io()
+        lp = self.L.bp_obs_height(self.h)
+        self.obs_shape = (lp, lp, 4)
+        self.obs = torch.zeros((self.num_envs,) + self.obs_shape, dtype=torch.uint8, device=self.device)
+
+    def maps(self, trial=0):
+        dims = np.zeros(6, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L, self.h, self.L.bp_bd_get_maps(self.h, trial, p(dims), None, None, None, None, None), "bp_bd_get_maps")
+        SH, SW = int(dims[2]), int(dims[3])
+        out = dict(dims=dims, cspace=np.zeros((SH, SW), np.uint8), cspace_thin=np.zeros((SH, SW), np.uint8), edt=np.zeros((SH, SW, 2), np.uint16),
+                   recept=np.zeros((SH, SW), np.float32), small_free=np.zeros((SH, SW), np.uint8))
+        _lib.check(self.L, self.h, self.L.bp_bd_get_maps(self.h, trial, p(dims), p(out["cspace"]), p(out["cspace_thin"]), p(out["edt"]), p(out["recept"]),
+                                                        p(out["small_free"])), "bp_bd_get_maps")
+        return out
+
+    def box_state(self):
+        """(alive uint8 [E, 24], waypoints [E, 64, 3], number of waypoints [E]) of the last step (host copies)."""
+        alive = np.zeros((self.num_envs, _lib.BD_MAXBOX), np.uint8)
+        wp = np.zeros((self.num_envs, _lib.BD_MAXWP, 3), np.float64)
+        nwp = np.zeros(self.num_envs, np.int32)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        _lib.check(self.L, self.h, self.L.bp_bd_get_state(self.h, p(alive), p(wp), p(nwp)), "bp_bd_get_state")
+        return alive, wp, nwp
+
+
+class BoxDeliveryEnv(Env):
+    """Reference-shaped single environment (E = 1): reset()/step() returns and info keys of box_delivery_env.py:578-830."""
+
+    metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
+
+    def __init__(self, cfg=None, trials=None, device="cuda:0", num_trials=32):
+        super().__init__()
+        self._b = BatchedBoxDeliveryEnv(1, cfg=cfg, trials=trials, device=device, num_trials=num_trials)
+        self.cfg = self._b.cfg
+        self.num_boxes = self._b.nbox
+        self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float32)
+        self.observation_shape = self._b.obs_shape
+        self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
+        self.episode_idx = None
+        self.t = 0
+        self.box_clearance_statuses = [False] * self.num_boxes
+        self.receptacle_position = (self._b.bd_params["recept_x"], self._b.bd_params["recept_y"])
+        self.goal_points = [self.receptacle_position]
+
+    def _boxes(self):
+        verts, cnt = self._b.world_polys()
+        alive, _, _ = self._b.box_state()
+        verts, cnt = verts[0].cpu().numpy(), cnt[0].cpu().numpy()
+        return [verts[6 + k, : cnt[6 + k]].copy() for k in range(self.num_boxes) if alive[0, k]], alive[0, : self.num_boxes]
+
+    def _info(self, it, boxes, alive):
+        self.box_clearance_statuses = [not bool(a) for a in alive]
+        return {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)), "cumulative_distance": float(it[3]),
+                "cumulative_boxes": int(it[4]), "cumulative_reward": float(it[5]), "total_work": float(it[6]), "obs": boxes,
+                "box_completed_statuses": self.box_clearance_statuses, "goal_positions": self.goal_points, "ministeps": float(it[7]),
+                "inactivity": int(it[8])}
+
+    def reset(self, seed=None, options=None):
+        self.episode_idx = 0 if self.episode_idx is None else self.episode_idx + 1
+        self._b.reset()
+        self.t = 0
+        boxes, alive = self._boxes()
+        return self._b.obs[0].cpu().numpy(), self._info(self._b.info[0].cpu().numpy(), boxes, alive)
+
+    def step(self, action):
+        self.t += 1
+        a = torch.tensor([float(np.asarray(action, dtype=np.float64).reshape(-1)[0])], dtype=torch.float64)
+        self._b.step(a)
+        boxes, alive = self._boxes()
+        info = self._info(self._b.info[0].cpu().numpy(), boxes, alive)
+        return (self._b.obs[0].cpu().numpy(), float(self._b.reward[0].item()), bool(self._b.terminated[0].item()),
+                bool(self._b.truncated[0].item()), info)
+
+    def render(self, mode="human", close=False):
+        raise NotImplementedError("rendering (pygame) is outside the accelerated path")
+
+    def close(self):
+        self._b.close()

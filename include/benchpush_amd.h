@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 2
+#define BP_ABI_VERSION 3
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -38,7 +38,7 @@ enum {
     BP_ECAPACITY = -6    /* an in-kernel capacity (neighbour list / arbiter slots) overflowed */
 };
 
-enum { BP_ENV_SHIP_ICE = 0, BP_ENV_MAZE = 1 };
+enum { BP_ENV_SHIP_ICE = 0, BP_ENV_MAZE = 1, BP_ENV_BOX = 2 };
 #define BP_MAX_WHEELS 4
 
 /* per-env error bits reported by bp_check_errors */
@@ -165,6 +165,57 @@ int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32
 int bp_enable_timing(bp_handle *h, int32_t on);
 /* shader cycles >> 8 each env's wavefront spent in the last bp_step (the dispatch-order hint): host uint32 [E] (synchronises) */
 int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * box-delivery-v0 (benchpush/environments/box_delivery/box_delivery_env.py, config.yaml).  A handle made by bp_bd_create is
+ * driven by the same bp_reset / bp_step / bp_observe / bp_get_body_state / bp_check_errors / bp_destroy entry points:
+ *   actions  device double [E]: the 'heading' action in [-1, 1] (box_delivery_env.py:706-723)
+ *   obs      device uint8 [E][local_px][local_px][4], channels last (box_delivery_env.py:1045-1059)
+ *   info     device double [E][BP_INFO_COUNT]: BP_BD_I_* columns
+ * Replaces BoxDeliveryEnv.step (:634-830: PositionController waypoints, execute_robot_path, step_simulation_until_still,
+ * spfa-based box distances, rewards, receptacle removal) and generate_observation (:1045-1207).
+ * --------------------------------------------------------------------------------------------------------------- */
+enum {
+    BP_BD_I_X = 0, BP_BD_I_Y, BP_BD_I_THETA, BP_BD_I_CUM_DIST, BP_BD_I_CUM_BOXES, BP_BD_I_CUM_REWARD, BP_BD_I_TOTAL_WORK,
+    BP_BD_I_MINISTEPS, BP_BD_I_INACTIVITY, BP_BD_I_HIT, BP_BD_I_SUBSTEPS, BP_BD_I_ROBOT_DIST, BP_BD_I_BOXES_DIST, BP_BD_I_NWP,
+    BP_BD_I_NALIVE, BP_BD_I_WORK
+};
+typedef struct bp_bd_config {
+    double ctrl_dt;                    /* controller.dt (config.yaml:43); one sim step is ctrl_dt / steps */
+    int32_t steps, iterations, persistence, settle_steps;   /* sim.steps, sim.iterations, Chipmunk persistence 3, 1000 (:284) */
+    double damping_pow, bias_coef, slop;                     /* as in bp_config */
+    double room_length, room_width;    /* env.room_length, env.room_width_small|large */
+    double recept_x, recept_y, recept_size;                  /* get_receptacle_position_and_size (:322-324) */
+    double ppm;                        /* local_map_pixel_width / local_map_width */
+    double local_w;                    /* env.local_map_width */
+    int32_t local_px;                  /* env.local_map_pixel_width */
+    int32_t use_correct_direction_reward;
+    double robot_radius, robot_half_width;                   /* :122-123 */
+    double step_size, target_speed;    /* agent.step_size, controller.target_speed */
+    double partial_rewards_scale, goal_reward, collision_penalty, non_movement_penalty, correct_direction_reward_scale;
+    double ministep_size, sp_channel_scale;
+    int32_t inactivity_cutoff, invert_receptacle_map, num_boxes, step_limit;
+    double box_half, box_density;      /* boxes.box_size / 2, boxes.box_density */
+    double robot_verts[4][2];          /* agent.vertices */
+    double wheel_verts[4][4][2];       /* agent.wheel_vertices */
+    double bumper_verts[4][2];         /* agent.front_bumper_vertices */
+} bp_bd_config;
+int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offset, int32_t device, bp_handle **out);
+/* `num_trials` episodes (host pointers): starts[T][3] robot start pose, boxes[T][nbox][3] = x, y, heading, and `nstatic` static
+ * polygons per trial in generate_sim_bounds order (sim_utils.py:90-135): sverts[T][ns][4][2], scount[T][ns] (3 or 4 vertices),
+ * spose[T][ns][3] body x, y, angle, srad[T][ns] shape radius, stype[T][ns] collision type (3 obstacle, 4 receptacle; exactly one
+ * receptacle).  Builds bodies/shapes (sim_utils.py:20-160), the configuration space, nearest-free-cell indices and the
+ * receptacle distance map (box_delivery_env.py:1115-1175) on the host, settles every trial once.
+ * Replaces init_box_delivery_sim / init_box_delivery_env (:193-292). */
+int bp_bd_load(bp_handle *h, int32_t num_trials, int32_t nbox, const double *starts, const double *boxes, int32_t nstatic,
+               const double *sverts, const int32_t *scount, const double *spose, const double *srad, const int32_t *stype);
+int32_t bp_bd_sizeof_config(void);
+/* tests: static rasters of trial t over the small-map window, host buffers (any may be NULL): dims[6] = H, W, SH, SW, si0, sj0;
+ * cspace / cspace_thin uint8 [SH][SW]; edt uint16 [SH][SW][2]; recept float [SH][SW]; small_free uint8 [SH][SW] */
+int bp_bd_get_maps(bp_handle *h, int32_t trial, int32_t *dims, uint8_t *cspace, uint8_t *cspace_thin, uint16_t *edt, float *recept,
+                   uint8_t *small_free);
+/* tests: per-env box bookkeeping, host buffers: alive uint8 [E][24], waypoints double [E][64][3], nwp int32 [E] (synchronises) */
+int bp_bd_get_state(bp_handle *h, uint8_t *alive, double *waypoints, int32_t *nwp);
 
 const char *bp_last_error(const bp_handle *h);
 int32_t bp_abi_version(void);

@@ -212,7 +212,7 @@ typedef struct orc_env {
     int kind;                  /* 0 = ship-ice / maze, 2 = box-delivery (collision handlers of box_delivery_env.py:208-229) */
     unsigned char *removed;    /* per shape: space.remove(body, shape) was called (box_delivery_env.py:765-767) */
     int robot_hit;             /* robot_hit_obstacle, written by the (1,3) pre_solve (box_delivery_env.py:208-210) */
-    struct { uint32_t key; } *events; int nevents, capevents; /* (1,3)/(2,3) pre_solve calls of this sub-step */
+    struct { uint32_t key; vec n, r1, r2; } *events; int nevents, capevents; /* (1,3)/(2,3) pre_solve calls of this sub-step */
 } orc_env;
 
 /* ---- Chipmunk geometry helpers (cpPolyline.c cpConvexHull / cpChipmunk.c) restated ---- */
@@ -548,7 +548,9 @@ static void collide_pair(orc_env *E, int sa, int sb)
                 E->capevents = E->capevents ? E->capevents * 2 : 32;
                 E->events = realloc(E->events, (size_t)E->capevents * sizeof(*E->events));
             }
-            E->events[E->nevents++].key = arb_key(sa, sb);
+            E->events[E->nevents].key = arb_key(sa, sb);
+            E->events[E->nevents].n = arb->n; E->events[E->nevents].r1 = arb->con[0].r1; E->events[E->nevents].r2 = arb->con[0].r2;
+            E->nevents++;
         }
         if (A->ctype == 2 && B->ctype == 4) presolve_ok = 0;
     }
@@ -656,19 +658,16 @@ static void bd_run_presolve(orc_env *E)
 {
     qsort(E->events, (size_t)E->nevents, sizeof(*E->events), cmp_u32);
     for (int k = 0; k < E->nevents; k++) {
-        int pos;
-        if (!arb_find(E, E->events[k].key, &pos)) continue;
-        arb_t *arb = &E->arbs[pos];
-        if (arb->count == 0) continue;
-        body_t *a = &E->bodies[E->shapes[arb->sa].body], *b = &E->bodies[E->shapes[arb->sb].body];
-        vec n = arb->n;
+        int sa = (int)(E->events[k].key >> 16), sb = (int)(E->events[k].key & 0xFFFFu);
+        body_t *a = &E->bodies[E->shapes[sa].body], *b = &E->bodies[E->shapes[sb].body];
+        vec n = E->events[k].n;
         vec v = a->v;
         double f = 2 * (v.x * n.x + v.y * n.y);
         vec refl = V(v.x - n.x * f, v.y - n.y * f);
         vec nv = V(refl.x * 0.5, refl.y * 0.5);
-        vec p1 = vadd(a->p, arb->con[0].r1), p2 = vadd(b->p, arb->con[0].r2);
+        vec p1 = vadd(a->p, E->events[k].r1), p2 = vadd(b->p, E->events[k].r2);
         double depth = vdot(vsub(p2, p1), n);
-        if (E->shapes[arb->sa].ctype == 1) E->robot_hit = depth < 0;
+        if (E->shapes[sa].ctype == 1) E->robot_hit = depth < 0;
         a->p = V(a->p.x + n.x * depth, a->p.y + n.y * depth);
         body_set_transform(a);
         a->v = nv;

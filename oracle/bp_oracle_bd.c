@@ -958,7 +958,7 @@ void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *te
         double bound_x = sgx * B->room_length / 2, bound_y = sgy * B->room_width / 2;
         if (fabs(tx) > fabs(bound_x)) ratio_x = (bound_x - ix) / (tx - ix);
         if (fabs(ty) > fabs(bound_y)) ratio_y = (bound_y - iy) / (ty - iy);
-        double ratio = ratio_x < ratio_y ? ratio_x : ratio_y; /* python min(): first on ties */
+        double ratio = ratio_y < ratio_x ? ratio_y : ratio_x; /* python min(a, b): b if b < a else a */
         tx = ix + ratio * dfx; ty = iy + ratio * dfy;
         nwp = bd_shortest_path(D, ix, iy, tx, ty, 1, wpp);
         wph[0] = 0.0; /* None */
