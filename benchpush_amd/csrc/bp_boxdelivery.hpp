@@ -51,7 +51,7 @@ struct BdPtrs {
     float *rmap;                    // [E][SH*SW] spfa map from the robot (observation channel 2)
 };
 
-// ---- deterministic libm replacements (same operation order as oracle/bp_oracle_bd.c) ----------------------------------------
+// ---- deterministic libm replacements (fdlibm s_atan.c / e_atan2.c restated, fixed operation order, no FMA contraction) --------
 __device__ __forceinline__ double bd_atan(double x)
 {
     const double atanhi[4] = {4.63647609000806093515e-01, 7.85398163397448278999e-01, 9.82793723247329054082e-01, 1.57079632679489655800e+00};
