@@ -649,6 +649,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
         for (int k = 0; k < ns; k++) {
             const size_t o = (size_t)t * ns + k;
             const int n = scount[o];
+            if (n == 0) continue;   // padding: trials may hold different numbers of columns
             if (n < 3 || n > 4) return fail(h, BP_EINVAL, "static polygons have 3 or 4 vertices");
             Shape s;
             build_static_poly(sverts + o * 8, n, spose[o * 3], spose[o * 3 + 1], spose[o * 3 + 2], s);
@@ -664,7 +665,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
             nst++;
         }
         if (nrec != 1) return fail(h, BP_EINVAL, "exactly one receptacle polygon per trial is required");
-        if (nphys_static < 0) nphys_static = nst; else if (nphys_static != nst) return fail(h, BP_EINVAL, "trials differ in obstacle count");
+        (void)nphys_static; (void)nst;
         int mi = -1;
         for (size_t m = 0; m < map_keys.size() && mi < 0; m++) {
             bool same = map_keys[m].size() == obstacles.size();

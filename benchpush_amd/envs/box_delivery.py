@@ -49,9 +49,9 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
             trials = generate_trials(self.cfg, num_trials, seed)
         self.trials = trials
         nbox = len(trials[0]["boxes"])
-        ns = len(trials[0]["statics"][1])
-        if any(len(t["boxes"]) != nbox or len(t["statics"][1]) != ns for t in trials):
-            raise ValueError("all trials must hold the same number of boxes and static shapes")
+        ns = max(len(t["statics"][1]) for t in trials)
+        if any(len(t["boxes"]) != nbox for t in trials):
+            raise ValueError("all trials must hold the same number of boxes")
         self.bd_params["num_boxes"] = nbox
         self.nbox = nbox
         bcfg = _lib.make_bd_config(self.params, self.bd_params, self.cfg)
@@ -61,11 +61,15 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
         c = lambda a, dt: np.ascontiguousarray(a, dt)
         starts = c(np.stack([t["start"] for t in trials]), np.float64)
         boxes = c(np.stack([t["boxes"] for t in trials]), np.float64)
-        sv = c(np.stack([t["statics"][0] for t in trials]), np.float64)
-        sc = c(np.stack([t["statics"][1] for t in trials]), np.int32)
-        sp = c(np.stack([t["statics"][2] for t in trials]), np.float64)
-        sr = c(np.stack([t["statics"][3] for t in trials]), np.float64)
-        st = c(np.stack([t["statics"][4] for t in trials]), np.int32)
+        def pad(a, fill=0):   # trials may hold different numbers of columns: unused slots have vertex count 0
+            out = np.full((ns,) + a.shape[1:], fill, a.dtype)
+            out[: len(a)] = a
+            return out
+        sv = c(np.stack([pad(t["statics"][0]) for t in trials]), np.float64)
+        sc = c(np.stack([pad(t["statics"][1]) for t in trials]), np.int32)
+        sp = c(np.stack([pad(t["statics"][2]) for t in trials]), np.float64)
+        sr = c(np.stack([pad(t["statics"][3]) for t in trials]), np.float64)
+        st = c(np.stack([pad(t["statics"][4], 3) for t in trials]), np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)
         _lib.check(self.L, self.h, self.L.bp_bd_load(self.h, len(trials), nbox, p(starts), p(boxes), ns, p(sv), p(sc), p(sp), p(sr), p(st)), "bp_bd_load")
         self._alloc_io()

@@ -204,7 +204,7 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
 /* `num_trials` episodes (host pointers): starts[T][3] robot start pose, boxes[T][nbox][3] = x, y, heading, and `nstatic` static
  * polygons per trial in generate_sim_bounds order (sim_utils.py:90-135): sverts[T][ns][4][2], scount[T][ns] (3 or 4 vertices),
  * spose[T][ns][3] body x, y, angle, srad[T][ns] shape radius, stype[T][ns] collision type (3 obstacle, 4 receptacle; exactly one
- * receptacle).  Builds bodies/shapes (sim_utils.py:20-160), the configuration space, nearest-free-cell indices and the
+ * receptacle; scount 0 = unused padding slot when trials hold different numbers of columns).  Builds bodies/shapes (sim_utils.py:20-160), the configuration space, nearest-free-cell indices and the
  * receptacle distance map (box_delivery_env.py:1115-1175) on the host, settles every trial once.
  * Replaces init_box_delivery_sim / init_box_delivery_env (:193-292). */
 int bp_bd_load(bp_handle *h, int32_t num_trials, int32_t nbox, const double *starts, const double *boxes, int32_t nstatic,

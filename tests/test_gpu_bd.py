@@ -1,0 +1,122 @@
+"""box-delivery-v0: GPU (C ABI) vs oracle, bit-exact on bodies, info scalars, rewards, termination and all observation channels."""
+import numpy as np
+import pytest
+import torch
+
+from benchpush_amd import box_delivery_scenario as S
+from benchpush_amd.config import default_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(cfg, trial, **over):
+    from oracle.oracle_bd import OracleBoxDelivery
+    bp = S.box_delivery_params(cfg)
+    bp["num_boxes"] = len(trial["boxes"])
+    bp.update(over)
+    o = OracleBoxDelivery(S.box_delivery_physics_params(cfg), bp, cfg)
+    o.reset(trial, observe=False)
+    return o
+
+
+def _compare_step(env, oracles, actions, tag):
+    from oracle.oracle_bd import BD_INFO_KEYS
+    obs, rew, term, trunc, info = env.step(torch.tensor(actions))
+    torch.cuda.synchronize()
+    res = [o.step(float(actions[e])) for e, o in enumerate(oracles)]
+    gi = info.cpu().numpy()
+    oi = np.array([[r[4][k] for k in BD_INFO_KEYS] for r in res])
+    assert np.array_equal(gi, oi), (tag, np.argwhere(gi != oi)[:5])
+    assert np.array_equal(rew.cpu().numpy(), np.array([r[1] for r in res])), tag
+    assert np.array_equal(term.cpu().numpy().astype(bool), np.array([r[2] for r in res])), tag
+    assert np.array_equal(trunc.cpu().numpy().astype(bool), np.array([r[3] for r in res])), tag
+    assert np.array_equal(obs.cpu().numpy(), np.stack([r[0] for r in res])), tag
+    st = env.body_state().cpu().numpy()
+    alive, _, _ = env.box_state()
+    for e, o in enumerate(oracles):
+        ost = o.shape_states()
+        n = 6 + env.nbox
+        sel = np.ones(n, bool)
+        sel[6:] = o.alive().astype(bool)
+        assert np.array_equal(st[e, :n][sel], ost[:n][sel]), (tag, e)
+        assert np.array_equal(alive[e, : env.nbox].astype(bool), o.alive().astype(bool)), (tag, e)
+    return res
+
+
+@pytest.mark.parametrize("oc", ["small_empty", "small_columns"])
+def test_maps_reset_and_steps_match_oracle(oc):
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    cfg.env.obstacle_config = oc
+    trials = S.generate_trials(cfg, 5)
+    E = 5
+    env = BatchedBoxDeliveryEnv(E, cfg={"env": {"obstacle_config": oc}}, trials=trials)
+    oracles = [_oracle(cfg, trials[e % len(trials)]) for e in range(E)]
+    for t in (0, 3):
+        m, om = env.maps(t), oracles[t].maps()
+        d = m["dims"]
+        si, sj, SH, SW = int(d[4]), int(d[5]), int(d[2]), int(d[3])
+        win = (slice(si, si + SH), slice(sj, sj + SW))
+        assert np.array_equal(m["cspace"], om["cspace"][win]) and np.array_equal(m["cspace_thin"], om["cspace_thin"][win])
+        assert om["cspace"].sum() == om["cspace"][win].sum()
+        assert np.array_equal(m["edt"][..., 0].astype(int) + si, om["edt_i"][win]) and np.array_equal(m["edt"][..., 1].astype(int) + sj, om["edt_j"][win])
+        assert np.array_equal(m["recept"], om["recept"][win]) and np.array_equal(m["small_free"], om["small_free"])
+    obs, info = env.reset()
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
+    assert obs.shape == (E, 224, 224, 4)
+    rng = np.random.RandomState(7)
+    for t in range(5):
+        _compare_step(env, oracles, rng.uniform(-1, 1, E), "step %d" % t)
+    env.check_errors()
+    env.close()
+
+
+def test_delivery_removes_the_box_like_the_oracle():
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    base = S.generate_trials(cfg, 1)[0]
+    tr = dict(base)
+    tr["start"] = np.array([1.5, 1.75, 0.0])
+    tr["boxes"] = np.array([[2.6, 1.75, 0.3], [-3.0, -1.0, 0.0]])
+    env = BatchedBoxDeliveryEnv(2, trials=[tr])
+    oracles = [_oracle(cfg, tr), _oracle(cfg, tr)]
+    env.reset()
+    rewards = []
+    for t in range(4):
+        res = _compare_step(env, oracles, np.array([1.0, 1.0]), "push %d" % t)
+        rewards.append(res[0][1])
+    assert max(rewards) > 10 and list(oracles[0].alive()) == [0, 1]
+    env.check_errors()
+    env.close()
+
+
+def test_masked_reset_and_gym_adapter():
+    import benchpush_amd
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    from benchpush_amd.metrics.box_pushing_metric import BoxDeliveryMetric
+    cfg = default_cfg("box_delivery")
+    trials = S.generate_trials(cfg, 3)
+    env = BatchedBoxDeliveryEnv(3, trials=trials)
+    env.reset()
+    env.step(torch.tensor([0.3, -0.2, 0.9]))
+    before = env.body_state().cpu().numpy().copy()
+    env.reset(torch.tensor([0, 1, 0], dtype=torch.uint8))
+    torch.cuda.synchronize()
+    after = env.body_state().cpu().numpy()
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[2], after[2]) and not np.array_equal(before[1], after[1])
+    # env 1 is now in its second episode: trial (1 + 1) % 3
+    o = _oracle(cfg, trials[2])
+    assert np.array_equal(after[1, :16], o.shape_states()[:16])
+    env.close()
+    g = benchpush_amd.make("box-delivery-v0", cfg={"agent": {"action_type": "heading"}}).unwrapped
+    metric = BoxDeliveryMetric(alg_name="random", robot_mass=g.cfg.agent.mass)
+    obs, info = g.reset()
+    metric.reset(info)
+    assert obs.shape == (224, 224, 4) and obs.dtype == np.uint8
+    assert set(info) == {"state", "cumulative_distance", "cumulative_boxes", "cumulative_reward", "total_work", "obs", "box_completed_statuses",
+                         "goal_positions", "ministeps", "inactivity"}
+    obs, r, term, trunc, info = g.step(np.array([0.5], np.float32))
+    assert len(info["obs"]) == 10 and info["obs"][0].shape == (4, 2) and isinstance(r, float) and not term
+    assert info["inactivity"] == 1 and info["cumulative_distance"] > 0
+    g.close()
