@@ -77,6 +77,28 @@ def cpu_baseline(env, trials):
                       "threads, step loop only (resets untimed), %.2f s wall = %.0f core-seconds" % (nenv, steps, cores, sec, sec * cores)}
 
 
+def cpu_baseline_box(env, trials):
+    """box-delivery oracle (oracle/bp_oracle_bd.c) on one host core: a bounded sample of the same trials and action stream."""
+    from benchpush_amd import box_delivery_scenario as S
+    from oracle.oracle_bd import OracleBoxDelivery
+
+    nenv, steps = 8, 12
+    rng = np.random.RandomState(0)
+    orcs = []
+    for e in range(nenv):
+        bp = dict(env.bd_params)
+        o = OracleBoxDelivery(S.box_delivery_physics_params(env.cfg), bp, env.cfg)
+        o.reset(trials[e % len(trials)], observe=False)
+        orcs.append(o)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for o in orcs:
+            o.step(float(rng.uniform(-1, 1)))
+    sec = time.perf_counter() - t0
+    return {"value": nenv * steps / sec, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d env.step() of the same trials (heading actions U(-1,1), observation included), one thread, %.2f s" % (nenv, steps, sec)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,8 +109,9 @@ def main():
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
-    ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze"],
-                    help="ship-ice = BASELINE.json configs[1] (the headline); maze = configs[2], informational")
+    ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze", "box"],
+                    help="ship-ice = BASELINE.json configs[1] (the headline); maze = configs[2], box = configs[3] (box-delivery-v0, "
+                         "12 boxes), both informational")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +137,12 @@ def main():
         env = BatchedMazeEnv(E, cfg={"num_obstacles": 20}, num_layouts=args.trials, base_seed=0, device=device, env_id_offset=rank * E)
         trials = env.layouts
         nf_mean = 20.0
+    elif args.env == "box":
+        from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+        env = BatchedBoxDeliveryEnv(E, cfg={"boxes": {"num_boxes_small": 12}}, num_trials=min(args.trials, 64), device=device,
+                                    env_id_offset=rank * E)
+        trials = env.trials
+        nf_mean = 12.0
     else:
         trials = default_trials(args.concentration, args.trials, base_seed=0)
         env = BatchedShipIceEnv(E, cfg={"concentration": args.concentration}, trials=trials, device=device,
@@ -133,7 +162,10 @@ def main():
         obs, rew, term, trunc, info = env.step(actions[t])
         if not args.no_auto_reset:
             ep_done.add_(term.to(torch.int64))
-            ep_success.add_(info[:, 8].to(torch.int64))
+            if args.env == "box":   # success = every box delivered (terminated without the inactivity truncation)
+                ep_success.add_((term.to(torch.int64) - trunc.to(torch.int64)).clamp_min(0))
+            else:
+                ep_success.add_(info[:, 8].to(torch.int64))
             env.reset(term)
 
     for t in range(W):
@@ -166,7 +198,7 @@ def main():
     value = total_envs * K / tmax
 
     if rank == 0:
-        nb = int(round(nf_mean)) + (11 if args.env == "maze" else 1)
+        nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         roof = {
             "bound": "hbm",
@@ -189,7 +221,8 @@ def main():
                 pass
         out = {
             "metric": "env-steps/sec at N=4096 envs (ship-ice-v0), 1/2/4/8 MI355X" if args.env == "ship-ice"
-                      else "env-steps/sec at N=4096 envs (maze-NAMO-v0), informational",
+                      else "env-steps/sec at N=4096 envs (maze-NAMO-v0), informational" if args.env == "maze"
+                      else "env-steps/sec at N=4096 envs (box-delivery-v0), informational",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -197,15 +230,24 @@ def main():
                                     "solver iterations per env.step, 4x150x150 u8 obs, auto-reset" % (E, args.concentration * 100, nf_mean))
                                    if args.env == "ship-ice" else
                                    ("maze-NAMO-v0, %d envs per GPU, 20 boxes, 400 sub-steps x 10 solver iterations per env.step, "
-                                    "4x192x192 u8 rotated obs, auto-reset" % E),
+                                    "4x192x192 u8 rotated obs, auto-reset" % E) if args.env == "maze" else
+                                   ("box-delivery-v0 (small_empty), %d envs per GPU, 12 boxes, heading actions, a variable number of "
+                                    "2 ms sim steps per env.step (about 1000), one spfa per box + robot map, 224x224x4 u8 obs, auto-reset" % E),
                        "envs_per_gpu": E, "total_envs": total_envs, "concentration": args.concentration,
                        "substeps_per_step": env.params["steps"], "auto_reset": not args.no_auto_reset,
                        "episodes_finished": int(allm[:, 0].sum().item()), "episodes_success": int(allm[:, 1].sum().item())},
             "substeps_per_s": value * env.params["steps"],
             "roofline": roof,
         }
+        if args.env == "box":
+            out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish in physics_ms)"
+            out["roofline"]["note"] = "persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c)"
+            out["substeps_per_s"] = None
         if world == 1 and not args.no_cpu_baseline and args.env == "ship-ice":
             out["cpu_baseline"] = cpu_baseline(env, trials)
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and not args.no_cpu_baseline and args.env == "box":
+            out["cpu_baseline"] = cpu_baseline_box(env, trials)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:

@@ -41,6 +41,7 @@ struct BdPtrs {
     unsigned char *order;           // [E][BD_MAXBOX] self.boxes list order
     int *nalive, *nprev;            // [E]
     double *boxdist;                // [E][BD_MAXBOX]
+    d2 *boxpos;                     // [E][BD_MAXBOX] box position the cached distance was computed for
     d2 *prev;                       // [E][BD_MAXBOX][4] prev_boxes by list position
     double *cum;                    // [E][4] cumulative_distance, cumulative_reward, -, -
     int *cnt;                       // [E][4] inactivity, cumulative_boxes, -, -
@@ -534,6 +535,11 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
     env_ctx(P, D, env, trial, E);
     ArbReg A;
     SubState S;
+#ifdef BP_PROF
+    for (int q = 0; q < 24; q++) S.prof[q] = 0;
+    const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
+    unsigned long long _t_ctrl = 0;
+#endif
     init_regs(A, S);
     load_state_a<BP_ENV_BOX>(P, D, E, L, A, S, env);
     load_state_b<BP_ENV_BOX>(P, D, E, L, A, S, env);
@@ -555,6 +561,9 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
         int sim_steps = 0;
         double cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0, plen = 0, al = 0, spx = 0, spy = 0;
         for (;;) {
+#ifdef BP_PROF
+            const unsigned long long _tc0 = __builtin_amdgcn_s_memtime();
+#endif
             const double prevx = px, prevy = py, prevh = ph;
             const double wpx_ = wp[3 * wi], wpy_ = wp[3 * wi + 1], wph_ = wp[3 * wi + 2];
             const double hd = bd_hdiff(ph, wph_);
@@ -588,6 +597,9 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
                 L.sv[lane] = done_turning ? mk2(gvx * 2, gvy * 2) : mk2((gvx * 0) * 2, (gvy * 0) * 2);
             }
             __syncthreads();
+#ifdef BP_PROF
+            _t_ctrl += __builtin_amdgcn_s_memtime() - _tc0;
+#endif
             substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
             total_sub++;
             px = E.pxy[0].x; py = E.pxy[0].y; ph = bd_restrict(E.ang[0]);
@@ -670,6 +682,13 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
     }
     __syncthreads();
     store_state(P, D, L, A, env);
+#ifdef BP_PROF
+    if (D.prof != nullptr && lane == 0) {
+        S.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
+        S.prof[22] = total_sub; S.prof[15] = _t_ctrl;
+        for (int q = 0; q < 24; q++) D.prof[(size_t)env * 24 + q] = S.prof[q];
+    }
+#endif
     const int err_any = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |
                         (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
                         (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
@@ -724,10 +743,14 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
     double4 rbb;
     rbb.x = fmin(fmin(rp[0].x, rp[1].x), fmin(rp[2].x, rp[3].x)); rbb.z = fmax(fmax(rp[0].x, rp[1].x), fmax(rp[2].x, rp[3].x));
     rbb.y = fmin(fmin(rp[0].y, rp[1].y), fmin(rp[2].y, rp[3].y)); rbb.w = fmax(fmax(rp[0].y, rp[1].y), fmax(rp[2].y, rp[3].y));
+    d2 *boxpos = Q.boxpos + (size_t)env * BD_MAXBOX;
     for (int q = 0; q < nalive; q++) {
         const int k = order[q], body = B.first_box + k;
         const d2 p = E.pxy[body];
-        const double fin = bd_path_distance(B, Q, L, map, dist, p.x, p.y, B.recept_x, B.recept_y, err);
+        // shortest_path_distance is a pure function of (position, layout): a box that did not move keeps its distance
+        const d2 lastp = boxpos[k];
+        const bool same = !init && lastp.x == p.x && lastp.y == p.y;
+        const double fin = same ? boxdist[k] : bd_path_distance(B, Q, L, map, dist, p.x, p.y, B.recept_x, B.recept_y, err);
         if (!init) {
             double moved = boxdist[k] - fin;
             boxes_distance += __builtin_fabs(moved);
@@ -738,7 +761,7 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
             if (inside) { remove_mask |= 1ull << q; robot_boxes += 1; robot_reward += B.goal_reward; }
         }
         __syncthreads();
-        if (lane == 0) boxdist[k] = fin;
+        if (lane == 0) { boxdist[k] = fin; boxpos[k] = p; }
     }
     int inactivity = init ? 0 : Q.cnt[env * 4 + 0];
     if (remove_mask) {
@@ -857,6 +880,7 @@ __global__ __launch_bounds__(256) void k_bd_reset_copy(const DevParams P, const 
     copy_span(Q.alive + (size_t)env * BD_MAXBOX, Q.alive + se * BD_MAXBOX, (size_t)BD_MAXBOX, tid, nt);
     copy_span(Q.order + (size_t)env * BD_MAXBOX, Q.order + se * BD_MAXBOX, (size_t)BD_MAXBOX, tid, nt);
     copy_span(Q.boxdist + (size_t)env * BD_MAXBOX, Q.boxdist + se * BD_MAXBOX, (size_t)BD_MAXBOX, tid, nt);
+    copy_span(Q.boxpos + (size_t)env * BD_MAXBOX, Q.boxpos + se * BD_MAXBOX, (size_t)BD_MAXBOX, tid, nt);
     copy_span(Q.prev + (size_t)env * BD_MAXBOX * 4, Q.prev + se * BD_MAXBOX * 4, (size_t)BD_MAXBOX * 4, tid, nt);
     copy_span(Q.rmap + (size_t)env * B.SH * B.SW, Q.rmap + se * B.SH * B.SW, (size_t)B.SH * B.SW, tid, nt);
     if (tid == 0) {

@@ -743,6 +743,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if ((rc = dalloc(h, &Q.nalive, E))) return rc;
     if ((rc = dalloc(h, &Q.nprev, E))) return rc;
     if ((rc = dalloc(h, &Q.boxdist, E * BD_MAXBOX))) return rc;
+    if ((rc = dalloc(h, &Q.boxpos, E * BD_MAXBOX))) return rc;
     if ((rc = dalloc(h, &Q.prev, E * BD_MAXBOX * 4))) return rc;
     if ((rc = dalloc(h, &Q.cum, E * 4))) return rc;
     if ((rc = dalloc(h, &Q.cnt, E * 4))) return rc;

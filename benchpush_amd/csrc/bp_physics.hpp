@@ -215,6 +215,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                                         const double dt, const bool ship_rules)
 {
     const int lane = lane_id();
+    // vertex loops run to the largest hull of the environment family (box-delivery: quads and triangles only)
+    constexpr int VL = (KIND == BP_ENV_BOX) ? 4 : BP_MAXV;
     if (KIND == BP_ENV_BOX) { S.nev = 0; S.evmask = 0ull; }
     S.stamp += 1u;
     const unsigned now = S.stamp;
@@ -257,9 +259,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         unsigned long long *bbk = L.res_smA; // [64][4] = min x, max x, min y, max y
         if (lane < cnt) { bbk[lane * 4 + 0] = ~0ull; bbk[lane * 4 + 1] = 0ull; bbk[lane * 4 + 2] = ~0ull; bbk[lane * 4 + 3] = 0ull; }
         lds_sync();
-        for (int t0 = 0; t0 < cnt * BP_MAXV; t0 += 64) {
+        for (int t0 = 0; t0 < cnt * VL; t0 += 64) {
             const int t = t0 + lane;
-            const int kk = t / BP_MAXV, q = t - kk * BP_MAXV;
+            const int kk = t / VL, q = t - kk * VL;
             if (kk < cnt) {
                 const int i = L.mv[k0 + kk];
                 if (q < E.nv[i]) {
@@ -351,7 +353,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const int nq = (qb == sa) ? nA_h : nB_h;
             double mn = BP_INF;
 #pragma unroll 10
-            for (int q = 0; q < BP_MAXV; q++) { // several loads in flight at once; slots >= nq repeat vertex 0
+            for (int q = 0; q < VL; q++) { // several loads in flight at once; slots >= nq repeat vertex 0
                 const double d = vdot(fn, E.wv[qb * BP_MAXV + (q < nq ? q : 0)]);
                 if (d < mn) mn = d;
             }
@@ -410,7 +412,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 const d2 fn = E.wn[pbody * BP_MAXV + f], fp = E.wv[pbody * BP_MAXV + f];
                 double mn = BP_INF;
 #pragma unroll 10
-                for (int q = 0; q < BP_MAXV; q++) { // slots >= nq repeat vertex 0, which cannot win the strict '<'
+                for (int q = 0; q < VL; q++) { // slots >= nq repeat vertex 0, which cannot win the strict '<'
                     const double d = vdot(fn, E.wv[qbody * BP_MAXV + (q < nq ? q : 0)]);
                     if (d < mn) { mn = d; jm = q; }
                 }
@@ -485,13 +487,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 {
                     double mx = -BP_INF;
 #pragma unroll 5
-                    for (int q = 0; q < BP_MAXV; q++) { // slots >= nA repeat vertex 0: equal, cannot win the strict '>'
+                    for (int q = 0; q < VL; q++) { // slots >= nA repeat vertex 0: equal, cannot win the strict '>'
                         const double d = vdot(Av[q < nA ? q : 0], n);
                         if (d > mx) { mx = d; i1A = q; }
                     }
                     mx = -BP_INF;
 #pragma unroll 5
-                    for (int q = 0; q < BP_MAXV; q++) {
+                    for (int q = 0; q < VL; q++) {
                         const double d = vdot(Bv[q < nB ? q : 0], nn);
                         if (d > mx) { mx = d; i1B = q; }
                     }

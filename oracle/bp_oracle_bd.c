@@ -902,6 +902,11 @@ int orc_bd_reset(bd_env *D, const double *start, const double *robot_verts, cons
     return nsh;
 }
 
+/* test hook: robot pose after every sim step of execute_robot_path (from step index orc_bd_trace_from on) */
+double *orc_bd_trace = NULL; long orc_bd_trace_from = 0, orc_bd_trace_n = 0, orc_bd_trace_cap = 0;
+void orc_bd_set_trace(double *buf, long from, long cap) { orc_bd_trace = buf; orc_bd_trace_from = from; orc_bd_trace_n = 0; orc_bd_trace_cap = cap; }
+long orc_bd_trace_count(void) { return orc_bd_trace_n; }
+
 /* DP controller state (dp.py): only what ideal_control / advance use */
 typedef struct { int valid; double cx[2], cy[2]; double plen; double al; double spx, spy; } bd_dp;
 
@@ -1013,6 +1018,10 @@ void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *te
             space_step(E, dts);
             total_sub++;
             px = rb->p.x; py = rb->p.y; ph = bd_restrict_heading(rb->a);
+            if (orc_bd_trace && sim_steps >= orc_bd_trace_from && orc_bd_trace_n < orc_bd_trace_cap) {
+                double *o = orc_bd_trace + 4 * (size_t)orc_bd_trace_n++;
+                o[0] = px; o[1] = py; o[2] = rb->a; o[3] = (double)E->nactive;
+            }
             prev_hd = hd;
             if (bd_dist2(pwx, pwy, px, py) > 0.05) { /* MOVE_STEP_SIZE */
                 if (E->robot_hit) break;
@@ -1059,7 +1068,14 @@ void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *te
             if (np_ > 0) {
                 done = 1;
                 for (int i = 0; i < n; i++)
-                    if (bd_dist2(prevp[2 * i], prevp[2 * i + 1], cur[2 * i], cur[2 * i + 1]) > 0.005) { done = 0; break; }
+                    if (bd_dist2(prevp[2 * i], prevp[2 * i + 1], cur[2 * i], cur[2 * i + 1]) > 0.005) {
+                        done = 0;
+                        if (orc_bd_trace && orc_bd_trace_n < orc_bd_trace_cap) {
+                            double *o = orc_bd_trace + 4 * (size_t)orc_bd_trace_n++;
+                            o[0] = -1000 - i; o[1] = cur[2 * i]; o[2] = cur[2 * i + 1]; o[3] = bd_dist2(prevp[2 * i], prevp[2 * i + 1], cur[2 * i], cur[2 * i + 1]);
+                        }
+                        break;
+                    }
             }
             memcpy(prevp, cur, sizeof(double) * 2 * (size_t)n); np_ = n;
             free(cur);
