@@ -70,6 +70,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise BpError("libbenchpush_hip.so not found at %s -- build it with `python -m benchpush_amd.build` "
                       "(hipcc, gfx950). There is no CPU fallback." % LIB_PATH)
+    try:  # torch ships its own HIP runtime: load it first so that this library binds to the same copy (device memory and
+        import torch  # noqa: F401   streams are shared with torch; two runtimes in one process do not see each other's devices)
+    except ImportError:
+        pass
     path = LIB_PATH
     if os.environ.get("BP_PROF") == "1":  # diagnostic build with in-kernel phase timers (tools/prof_phases.py)
         path = LIB_PATH.replace(".so", "_prof.so")
