@@ -51,7 +51,7 @@ class BpBdConfig(C.Structure):
                 ("collision_penalty", C.c_double), ("non_movement_penalty", C.c_double), ("correct_direction_reward_scale", C.c_double),
                 ("ministep_size", C.c_double), ("sp_channel_scale", C.c_double), ("inactivity_cutoff", C.c_int32),
                 ("invert_receptacle_map", C.c_int32), ("num_boxes", C.c_int32), ("step_limit", C.c_int32),
-                ("box_half", C.c_double), ("box_density", C.c_double), ("robot_verts", (C.c_double * 2) * 4),
+                ("action_type", C.c_int32), ("_pad", C.c_int32), ("box_half", C.c_double), ("box_density", C.c_double), ("robot_verts", (C.c_double * 2) * 4),
                 ("wheel_verts", ((C.c_double * 2) * 4) * 4), ("bumper_verts", (C.c_double * 2) * 4)]
 
 

@@ -182,7 +182,8 @@ def box_delivery_params(cfg):
         use_correct_direction_reward=int(bool(cfg.train.use_correct_direction_reward)),
         inactivity_cutoff=int(cfg.misc.inactivity_cutoff_sam if sam else cfg.misc.inactivity_cutoff),
         ministep_size=float(cfg.misc.ministep_size), sp_channel_scale=float(cfg.env.shortest_path_channel_scale),
-        invert_receptacle_map=int(bool(cfg.env.invert_receptacle_map)), num_boxes=n, step_limit=10000)
+        invert_receptacle_map=int(bool(cfg.env.invert_receptacle_map)), num_boxes=n, step_limit=10000,
+        action_type={'heading': 0, 'position': 1, 'velocity': 2}[cfg.agent.action_type])
 
 
 def box_delivery_physics_params(cfg):

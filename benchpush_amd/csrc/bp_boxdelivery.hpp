@@ -24,6 +24,7 @@ struct BdParams {
     int H, W, SH, SW, si0, sj0;     // padded room, small-map window and its origin in the padded room
     int nbox, first_box;            // box slots [first_box, first_box + nbox)
     int nrecept;                    // receptacle polygons (not physics slots)
+    int action_type;                // 0 heading, 1 position (index into the local map), 2 velocity (actions [E][2])
 };
 struct BdPtrs {
     // per map (trial -> map index): window rasters
@@ -440,13 +441,22 @@ __global__ __launch_bounds__(64) void k_bd_plan(const DevParams P, const DevPtrs
     int err = 0;
     const size_t eb = (size_t)env * P.nbcap;
     const double ix = D.pxy[eb].x, iy = D.pxy[eb].y, ih = bd_restrict(D.ang[eb]);
-    // heading action -> pixel of the local map (box_delivery_env.py:706-723), in binary64
+    if (B.action_type == 2) { // velocity control needs no plan: remember the start pose and the two speeds
+        if (lane == 0) {
+            double *sf = Q.stepf + (size_t)env * 8;
+            sf[1] = ix; sf[2] = iy; sf[3] = ih; sf[6] = actions[2 * env]; sf[7] = actions[2 * env + 1];
+            Q.nwp[env] = 0;
+        }
+        return;
+    }
+    // heading action -> pixel of the local map (box_delivery_env.py:706-723), in binary64; a position action is the index itself
     const double angle = (actions[env] + 1) * BP_PI + BP_PI / 2;
     double sa, ca;
     bp_sincos(angle, sa, ca);
     const double x_movement = B.step_size * ca, y_movement = B.step_size * sa;
-    const int x_pixel = (int)((double)B.local_px / 2 + x_movement * B.ppm);
-    const int y_pixel = (int)((double)B.local_px / 2 - y_movement * B.ppm);
+    int x_pixel = (int)((double)B.local_px / 2 + x_movement * B.ppm);
+    int y_pixel = (int)((double)B.local_px / 2 - y_movement * B.ppm);
+    if (B.action_type == 1) { const long long idx = (long long)actions[env]; y_pixel = (int)(idx / B.local_px); x_pixel = (int)(idx % B.local_px); }
     // get_waypoints_to_spatial_action (position_controller.py:56-123)
     const double xm = -B.local_w / 2 + (double)x_pixel / B.ppm;
     const double ym = B.local_w / 2 - (double)y_pixel / B.ppm;
@@ -551,8 +561,25 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
     S.robot_hit = 0;
     double robot_distance = 0.0;
     unsigned total_sub = 0;
-    // ---- execute_robot_path (box_delivery_env.py:891-988) ----
-    {
+    if (B.action_type == 2) {
+        // ---- velocity control (box_delivery_env.py:672-703) ----
+        double lin = sf[6];
+        const double angv = sf[7];
+        if (__builtin_fabs(lin) >= B.target_speed) lin = B.target_speed * (double)((lin > 0) - (lin < 0));
+        for (int k = 0; k < P.steps; k++) {
+            const d2 r = E.rot[0]; // (cos, sin) of body.angle, refreshed by the previous sim step
+            if (lane < P.nkin) {
+                L.sw[lane] = mk2(angv, L.sw[lane].y);
+                L.sv[lane] = mk2(r.x * lin + -r.y * 0.0, r.y * lin + r.x * 0.0);
+            }
+            __syncthreads();
+            substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
+            total_sub++;
+            if (S.robot_hit) break;
+        }
+        robot_distance = bd_dist2(ix, iy, E.pxy[0].x, E.pxy[0].y);
+    } else {
+        // ---- execute_robot_path (box_delivery_env.py:891-988) ----
         double px = ix, py = iy, ph = ih;
         int wi = 1, path0 = 0;
         double pwx = wp[0], pwy = wp[1];

@@ -604,6 +604,8 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     B.local_px = cfg->local_px; B.use_correct_direction_reward = cfg->use_correct_direction_reward;
     B.inactivity_cutoff = cfg->inactivity_cutoff; B.num_boxes = cfg->num_boxes; B.step_limit = cfg->step_limit;
     B.first_box = 6;
+    B.action_type = cfg->action_type;
+    if (cfg->action_type < 0 || cfg->action_type > 2) { delete h; return BP_EINVAL; }
     *out = h;
     return BP_OK;
 }

@@ -26,8 +26,8 @@ BD_INFO_KEYS = _lib.BD_INFO_KEYS
 
 def _bd_cfg(cfg):
     c = merge_user_cfg(default_cfg("box_delivery"), cfg)
-    if c.agent.action_type != "heading":
-        raise NotImplementedError("only agent.action_type == 'heading' is on the accelerated path")
+    if c.agent.action_type not in ("heading", "position", "velocity"):
+        raise ValueError("agent.action_type must be heading, position or velocity")
     if c.teleop_mode or c.low_dim_state:
         raise NotImplementedError("teleop / low-dimensional modes are outside the accelerated path")
     return c
@@ -76,6 +76,15 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
         lp = self.L.bp_obs_height(self.h)
         self.obs_shape = (lp, lp, 4)
         self.obs = torch.zeros((self.num_envs,) + self.obs_shape, dtype=torch.uint8, device=self.device)
+        self.action_dim = 2 if self.cfg.agent.action_type == "velocity" else 1
+        self._actions = torch.zeros(self.num_envs * self.action_dim, dtype=torch.float64, device=self.device)
+
+    def step(self, actions):
+        """actions: [E] heading in [-1, 1] / position index, or [E, 2] = (linear, angular) speed for 'velocity'."""
+        self._actions.copy_(actions.reshape(-1).to(self.device), non_blocking=True)
+        _lib.check(self.L, self.h, self.L.bp_step(self.h, _ptr(self._actions), _ptr(self.obs), _ptr(self.reward), _ptr(self.terminated),
+                                                 _ptr(self.truncated), _ptr(self.info), self._stream()), "bp_step")
+        return self.obs, self.reward, self.terminated, self.truncated, self.info
 
     def maps(self, trial=0):
         dims = np.zeros(6, np.int32)
@@ -108,7 +117,13 @@ class BoxDeliveryEnv(Env):
         self._b = BatchedBoxDeliveryEnv(1, cfg=cfg, trials=trials, device=device, num_trials=num_trials)
         self.cfg = self._b.cfg
         self.num_boxes = self._b.nbox
-        self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float32)
+        lp = self._b.obs_shape[0]
+        if self.cfg.agent.action_type == "velocity":     # box_delivery_env.py:157-162
+            self.action_space = spaces.Box(low=-1, high=1, shape=(2,), dtype=np.float32)
+        elif self.cfg.agent.action_type == "heading":
+            self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float32)
+        else:
+            self.action_space = spaces.Box(low=0, high=lp * lp, dtype=np.float32)
         self.observation_shape = self._b.obs_shape
         self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
         self.episode_idx = None
@@ -139,7 +154,7 @@ class BoxDeliveryEnv(Env):
 
     def step(self, action):
         self.t += 1
-        a = torch.tensor([float(np.asarray(action, dtype=np.float64).reshape(-1)[0])], dtype=torch.float64)
+        a = torch.tensor(np.asarray(action, dtype=np.float64).reshape(-1)[: self._b.action_dim], dtype=torch.float64)
         self._b.step(a)
         boxes, alive = self._boxes()
         info = self._info(self._b.info[0].cpu().numpy(), boxes, alive)

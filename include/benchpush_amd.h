@@ -169,7 +169,8 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
 /* ---------------------------------------------------------------------------------------------------------------
  * box-delivery-v0 (benchpush/environments/box_delivery/box_delivery_env.py, config.yaml).  A handle made by bp_bd_create is
  * driven by the same bp_reset / bp_step / bp_observe / bp_get_body_state / bp_check_errors / bp_destroy entry points:
- *   actions  device double [E]: the 'heading' action in [-1, 1] (box_delivery_env.py:706-723)
+ *   actions  device double [E]: 'heading' action in [-1, 1] (box_delivery_env.py:706-723) or 'position' index into the local map;
+ *            device double [E][2] = (linear, angular) speed for 'velocity' (:672-703), selected by bp_bd_config.action_type
  *   obs      device uint8 [E][local_px][local_px][4], channels last (box_delivery_env.py:1045-1059)
  *   info     device double [E][BP_INFO_COUNT]: BP_BD_I_* columns
  * Replaces BoxDeliveryEnv.step (:634-830: PositionController waypoints, execute_robot_path, step_simulation_until_still,
@@ -195,6 +196,7 @@ typedef struct bp_bd_config {
     double partial_rewards_scale, goal_reward, collision_penalty, non_movement_penalty, correct_direction_reward_scale;
     double ministep_size, sp_channel_scale;
     int32_t inactivity_cutoff, invert_receptacle_map, num_boxes, step_limit;
+    int32_t action_type, _pad;         /* agent.action_type: 0 heading, 1 position, 2 velocity */
     double box_half, box_density;      /* boxes.box_size / 2, boxes.box_density */
     double robot_verts[4][2];          /* agent.vertices */
     double wheel_verts[4][4][2];       /* agent.wheel_vertices */

@@ -422,6 +422,7 @@ typedef struct bd_params {
     int    invert_receptacle_map;
     int    num_boxes;
     int    step_limit;                     /* STEP_LIMIT 10000 */
+    int    action_type;                    /* agent.action_type: 0 heading, 1 position, 2 velocity */
 } bd_params;
 
 typedef struct bd_env {
@@ -924,8 +925,13 @@ static void bd_dp_init(bd_dp *dp, double x, double y, const double wp[][3])
     dp->spx = dp->cx[ind]; dp->spy = dp->cy[ind];
 }
 
-/* BoxDeliveryEnv.step, heading action (box_delivery_env.py:634-830) */
+/* BoxDeliveryEnv.step (box_delivery_env.py:634-830); action2 is the angular speed of 'velocity' actions */
+void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double *reward, int *terminated, int *truncated, double *info);
 void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *terminated, int *truncated, double *info)
+{
+    orc_bd_step2(D, action, 0.0, obs, reward, terminated, truncated, info);
+}
+void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double *reward, int *terminated, int *truncated, double *info)
 {
     orc_env *E = D->E;
     const bd_params *B = &D->B;
@@ -941,14 +947,33 @@ void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *te
         const body_t *bb = &E->bodies[1 + k];
         init_d[k] = bd_shortest_path_distance(D, bb->p.x, bb->p.y, B->recept_x, B->recept_y);
     }
-    /* heading action -> spatial action index (box_delivery_env.py:706-723) */
+    double robot_distance = 0.0;
+    long total_sub = 0;
+    int nwp = 0;
+    if (B->action_type == 2) {
+        /* velocity control (box_delivery_env.py:672-703) */
+        double lin = action, angv = action2;
+        if (fabs(lin) >= B->target_speed) lin = B->target_speed * (double)((lin > 0) - (lin < 0));
+        rb->w = angv;
+        for (int k = 0; k < B->steps; k++) {
+            double sn_, cs_; bp_sincos(rb->a, &sn_, &cs_);
+            rb->v = V(cs_ * lin + -sn_ * 0.0, sn_ * lin + cs_ * 0.0);
+            space_step(E, dts);
+            total_sub++;
+            if (E->robot_hit) break;
+        }
+        robot_distance = bd_dist2(ix, iy, rb->p.x, rb->p.y);
+        D->last_nwp = 0;
+    } else {
+    /* heading action -> spatial action index (box_delivery_env.py:706-723); a position action is the index itself */
     double angle = (action + 1) * M_PI + M_PI / 2;
     double sa, ca; bp_sincos(angle, &sa, &ca);
     double x_movement = B->step_size * ca, y_movement = B->step_size * sa;
     int x_pixel = (int)((double)B->local_px / 2 + x_movement * B->ppm);
     int y_pixel = (int)((double)B->local_px / 2 - y_movement * B->ppm);
+    if (B->action_type == 1) { long idx = (long)action; y_pixel = (int)(idx / B->local_px); x_pixel = (int)(idx % B->local_px); }
     /* PositionController.get_waypoints_to_spatial_action (position_controller.py:56-123) */
-    double wpp[BD_MAXWP][2]; double wph[BD_MAXWP]; int nwp; double move_sign;
+    double wpp[BD_MAXWP][2]; double wph[BD_MAXWP]; double move_sign;
     {
         double xm = -B->local_w / 2 + (double)x_pixel / B->ppm;
         double ym = B->local_w / 2 - (double)y_pixel / B->ppm;
@@ -982,8 +1007,6 @@ void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *te
     D->last_nwp = nwp;
     for (int i = 0; i < nwp && i < BD_MAXWP; i++) { D->last_wp[i][0] = wpp[i][0]; D->last_wp[i][1] = wpp[i][1]; D->last_wp[i][2] = wph[i]; }
     /* execute_robot_path (box_delivery_env.py:891-988) */
-    double robot_distance = 0.0;
-    long total_sub = 0;
     {
         double px = ix, py = iy, ph = ih;
         int wi = 1, path0 = 0; /* path0: index of self.path[0] in the waypoint list (self.path = self.path[1:]) */
@@ -1037,6 +1060,7 @@ void orc_bd_step(bd_env *D, double action, uint8_t *obs, double *reward, int *te
             if (sim_steps > B->step_limit) break;
         }
     }
+    } /* action_type */
     /* step_simulation_until_still (box_delivery_env.py:990-1023) */
     {
         int np_ = 0; double *prevp = (double *)malloc(sizeof(double) * 2 * (size_t)(D->nbox + 2));

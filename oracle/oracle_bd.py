@@ -20,7 +20,8 @@ class BdParams(C.Structure):
                 ("partial_rewards_scale", C.c_double), ("goal_reward", C.c_double), ("collision_penalty", C.c_double),
                 ("non_movement_penalty", C.c_double), ("correct_direction_reward_scale", C.c_double),
                 ("use_correct_direction_reward", C.c_int), ("inactivity_cutoff", C.c_int), ("ministep_size", C.c_double),
-                ("sp_channel_scale", C.c_double), ("invert_receptacle_map", C.c_int), ("num_boxes", C.c_int), ("step_limit", C.c_int)]
+                ("sp_channel_scale", C.c_double), ("invert_receptacle_map", C.c_int), ("num_boxes", C.c_int), ("step_limit", C.c_int),
+                ("action_type", C.c_int)]
 
 
 _ready = False
@@ -38,6 +39,7 @@ def bdlib():
         L.orc_bd_reset.restype = ci
         L.orc_bd_reset.argtypes = [vp, vp, vp, vp, vp, ci, vp, cd, cd, ci, vp, vp, vp, vp, vp]
         L.orc_bd_step.argtypes = [vp, cd, vp, C.POINTER(cd), C.POINTER(ci), C.POINTER(ci), vp]
+        L.orc_bd_step2.argtypes = [vp, cd, cd, vp, C.POINTER(cd), C.POINTER(ci), C.POINTER(ci), vp]
         L.orc_bd_observe.argtypes = [vp, vp]
         L.orc_bd_get_maps.argtypes = [vp] + [vp] * 7
         L.orc_bd_physics.restype = vp
@@ -116,10 +118,13 @@ class OracleBoxDelivery:
         return obs
 
     def step(self, action, observe=True):
+        """action: heading in [-1, 1], a position index, or (linear, angular) for 'velocity' (bd_params['action_type'] 0 / 1 / 2)."""
         obs = np.zeros((self.lp, self.lp, 4), np.uint8) if observe else None
         r, t, tr = C.c_double(), C.c_int(), C.c_int()
         info = np.zeros(len(BD_INFO_KEYS), np.float64)
-        self.L.orc_bd_step(self.h, float(action), _p(obs) if observe else None, C.byref(r), C.byref(t), C.byref(tr), _p(info))
+        a = np.asarray(action, np.float64).reshape(-1)
+        self.L.orc_bd_step2(self.h, float(a[0]), float(a[1]) if len(a) > 1 else 0.0, _p(obs) if observe else None, C.byref(r), C.byref(t),
+                            C.byref(tr), _p(info))
         return obs, r.value, bool(t.value), bool(tr.value), dict(zip(BD_INFO_KEYS, info.tolist()))
 
     def maps(self):

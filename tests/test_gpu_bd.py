@@ -23,7 +23,7 @@ def _compare_step(env, oracles, actions, tag):
     from oracle.oracle_bd import BD_INFO_KEYS
     obs, rew, term, trunc, info = env.step(torch.tensor(actions))
     torch.cuda.synchronize()
-    res = [o.step(float(actions[e])) for e, o in enumerate(oracles)]
+    res = [o.step(actions[e]) for e, o in enumerate(oracles)]
     gi = info.cpu().numpy()
     oi = np.array([[r[4][k] for k in BD_INFO_KEYS] for r in res])
     assert np.array_equal(gi, oi), (tag, np.argwhere(gi != oi)[:5])
@@ -120,3 +120,24 @@ def test_masked_reset_and_gym_adapter():
     assert len(info["obs"]) == 10 and info["obs"][0].shape == (4, 2) and isinstance(r, float) and not term
     assert info["inactivity"] == 1 and info["cumulative_distance"] > 0
     g.close()
+
+
+@pytest.mark.parametrize("atype", ["position", "velocity"])
+def test_other_action_types_match_oracle(atype):
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    cfg.agent.action_type = atype
+    trials = S.generate_trials(cfg, 3)
+    E = 3
+    env = BatchedBoxDeliveryEnv(E, cfg={"agent": {"action_type": atype}}, trials=trials)
+    oracles = [_oracle(cfg, trials[e]) for e in range(E)]
+    env.reset()
+    rng = np.random.RandomState(11)
+    for t in range(4):
+        if atype == "position":
+            acts = rng.randint(0, 224 * 224, E).astype(np.float64)
+        else:
+            acts = np.stack([rng.uniform(-0.5, 0.5, E), rng.uniform(-1, 1, E)], 1)
+        _compare_step(env, oracles, acts, "%s %d" % (atype, t))
+    env.check_errors()
+    env.close()
