@@ -23,6 +23,7 @@ struct bp_handle {
     int *order_buf = nullptr;
     bool steps_done = false;
     bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
+    bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -254,6 +255,17 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     if (!settle) return BP_OK;
+    h->maze8 = (h->P.env_kind == BP_ENV_MAZE);
+    for (int v : h_nv) if (v > 8) h->maze8 = false;
+    if (h->maze8) {
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        hipLaunchKernelGGL(k_physics_reset_maze, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipDeviceSynchronize());
+        h->loaded = true;
+        return BP_OK;
+    }
     // settle every trial once (new space + bodies + 1000 sub-steps, ship_ice_env.py:109-220); reset() copies from these
     hipLaunchKernelGGL(k_physics_reset, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
     HIPCHK(h, hipGetLastError());
@@ -409,8 +421,12 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             h->D.order = h->order_buf;
         }
         if (mode == MODE_STEP) h->steps_done = true;
-        if (mode == MODE_STEP)
+        if (mode == MODE_STEP && h->maze8)
+            hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (mode == MODE_STEP)
             hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (h->resettle && h->maze8)
+            hipLaunchKernelGGL(k_physics_reset_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mask, info, 0);
         else if (h->resettle)
             hipLaunchKernelGGL(k_physics_reset, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mask, info, 0);
         else

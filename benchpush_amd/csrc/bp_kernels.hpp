@@ -507,6 +507,18 @@ __global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const D
 {
     physics_body<MODE_RESET, 0>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
 }
+// maze-NAMO-v0 instantiations (vertex loops of 8)
+__global__ __launch_bounds__(64) void k_physics_step_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                          double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                          unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    physics_body<MODE_STEP, BP_ENV_MAZE>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
+}
+__global__ __launch_bounds__(64) void k_physics_reset_maze(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                           double *__restrict__ info, const int tmpl)
+{
+    physics_body<MODE_RESET, BP_ENV_MAZE>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+}
 // box-delivery: new space + 1000 settle sub-steps with the boundary handlers (box_delivery_env.py:239-285)
 __global__ __launch_bounds__(64) void k_bd_settle(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                   double *__restrict__ info, const int tmpl)

@@ -215,8 +215,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                                         const double dt, const bool ship_rules)
 {
     const int lane = lane_id();
-    // vertex loops run to the largest hull of the environment family (box-delivery: quads and triangles only)
-    constexpr int VL = (KIND == BP_ENV_BOX) ? 4 : BP_MAXV;
+    // vertex loops run to the largest hull of the environment family (box-delivery: quads and triangles only; maze: the
+    // 8-vertex robot outline, checked at load -- larger outlines use the generic instantiation)
+    constexpr int VL = (KIND == BP_ENV_BOX) ? 4 : (KIND == BP_ENV_MAZE) ? 8 : BP_MAXV;
     if (KIND == BP_ENV_BOX) { S.nev = 0; S.evmask = 0ull; }
     S.stamp += 1u;
     const unsigned now = S.stamp;
