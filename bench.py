@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--trials", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
-    ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze", "box"],
+    ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze", "box", "area"],
                     help="ship-ice = BASELINE.json configs[1] (the headline); maze = configs[2], box = configs[3] (box-delivery-v0, "
                          "12 boxes), both informational")
     args = ap.parse_args()
@@ -143,6 +143,11 @@ def main():
                                     env_id_offset=rank * E)
         trials = env.trials
         nf_mean = 12.0
+    elif args.env == "area":
+        from benchpush_amd.envs.area_clearing import BatchedAreaClearingEnv
+        env = BatchedAreaClearingEnv(E, num_trials=min(args.trials, 64), device=device, env_id_offset=rank * E)
+        trials = env.trials
+        nf_mean = 10.0
     else:
         trials = default_trials(args.concentration, args.trials, base_seed=0)
         env = BatchedShipIceEnv(E, cfg={"concentration": args.concentration}, trials=trials, device=device,
@@ -162,11 +167,13 @@ def main():
         obs, rew, term, trunc, info = env.step(actions[t])
         if not args.no_auto_reset:
             ep_done.add_(term.to(torch.int64))
-            if args.env == "box":   # success = every box delivered (terminated without the inactivity truncation)
-                ep_success.add_((term.to(torch.int64) - trunc.to(torch.int64)).clamp_min(0))
+            if args.env in ("box", "area"):   # success = every box delivered / cleared (terminated without the truncation)
+                done = (term | trunc) if args.env == "area" else term
+                ep_done.add_((done.to(torch.int64) - term.to(torch.int64)))   # area-clearing also ends episodes by time truncation
+                ep_success.add_((term.to(torch.int64) - (trunc.to(torch.int64) if args.env == "box" else 0)).clamp_min(0))
             else:
                 ep_success.add_(info[:, 8].to(torch.int64))
-            env.reset(term)
+            env.reset((term | trunc) if args.env == "area" else term)
 
     for t in range(W):
         one_step(t)
@@ -222,7 +229,8 @@ def main():
         out = {
             "metric": "env-steps/sec at N=4096 envs (ship-ice-v0), 1/2/4/8 MI355X" if args.env == "ship-ice"
                       else "env-steps/sec at N=4096 envs (maze-NAMO-v0), informational" if args.env == "maze"
-                      else "env-steps/sec at N=4096 envs (box-delivery-v0), informational",
+                      else "env-steps/sec at N=4096 envs (box-delivery-v0), informational" if args.env == "box"
+                      else "env-steps/sec at N=4096 envs (area-clearing-v0), informational",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": tmax / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -232,14 +240,17 @@ def main():
                                    ("maze-NAMO-v0, %d envs per GPU, 20 boxes, 400 sub-steps x 10 solver iterations per env.step, "
                                     "4x192x192 u8 rotated obs, auto-reset" % E) if args.env == "maze" else
                                    ("box-delivery-v0 (small_empty), %d envs per GPU, 12 boxes, heading actions, a variable number of "
-                                    "2 ms sim steps per env.step (about 1000), one spfa per box + robot map, 224x224x4 u8 obs, auto-reset" % E),
+                                    "2 ms sim steps per env.step (about 1000), one spfa per box + robot map, 224x224x4 u8 obs, auto-reset" % E)
+                                   if args.env == "box" else
+                                   ("area-clearing-v0 (clear_env), %d envs per GPU, 10 boxes, heading actions, path execution + 100 sim steps "
+                                    "per env.step (about 950), robot spfa map, 224x224x4 u8 obs, auto-reset" % E),
                        "envs_per_gpu": E, "total_envs": total_envs, "concentration": args.concentration,
                        "substeps_per_step": env.params["steps"], "auto_reset": not args.no_auto_reset,
                        "episodes_finished": int(allm[:, 0].sum().item()), "episodes_success": int(allm[:, 1].sum().item())},
             "substeps_per_s": value * env.params["steps"],
             "roofline": roof,
         }
-        if args.env == "box":
+        if args.env in ("box", "area"):
             out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish in physics_ms)"
             out["roofline"]["note"] = "persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c)"
             out["substeps_per_s"] = None

@@ -51,7 +51,13 @@ class BpBdConfig(C.Structure):
                 ("collision_penalty", C.c_double), ("non_movement_penalty", C.c_double), ("correct_direction_reward_scale", C.c_double),
                 ("ministep_size", C.c_double), ("sp_channel_scale", C.c_double), ("inactivity_cutoff", C.c_int32),
                 ("invert_receptacle_map", C.c_int32), ("num_boxes", C.c_int32), ("step_limit", C.c_int32),
-                ("action_type", C.c_int32), ("_pad", C.c_int32), ("box_half", C.c_double), ("box_density", C.c_double), ("robot_verts", (C.c_double * 2) * 4),
+                ("action_type", C.c_int32), ("task", C.c_int32), ("omega_scale", C.c_double), ("v_scale", C.c_double), ("lfc", C.c_double),
+                ("yaw_rate_step", C.c_double), ("t_max", C.c_int32), ("num_goal_points", C.c_int32), ("num_boundary_verts", C.c_int32),
+                ("num_outer_verts", C.c_int32), ("boundary_penalty", C.c_double), ("box_cleared_reward", C.c_double),
+                ("box_putback_penalty", C.c_double), ("truncation_penalty", C.c_double), ("terminal_reward", C.c_double),
+                ("pushing_mult", C.c_double), ("distance_scale_max", C.c_double), ("boundary", (C.c_double * 2) * 8),
+                ("outer_boundary", (C.c_double * 2) * 8), ("footprint_verts", (C.c_double * 2) * 4), ("goal_points", (C.c_double * 2) * 128),
+                ("box_half", C.c_double), ("box_density", C.c_double), ("robot_verts", (C.c_double * 2) * 4),
                 ("wheel_verts", ((C.c_double * 2) * 4) * 4), ("bumper_verts", (C.c_double * 2) * 4)]
 
 
@@ -165,8 +171,12 @@ def make_bd_config(phys, bd, cfg):
             if k in fields:
                 setattr(c, k, v)
     c.ctrl_dt = float(phys["dt"])
-    c.box_half = float(cfg.boxes.box_size) / 2
-    c.box_density = float(cfg.boxes.box_density)
+    if bd.get("task", 0) == 1:      # area-clearing: boxes are squares of half-size obstacle_size, density sim.obstacle_density
+        c.box_half = float(cfg.obstacle_size)
+        c.box_density = float(cfg.sim.obstacle_density)
+    else:
+        c.box_half = float(cfg.boxes.box_size) / 2
+        c.box_density = float(cfg.boxes.box_density)
     for i, (x, y) in enumerate(cfg.agent.vertices):
         c.robot_verts[i][0], c.robot_verts[i][1] = float(x), float(y)
     for w, quad in enumerate(cfg.agent.wheel_vertices):
@@ -174,4 +184,20 @@ def make_bd_config(phys, bd, cfg):
             c.wheel_verts[w][i][0], c.wheel_verts[w][i][1] = float(x), float(y)
     for i, (x, y) in enumerate(cfg.agent.front_bumper_vertices):
         c.bumper_verts[i][0], c.bumper_verts[i][1] = float(x), float(y)
+    return c
+
+
+def fill_area_geometry(c, boundary, outer_boundary, footprint, goal_points):
+    """area-clearing geometry of bp_bd_config (convex boundary polygons with at most 8 vertices, at most 128 goal points)."""
+    if len(boundary) > 8 or len(outer_boundary) > 8 or len(goal_points) > 128 or len(footprint) != 4:
+        raise ValueError("area-clearing geometry exceeds the ABI capacities")
+    c.num_boundary_verts, c.num_outer_verts, c.num_goal_points = len(boundary), len(outer_boundary), len(goal_points)
+    for i, (x, y) in enumerate(boundary):
+        c.boundary[i][0], c.boundary[i][1] = float(x), float(y)
+    for i, (x, y) in enumerate(outer_boundary):
+        c.outer_boundary[i][0], c.outer_boundary[i][1] = float(x), float(y)
+    for i, (x, y) in enumerate(footprint):
+        c.footprint_verts[i][0], c.footprint_verts[i][1] = float(x), float(y)
+    for i, (x, y) in enumerate(goal_points):
+        c.goal_points[i][0], c.goal_points[i][1] = float(x), float(y)
     return c

@@ -183,7 +183,8 @@ def box_delivery_params(cfg):
         inactivity_cutoff=int(cfg.misc.inactivity_cutoff_sam if sam else cfg.misc.inactivity_cutoff),
         ministep_size=float(cfg.misc.ministep_size), sp_channel_scale=float(cfg.env.shortest_path_channel_scale),
         invert_receptacle_map=int(bool(cfg.env.invert_receptacle_map)), num_boxes=n, step_limit=10000,
-        action_type={'heading': 0, 'position': 1, 'velocity': 2}[cfg.agent.action_type])
+        action_type={'heading': 0, 'position': 1, 'velocity': 2}[cfg.agent.action_type],
+        task=0, omega_scale=3.0, v_scale=2.0, lfc=0.0)   # apply_controller: omega*3, v*2 (box_delivery_env.py:887-889); DP Lfc default 0
 
 
 def box_delivery_physics_params(cfg):

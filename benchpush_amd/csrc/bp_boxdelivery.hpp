@@ -25,6 +25,15 @@ struct BdParams {
     int nbox, first_box;            // box slots [first_box, first_box + nbox)
     int nrecept;                    // receptacle polygons (not physics slots)
     int action_type;                // 0 heading, 1 position (index into the local map), 2 velocity (actions [E][2])
+    // task switch: 0 box-delivery-v0, 1 area-clearing-v0 (benchpush/environments/area_clearing/area_clearing.py)
+    int task;
+    double omega_scale, v_scale, lfc;   // apply_controller factors (box-delivery 3, 2; area-clearing 0.5, 5) and DP look-ahead Lfc
+    double yaw_rate_step;               // area-clearing velocity actions
+    int t_max, ngoal, nbd, nob;
+    double boundary_penalty, box_cleared_reward, box_putback_penalty, truncation_penalty, terminal_reward, pushing_mult;
+    double bd_poly[8][2], ob_poly[8][2], footprint[4][2];
+    float recept_outside;               // channel-3 map outside the small-map window: box-delivery 0; area-clearing 1, and 2 within
+    int out_r;                          // out_r pixels of the window (dilated outer walls: the whole window border is wall, checked at load)
 };
 struct BdPtrs {
     // per map (trial -> map index): window rasters
@@ -51,6 +60,8 @@ struct BdPtrs {
     double *stepf;                  // [E][8] robot_distance, ix, iy, ih, hit, substeps, -, -
     float *dist;                    // [E][SH*SW] spfa scratch
     float *rmap;                    // [E][SH*SW] spfa map from the robot (observation channel 2)
+    const d2 *goals;                // [ngoal] area-clearing goal points
+    unsigned char *cleared;         // [E][BD_MAXBOX] area-clearing box_clearance_statuses
 };
 
 // ---- deterministic libm replacements (fdlibm s_atan.c / e_atan2.c restated, fixed operation order, no FMA contraction) --------
@@ -558,10 +569,20 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
     const int nwp = Q.nwp[env];
     const double *sf = Q.stepf + (size_t)env * 8;
     const double ix = sf[1], iy = sf[2], ih = sf[3];
-    S.robot_hit = 0;
+    // box-delivery clears robot_hit_obstacle at the start of a step (:640), area-clearing at its end (area_clearing.py:776)
+    S.robot_hit = (B.task == 1) ? (int)sf[4] : 0;
     double robot_distance = 0.0;
     unsigned total_sub = 0;
-    if (B.action_type == 2) {
+    if (B.action_type == 2 && B.task == 1) {
+        // ---- area-clearing velocity control (area_clearing.py:660-667): set once; the common sim steps follow ----
+        const d2 r = E.rot[0];
+        const double sv = B.target_speed * sf[6];
+        if (lane < P.nkin) {
+            L.sw[lane] = mk2(B.yaw_rate_step * sf[7] / 2, L.sw[lane].y);
+            L.sv[lane] = mk2(r.x * sv + -r.y * 0.0, r.y * sv + r.x * 0.0);
+        }
+        __syncthreads();
+    } else if (B.action_type == 2) {
         // ---- velocity control (box_delivery_env.py:672-703) ----
         double lin = sf[6];
         const double angv = sf[7];
@@ -600,7 +621,9 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
                 const double dx = cx1 - cx0, dy = cy1 - cy0;
                 plen = __builtin_sqrt(dx * dx + dy * dy);
                 const double d0 = bd_dist2(prevx, prevy, cx0, cy0), d1 = bd_dist2(prevx, prevy, cx1, cy1);
-                const bool one = d1 < d0;
+                bool one = d1 < d0;
+                // look-ahead (dp.py:78-83): only ever advances from point 0 to point 1; never runs with Lfc == 0
+                if (!one && B.lfc > d0) one = true;
                 al = plen;
                 spx = one ? cx1 : cx0; spy = one ? cy1 : cy0;
                 dp_valid = true;
@@ -620,8 +643,8 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
             { const bool one = plen < al; spx = one ? cx1 : cx0; spy = one ? cy1 : cy0; }
             // apply_controller (box_delivery_env.py:887-889)
             if (lane < P.nkin) {
-                L.sw[lane] = mk2(omega * 3, L.sw[lane].y);
-                L.sv[lane] = done_turning ? mk2(gvx * 2, gvy * 2) : mk2((gvx * 0) * 2, (gvy * 0) * 2);
+                L.sw[lane] = mk2(omega * B.omega_scale, L.sw[lane].y);
+                L.sv[lane] = done_turning ? mk2(gvx * B.v_scale, gvy * B.v_scale) : mk2((gvx * 0) * B.v_scale, (gvy * 0) * B.v_scale);
             }
             __syncthreads();
 #ifdef BP_PROF
@@ -643,8 +666,11 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
             if (sim_steps > B.step_limit) break;
         }
     }
-    // ---- step_simulation_until_still (box_delivery_env.py:990-1023) ----
-    {
+    if (B.task == 1) {
+        // ---- area-clearing: `steps` more sim steps with the last commanded velocity (area_clearing.py:691-693) ----
+        for (int k = 0; k < P.steps; k++) { substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false); total_sub++; }
+    } else {
+        // ---- step_simulation_until_still (box_delivery_env.py:990-1023) ----
         const int nalive = Q.nalive[env];
         const unsigned char *order = Q.order + (size_t)env * BD_MAXBOX;
         d2 prevp = mk2(0.0, 0.0); // lane q < nalive: box order[q]; lane nalive: robot
@@ -895,6 +921,162 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// area-clearing-v0 tail of step (area_clearing.py:695-778): completion test, rewards, work, robot spfa map
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ac_orient(const double (*p)[2], int n)
+{
+    double a = 0.0;
+    for (int i = 0; i < n; i++) { const int j = (i + 1) % n; a += p[i][0] * p[j][1] - p[j][0] * p[i][1]; }
+    return a > 0 ? 1 : -1;
+}
+// shapely Polygon.intersects for two convex polygons: no edge of either is a strictly separating line
+__device__ __forceinline__ bool ac_sep_axis(const double (*a)[2], int na, const double (*b)[2], int nb)
+{
+    const int o = ac_orient(a, na);
+    for (int i = 0; i < na; i++) {
+        const int j = (i + 1) % na;
+        bool all_out = true;
+        for (int k = 0; k < nb && all_out; k++) {
+            const double cr = (a[j][0] - a[i][0]) * (b[k][1] - a[i][1]) - (a[j][1] - a[i][1]) * (b[k][0] - a[i][0]);
+            if (!(cr * o < 0)) all_out = false;
+        }
+        if (all_out) return true;
+    }
+    return false;
+}
+__device__ __forceinline__ bool ac_intersects(const double (*a)[2], int na, const double (*b)[2], int nb)
+{
+    return !(ac_sep_axis(a, na, b, nb) || ac_sep_axis(b, nb, a, na));
+}
+
+__global__ __launch_bounds__(64) void k_ac_finish(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q, const int init,
+                                                  const int tmpl, double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                  unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    const int env = tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
+    const int lane = lane_id();
+    BdLds L;
+    bd_carve(B, (char *)bp_smem, L);
+    const int trial = D.e_trial[env];
+    const int map = Q.map_of_trial[trial];
+    bd_load_bits(B, Q, L, map);
+    EnvCtx E;
+    E.nb = D.e_nb[env];
+    env_ctx(P, D, env, trial, E);
+    const size_t eb = (size_t)env * P.nbcap;
+    float *dist = Q.dist + (size_t)env * B.SH * B.SW;
+    d2 *prev = Q.prev + (size_t)env * BD_MAXBOX * 4;
+    unsigned char *cleared = Q.cleared + (size_t)env * BD_MAXBOX;
+    double *sf = Q.stepf + (size_t)env * 8;
+    int err = 0;
+    // lane k < nbox: box k (the list never shrinks in this task)
+    double nowv[4][2], prv[4][2];
+    const bool act = lane < B.nbox;
+    if (act) {
+        for (int i = 0; i < 4; i++) {
+            const d2 w = bd_local_to_world(E, B.first_box + lane, i);
+            nowv[i][0] = w.x; nowv[i][1] = w.y;
+            const d2 pv = prev[lane * 4 + i];
+            prv[i][0] = pv.x; prv[i][1] = pv.y;
+        }
+    }
+    double rwd = 0.0, work = 0.0, diff_reward = 0.0, box_reward = 0.0, pushing_reward = 0.0;
+    int num_completed = 0, term = 0, trunc = 0, tcount = init ? 0 : Q.cnt[env * 4 + 3];
+    const int hit = init ? 0 : (int)sf[4];
+    if (!init) {
+        const bool inter = act && ac_intersects(B.bd_poly, B.nbd, nowv, 4);
+        num_completed = __popcll(ballot(act && !inter));
+        double contrib_diff = 0.0, contrib_work = 0.0;
+        if (act) {
+            d2 pa[4], pb[4];
+            for (int i = 0; i < 4; i++) { pa[i] = mk2(prv[i][0], prv[i][1]); pb[i] = mk2(nowv[i][0], nowv[i][1]); }
+            const d2 ca = poly_centroid_seq(pa, 4), cb = poly_centroid_seq(pb, 4);
+            if (ac_intersects(B.bd_poly, B.nbd, prv, 4)) {   // obs_to_goal_difference (metrics.py:73-94)
+                double min_a = BP_INF, min_b = BP_INF;
+                for (int g = 0; g < B.ngoal; g++) {
+                    const d2 gp = Q.goals[g];
+                    const double da = bd_dist2(ca.x, ca.y, gp.x, gp.y), db = bd_dist2(cb.x, cb.y, gp.x, gp.y);
+                    if (da < min_a) min_a = da;
+                    if (db < min_b) min_b = db;
+                }
+                contrib_diff = min_a - min_b;
+            }
+            const double area = poly_area_seq(pa, 4);
+            contrib_work = __builtin_sqrt((ca.x - cb.x) * (ca.x - cb.x) + (ca.y - cb.y) * (ca.y - cb.y)) * area;
+        }
+        const unsigned long long dm = ballot(act && ac_intersects(B.bd_poly, B.nbd, prv, 4));
+        for (int k = 0; k < B.nbox; k++) {    // python loop order; boxes outside the boundary are skipped (not added as 0)
+            if ((dm >> k) & 1ull) diff_reward += __shfl(contrib_diff, k);
+            work += __shfl(contrib_work, k);
+        }
+        pushing_reward = diff_reward * B.pushing_mult;
+        const int cleared_count = Q.cnt[env * 4 + 2];
+        tcount += 1; // self.t += 1 at the top of step()
+        const double dcount = __builtin_fabs((double)(num_completed - cleared_count));
+        if (num_completed > cleared_count) { box_reward = dcount * B.box_cleared_reward; tcount = 0; }
+        else box_reward = dcount * B.box_putback_penalty;
+        const double collision_penalty = hit ? B.boundary_penalty : 0;
+        const double nonmovement_penalty = 0;
+        term = num_completed == B.nbox;
+        rwd = box_reward + collision_penalty + pushing_reward + nonmovement_penalty;
+        trunc = tcount >= B.t_max;
+        if (trunc) rwd += B.truncation_penalty;
+        else if (term) rwd += B.terminal_reward;
+        __syncthreads();
+        if (act) cleared[lane] = inter ? 0 : 1;
+    } else if (lane < BD_MAXBOX) {
+        cleared[lane] = 0;
+        Q.alive[(size_t)env * BD_MAXBOX + lane] = lane < B.nbox ? 1 : 0;
+        Q.order[(size_t)env * BD_MAXBOX + lane] = (unsigned char)lane;
+    }
+    if (act) for (int i = 0; i < 4; i++) prev[lane * 4 + i] = mk2(nowv[i][0], nowv[i][1]);
+    // robot spfa map for channel 2 (create_global_shortest_path_map, area_clearing.py:1046-1053: no channel scale)
+    {
+        const d2 rpos = E.pxy[0];
+        int wi, wj;
+        bd_pos_to_win(B, rpos.x, rpos.y, wi, wj);
+        const unsigned short *edt = Q.edt + ((size_t)map * B.SH * B.SW + (size_t)wi * B.SW + wj) * 2;
+        const int src = (int)edt[0] * B.SW + (int)edt[1];
+        bd_spfa(B, L, dist, src, -1, err);
+        float *rmap = Q.rmap + (size_t)env * B.SH * B.SW;
+        const float ppm32 = (float)B.ppm;
+        const double div2 = (__builtin_sqrt(2.0) * (double)B.local_px) / B.ppm;
+        for (int i = lane; i < B.SH * B.SW; i += 64) {
+            const float d = bd_ld(dist + i);
+            float v = (__float_as_uint(d) == BD_INF_BITS) ? 0.0f : d;
+            v = v / ppm32;
+            v = (float)((double)v / div2);
+            rmap[i] = v;
+        }
+    }
+    const unsigned long long em = ballot(err != 0);
+    if (lane == 0) {
+        if (em) atomicOr(&D.e_err[env], BP_ERR_ARB_OVERFLOW);
+        if (init) {
+            Q.nalive[env] = B.nbox; Q.nprev[env] = B.nbox;
+            for (int q = 0; q < 4; q++) { Q.cum[env * 4 + q] = 0.0; Q.cnt[env * 4 + q] = 0; }
+            D.e_total_work[env] = 0.0;
+            sf[4] = 0.0;
+        } else {
+            const double tw = D.e_total_work[env] + work;
+            D.e_total_work[env] = tw;
+            Q.cnt[env * 4 + 2] = num_completed; Q.cnt[env * 4 + 3] = tcount;
+            sf[4] = 0.0; // self.robot_hit_obstacle = False at the end of step (area_clearing.py:776)
+            if (reward) reward[env] = rwd;
+            if (terminated) terminated[env] = (unsigned char)term;
+            if (truncated) truncated[env] = (unsigned char)trunc;
+            if (info) {
+                double *o = info + (size_t)env * BP_INFO_COUNT;
+                const d2 rpos = D.pxy[eb];
+                o[0] = rpos.x; o[1] = rpos.y; o[2] = D.ang[eb]; o[3] = tw; o[4] = -work; o[5] = diff_reward; o[6] = box_reward;
+                o[7] = (double)num_completed; o[8] = (B.action_type == 2) ? 1.0 : sf[0] / 2.5; o[9] = (double)hit; o[10] = sf[5]; o[11] = sf[0];
+                o[12] = (double)tcount; o[13] = (double)Q.nwp[env]; o[14] = work; o[15] = pushing_reward;
+            }
+        }
+    }
+}
+
 // reset(): box-delivery extras of the settled template -> env (k_reset_copy moves the physics state)
 __global__ __launch_bounds__(256) void k_bd_reset_copy(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q,
                                                        const unsigned char *__restrict__ mask, double *__restrict__ info)
@@ -910,9 +1092,11 @@ __global__ __launch_bounds__(256) void k_bd_reset_copy(const DevParams P, const 
     copy_span(Q.boxpos + (size_t)env * BD_MAXBOX, Q.boxpos + se * BD_MAXBOX, (size_t)BD_MAXBOX, tid, nt);
     copy_span(Q.prev + (size_t)env * BD_MAXBOX * 4, Q.prev + se * BD_MAXBOX * 4, (size_t)BD_MAXBOX * 4, tid, nt);
     copy_span(Q.rmap + (size_t)env * B.SH * B.SW, Q.rmap + se * B.SH * B.SW, (size_t)B.SH * B.SW, tid, nt);
+    if (Q.cleared != nullptr) copy_span(Q.cleared + (size_t)env * BD_MAXBOX, Q.cleared + se * BD_MAXBOX, (size_t)BD_MAXBOX, tid, nt);
     if (tid == 0) {
         Q.nalive[env] = Q.nalive[se]; Q.nprev[env] = Q.nprev[se];
         for (int q = 0; q < 4; q++) { Q.cum[env * 4 + q] = 0.0; Q.cnt[env * 4 + q] = 0; }
+        Q.stepf[(size_t)env * 8 + 4] = 0.0;
         if (info) {
             double *o = info + (size_t)env * BP_INFO_COUNT;
             const size_t eb = (size_t)env * P.nbcap;
@@ -993,22 +1177,52 @@ __global__ __launch_bounds__(BDO_THREADS) void k_bd_observe(const DevParams P, c
     const int nalive = Q.nalive[env];
     const unsigned char *order = Q.order + (size_t)env * BD_MAXBOX;
     const d2 *rp = Q.recept_poly + (size_t)map * 4;
-    for (int pidx = 0; pidx < 1 + nalive + 1; pidx++) {
-        if (tid < 4) {
-            d2 w;
-            if (pidx == 0) w = rp[tid];
-            else if (pidx <= nalive) w = bd_local_to_world(E, B.first_box + order[pidx - 1], tid);
-            else w = bd_local_to_world(E, 0, tid);
-            const double vx = w.x * B.ppm, vy = w.y * B.ppm;
-            long long ixp = (long long)(int)vx, iyp = (long long)(int)vy; // astype(np.int32)
-            ixp += off; iyp += off;
-            iyp = B.SH - iyp;
-            spx[tid] = ixp; spy[tid] = iyp;
+    const int npoly = (B.task == 1) ? 4 + B.nbox + 1 : 1 + nalive + 1;
+    for (int pidx = 0; pidx < npoly; pidx++) {
+        unsigned char code;
+        if (B.task == 1) {
+            // area-clearing (area_clearing.py:968-1026): 4 goal-area rectangles, every box (cleared ones in another class), robot footprint
+            code = pidx < 4 ? 3 : (pidx < 4 + B.nbox ? (Q.cleared[(size_t)env * BD_MAXBOX + (pidx - 4)] ? 7 : 4) : 5);
+            if (tid < 4) {
+                d2 w;
+                if (pidx < 4) {
+                    const double il = __builtin_fabs(B.bd_poly[0][0]) * 2, iw = __builtin_fabs(B.bd_poly[0][1]) * 2;
+                    const double th = __builtin_fabs(B.ob_poly[0][0]) - __builtin_fabs(B.bd_poly[0][0]);
+                    double x, y, l, wd;
+                    if (pidx == 0) { x = -il / 2 - th / 2; y = 0; l = th; wd = iw; }
+                    else if (pidx == 1) { x = il / 2 + th / 2; y = 0; l = th; wd = iw; }
+                    else if (pidx == 2) { x = 0; y = -iw / 2 - th / 2; l = il + 2 * th; wd = th; }
+                    else { x = 0; y = iw / 2 + th / 2; l = il + 2 * th; wd = th; }
+                    w = mk2((tid == 0 || tid == 3) ? x - l / 2 : x + l / 2, (tid < 2) ? y - wd / 2 : y + wd / 2);
+                } else if (pidx < 4 + B.nbox) w = bd_local_to_world(E, B.first_box + (pidx - 4), tid);
+                else {
+                    const d2 p = E.pxy[0], r = E.rot[0];
+                    const double fx = B.footprint[tid][0], fy = B.footprint[tid][1];
+                    w = mk2((r.x * fx + (-r.y) * fy) + p.x, (r.y * fx + r.x * fy) + p.y);
+                }
+                const double vx = w.x * B.ppm, vy = w.y * B.ppm;
+                long long ixp = (long long)(int)vx, iyp = (long long)(int)vy;
+                ixp += off; iyp += off;
+                iyp = B.SH - iyp;
+                spx[tid] = ixp; spy[tid] = iyp;
+            }
+        } else {
+            code = pidx == 0 ? 3 : (pidx <= nalive ? 4 : 6);
+            if (tid < 4) {
+                d2 w;
+                if (pidx == 0) w = rp[tid];
+                else if (pidx <= nalive) w = bd_local_to_world(E, B.first_box + order[pidx - 1], tid);
+                else w = bd_local_to_world(E, 0, tid);
+                const double vx = w.x * B.ppm, vy = w.y * B.ppm;
+                long long ixp = (long long)(int)vx, iyp = (long long)(int)vy; // astype(np.int32)
+                ixp += off; iyp += off;
+                iyp = B.SH - iyp;
+                spx[tid] = ixp; spy[tid] = iyp;
+            }
         }
         __syncthreads();
         long long px[4], py[4];
         for (int i = 0; i < 4; i++) { px[i] = spx[i]; py[i] = spy[i]; }
-        const unsigned char code = pidx == 0 ? 3 : (pidx <= nalive ? 4 : 6);
         bd_fill_poly_lds(img, B.SH, B.SW, px, py, 4, code, tid, BDO_THREADS);
         __syncthreads();
     }
@@ -1050,6 +1264,8 @@ __global__ __launch_bounds__(BDO_THREADS) void k_bd_observe(const DevParams P, c
             const int oi = a0 + i, oj = b0_ + j;
             int code = 0;
             float v2 = 0.0f, v3 = 0.0f;
+            bool sampled = false, inwin = false;
+            int wi_ = 0, wj_ = 0;
             if (oi >= 0 && oi < oh && oj >= 0 && oj < ow) {
                 double c0 = 0.0, c1 = 0.0;
                 c0 += (double)oi * c; c0 += (double)oj * s; c0 += off0;
@@ -1057,18 +1273,28 @@ __global__ __launch_bounds__(BDO_THREADS) void k_bd_observe(const DevParams P, c
                 if (!(c0 < 0 || c0 > ch - 1 || c1 < 0 || c1 > cw - 1)) {
                     const long long s0 = (long long)__builtin_floor(c0 + 0.5), s1 = (long long)__builtin_floor(c1 + 0.5);
                     const int wi = (int)(i0 + s0) - B.si0, wj = (int)(j0 + s1) - B.sj0;
+                    sampled = true; wi_ = wi; wj_ = wj;
                     if (wi >= 0 && wi < B.SH && wj >= 0 && wj < B.SW) {
                         const int w = wi * B.SW + wj;
+                        inwin = true;
                         code = img[w]; v2 = rmap[w]; v3 = rcp[w];
                     }
                 }
             }
+            if (sampled && !inwin) { // the static map outside the small-map window (still inside the padded room)
+                v3 = B.recept_outside;
+                if (B.task == 1) {
+                    const int gi = wi_ + B.si0 - B.si0, gj = wj_ + B.sj0 - B.sj0; // window coordinates of the sample
+                    const int dy = gi < 0 ? -gi : (gi > B.SH - 1 ? gi - (B.SH - 1) : 0), dx = gj < 0 ? -gj : (gj > B.SW - 1 ? gj - (B.SW - 1) : 0);
+                    if (dx * dx + dy * dy <= B.out_r * B.out_r) v3 = 2.0f;
+                }
+            }
             if (pass == 0) { mn2 = fminf(mn2, v2); mn3 = fminf(mn3, v3); }
             else {
-                const unsigned c0u = code == 1 ? 31u : code == 3 ? 95u : code == 4 ? 127u : code == 6 ? 191u : 0u;
+                const unsigned c0u = code == 1 ? 31u : code == 3 ? 95u : code == 4 ? 127u : code == 5 ? 159u : code == 6 ? 191u : code == 7 ? 223u : 0u;
                 const unsigned c1u = Q.robot_chan[pix];
-                const unsigned c2u = (unsigned)(unsigned char)((v2 - mn2) * 255.0f);
-                const unsigned c3u = (unsigned)(unsigned char)((v3 - mn3) * 255.0f);
+                const unsigned c2u = (unsigned)((int)((v2 - mn2) * 255.0f) & 0xFF); // numpy astype(uint8): truncate, wrap mod 256
+                const unsigned c3u = (unsigned)((int)((v3 - mn3) * 255.0f) & 0xFF);
                 ((unsigned *)obs)[(size_t)env * lp * lp + pix] = c0u | (c1u << 8) | (c2u << 16) | (c3u << 24);
             }
         }

@@ -397,7 +397,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 HIPCHK(h, hipGetLastError());
                 hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
                 HIPCHK(h, hipGetLastError());
-                hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
+                if (h->B.task == 1)
+                    hipLaunchKernelGGL(k_ac_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
+                else
+                    hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
                 HIPCHK(h, hipGetLastError());
             } else {
                 hipLaunchKernelGGL(k_reset_copy, dim3(E), dim3(256), 0, st, h->P, h->D, mask, (double *)nullptr);
@@ -622,6 +625,19 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     B.first_box = 6;
     B.action_type = cfg->action_type;
     if (cfg->action_type < 0 || cfg->action_type > 2) { delete h; return BP_EINVAL; }
+    B.task = cfg->task; B.omega_scale = cfg->omega_scale; B.v_scale = cfg->v_scale; B.lfc = cfg->lfc;
+    B.yaw_rate_step = cfg->yaw_rate_step; B.t_max = cfg->t_max;
+    B.boundary_penalty = cfg->boundary_penalty; B.box_cleared_reward = cfg->box_cleared_reward; B.box_putback_penalty = cfg->box_putback_penalty;
+    B.truncation_penalty = cfg->truncation_penalty; B.terminal_reward = cfg->terminal_reward; B.pushing_mult = cfg->pushing_mult;
+    B.recept_outside = 0.0f;
+    if (cfg->task == 1) {
+        if (cfg->num_boundary_verts < 3 || cfg->num_boundary_verts > 8 || cfg->num_outer_verts < 3 || cfg->num_outer_verts > 8 ||
+            cfg->num_goal_points < 1 || cfg->num_goal_points > 128) { delete h; return BP_EINVAL; }
+        B.nbd = cfg->num_boundary_verts; B.nob = cfg->num_outer_verts; B.ngoal = cfg->num_goal_points;
+        memcpy(B.bd_poly, cfg->boundary, sizeof(B.bd_poly)); memcpy(B.ob_poly, cfg->outer_boundary, sizeof(B.ob_poly));
+        memcpy(B.footprint, cfg->footprint_verts, sizeof(B.footprint));
+        B.recept_outside = 1.0f;
+    } else if (cfg->task != 0) { delete h; return BP_EINVAL; }
     *out = h;
     return BP_OK;
 }
@@ -672,6 +688,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
             Shape s;
             build_static_poly(sverts + o * 8, n, spose[o * 3], spose[o * 3 + 1], spose[o * 3 + 2], s);
             s.radius = srad[o]; s.e = 0.01; s.u = 1.0;
+            if (cf.task == 1) { s.e = 0.0; s.u = 0.99; }   // area_clearing.py:446-474: pymunk default elasticity, friction 0.99
             if (stype[o] == 4) {
                 if (s.verts.size() != 4) return fail(h, BP_EINVAL, "the receptacle must be a quadrilateral");
                 recepts[t] = s; nrec++;
@@ -682,7 +699,8 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
             obstacles.push_back(world_verts(s));
             nst++;
         }
-        if (nrec != 1) return fail(h, BP_EINVAL, "exactly one receptacle polygon per trial is required");
+        if (cf.task == 0 && nrec != 1) return fail(h, BP_EINVAL, "exactly one receptacle polygon per trial is required");
+        if (cf.task == 1 && nrec != 0) return fail(h, BP_EINVAL, "area-clearing has no receptacle polygon");
         (void)nphys_static; (void)nst;
         int mi = -1;
         for (size_t m = 0; m < map_keys.size() && mi < 0; m++) {
@@ -695,8 +713,11 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
         }
         if (mi < 0) {
             BdMaps M;
+            AcGeom G;
+            G.nbd = cf.num_boundary_verts; G.nob = cf.num_outer_verts; G.ngoal = cf.num_goal_points;
+            G.bd = cf.boundary; G.ob = cf.outer_boundary; G.goals = cf.goal_points; G.scale_max = cf.distance_scale_max;
             if (!bd_build_maps(obstacles, cf.room_length, cf.room_width, cf.ppm, cf.local_px, cf.local_w, cf.robot_radius, cf.robot_half_width,
-                               cf.recept_x, cf.recept_y, cf.sp_channel_scale, M))
+                               cf.recept_x, cf.recept_y, cf.sp_channel_scale, M, cf.task, &G))
                 return fail(h, BP_EINVAL, "free space does not fit the small-map window");
             h->bd_maps.push_back(M);
             map_keys.push_back(obstacles);
@@ -710,7 +731,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     BdParams &B = h->B;
     const BdMaps &M0 = h->bd_maps[0];
     B.H = M0.H; B.W = M0.W; B.SH = M0.SH; B.SW = M0.SW; B.si0 = M0.si0; B.sj0 = M0.sj0;
-    B.nbox = nbox; B.nrecept = 1;
+    B.nbox = nbox; B.nrecept = 1; B.out_r = M0.out_r;
     const int NW = B.SH * B.SW, words = (NW + 31) / 32, nm = (int)h->bd_maps.size();
     BdPtrs &Q = h->Q;
     int *d_mot; unsigned *d_free, *d_thin; unsigned short *d_edt; float *d_rec; unsigned char *d_small, *d_rchan; d2 *d_rp, *d_rn;
@@ -733,12 +754,14 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
         HIPCHK(h, hipMemcpy(d_edt + (size_t)m * NW * 2, M.edt.data(), sizeof(unsigned short) * NW * 2, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(d_rec + (size_t)m * NW, M.recept.data(), sizeof(float) * NW, hipMemcpyHostToDevice));
         HIPCHK(h, hipMemcpy(d_small + (size_t)m * NW, M.small_free.data(), NW, hipMemcpyHostToDevice));
-        const Shape &r = recepts[first_trial_of_map[m]];
-        const std::vector<P2> wv = world_verts(r);
-        d2 hp[4], hn[4];
-        for (int i = 0; i < 4; i++) { hp[i].x = wv[i].x; hp[i].y = wv[i].y; hn[i].x = r.normals[i].x; hn[i].y = r.normals[i].y; }
-        HIPCHK(h, hipMemcpy(d_rp + (size_t)m * 4, hp, sizeof(hp), hipMemcpyHostToDevice));
-        HIPCHK(h, hipMemcpy(d_rn + (size_t)m * 4, hn, sizeof(hn), hipMemcpyHostToDevice));
+        if (cf.task == 0) {
+            const Shape &r = recepts[first_trial_of_map[m]];
+            const std::vector<P2> wv = world_verts(r);
+            d2 hp[4], hn[4];
+            for (int i = 0; i < 4; i++) { hp[i].x = wv[i].x; hp[i].y = wv[i].y; hn[i].x = r.normals[i].x; hn[i].y = r.normals[i].y; }
+            HIPCHK(h, hipMemcpy(d_rp + (size_t)m * 4, hp, sizeof(hp), hipMemcpyHostToDevice));
+            HIPCHK(h, hipMemcpy(d_rn + (size_t)m * 4, hn, sizeof(hn), hipMemcpyHostToDevice));
+        }
     }
     {   // robot_state_channel (box_delivery_env.py:124-131) * 255
         const int lp = B.local_px;
@@ -770,6 +793,13 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if ((rc = dalloc(h, &Q.stepf, E * 8))) return rc;
     if ((rc = dalloc(h, &Q.dist, E * NW))) return rc;
     if ((rc = dalloc(h, &Q.rmap, E * NW))) return rc;
+    if ((rc = dalloc(h, &Q.cleared, E * BD_MAXBOX))) return rc;
+    {
+        d2 *d_goals;
+        if ((rc = dalloc(h, &d_goals, 128))) return rc;
+        if (cf.task == 1) HIPCHK(h, hipMemcpy(d_goals, cf.goal_points, sizeof(d2) * (size_t)cf.num_goal_points, hipMemcpyHostToDevice));
+        Q.goals = d_goals;
+    }
     h->bd_lds = (size_t)words * 8 + (size_t)3 * BD_QCAP * 2 + 16 + (size_t)BD_PATHCAP * 2 * 2 + BD_PATHCAP + (size_t)BD_PATHCAP * 4 + (size_t)BD_MAXWP * 16 + 64;
     h->bd_obs_lds = (size_t)((NW + 15) & ~15);
     if (h->bd_lds > 160 * 1024 || h->bd_obs_lds > 160 * 1024) return fail(h, BP_EINVAL, "map window too large for LDS");
@@ -777,12 +807,17 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_ac_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_obs_lds));
     // settle every trial once into its template slot, then the episode-start bookkeeping (box distances, robot map)
     hipLaunchKernelGGL(k_bd_settle, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
     HIPCHK(h, hipGetLastError());
-    hipLaunchKernelGGL(k_bd_finish, dim3(T), dim3(64), h->bd_lds, 0, h->P, h->D, h->B, h->Q, 1, 1, (double *)nullptr, (unsigned char *)nullptr,
-                       (unsigned char *)nullptr, (double *)nullptr);
+    if (cf.task == 1)
+        hipLaunchKernelGGL(k_ac_finish, dim3(T), dim3(64), h->bd_lds, 0, h->P, h->D, h->B, h->Q, 1, 1, (double *)nullptr, (unsigned char *)nullptr,
+                           (unsigned char *)nullptr, (double *)nullptr);
+    else
+        hipLaunchKernelGGL(k_bd_finish, dim3(T), dim3(64), h->bd_lds, 0, h->P, h->D, h->B, h->Q, 1, 1, (double *)nullptr, (unsigned char *)nullptr,
+                           (unsigned char *)nullptr, (double *)nullptr);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipDeviceSynchronize());
     h->loaded = true;

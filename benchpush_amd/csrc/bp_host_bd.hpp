@@ -237,13 +237,33 @@ struct BdMaps {
     std::vector<unsigned> free_bits, thin_bits;      // window
     std::vector<unsigned short> edt;                 // window [SH*SW][2] (window coordinates)
     std::vector<float> recept;                       // window, scaled
+    int out_r = 0;                                   // dilation radius (area-clearing: closed form of the map outside the window)
     std::vector<unsigned char> small_free;           // window
 };
 
 // obstacle polygons in world coordinates (walls, columns, dividers, corner triangles) -> all static rasters of one layout
+// area-clearing extras of bd_build_maps (task 1): boundary polygons, goal points, DISTANCE_SCALE_MAX
+struct AcGeom { int nbd = 0, nob = 0, ngoal = 0; const double (*bd)[2] = nullptr; const double (*ob)[2] = nullptr; const double (*goals)[2] = nullptr; double scale_max = 0.5; };
+static int ac_orient(const double (*p)[2], int n)
+{
+    double a = 0.0;
+    for (int i = 0; i < n; i++) { const int j = (i + 1) % n; a += p[i][0] * p[j][1] - p[j][0] * p[i][1]; }
+    return a > 0 ? 1 : -1;
+}
+static bool ac_contains_point(const double (*p)[2], int n, double x, double y) // shapely Polygon.contains(Point): strictly inside (convex)
+{
+    const int o = ac_orient(p, n);
+    for (int i = 0; i < n; i++) {
+        const int j = (i + 1) % n;
+        const double cr = (p[j][0] - p[i][0]) * (y - p[i][1]) - (p[j][1] - p[i][1]) * (x - p[i][0]);
+        if (!(cr * o > 0)) return false;
+    }
+    return true;
+}
+
 static bool bd_build_maps(const std::vector<std::vector<P2>> &obstacles, double room_length, double room_width, double ppm, int local_px,
                           double local_w, double robot_radius, double robot_half_width, double recept_x, double recept_y,
-                          double sp_channel_scale, BdMaps &M)
+                          double sp_channel_scale, BdMaps &M, int task = 0, const AcGeom *G = nullptr)
 {
     const double pad = (double)local_px * std::sqrt(2.0);
     M.H = (int)(2 * std::ceil((room_width * ppm + pad) / 2));
@@ -266,16 +286,27 @@ static bool bd_build_maps(const std::vector<std::vector<P2>> &obstacles, double 
         }
         bd_fill_poly(small, SH, SW, px, py, n, 1);
     }
-    std::vector<unsigned char> obst((size_t)H * W, 1), dil, freec((size_t)H * W), thin((size_t)H * W);
+    // box-delivery pads the room with obstacle, area-clearing with free space (area_clearing.py:1092)
+    std::vector<unsigned char> obst((size_t)H * W, task == 1 ? 0 : 1), dil, freec((size_t)H * W), thin((size_t)H * W);
     for (int i = 0; i < SH; i++) memcpy(&obst[(size_t)(M.si0 + i) * W + M.sj0], &small[(size_t)i * SW], (size_t)SW);
-    bd_dilate_disk(obst, H, W, (int)std::floor(robot_radius * ppm), dil);
+    int rad = (int)std::floor(robot_radius * ppm), rad_thin = (int)std::floor(robot_half_width * ppm);
+    if (task == 1) { const int rpw = (int)(2 * robot_radius * ppm); rad = rad_thin = (int)std::floor((double)rpw / 4); } // :1112-1117
+    M.out_r = rad;
+    bd_dilate_disk(obst, H, W, rad, dil);
     for (size_t i = 0; i < freec.size(); i++) freec[i] = !dil[i];
-    bd_dilate_disk(obst, H, W, (int)std::floor(robot_half_width * ppm), dil);
+    bd_dilate_disk(obst, H, W, rad_thin, dil);
     for (size_t i = 0; i < thin.size(); i++) thin[i] = !dil[i];
-    // every free cell lies inside the window (the padding outside it is obstacle), so the window holds all that is needed
-    for (int i = 0; i < H; i++)
-        for (int j = 0; j < W; j++)
-            if ((freec[(size_t)i * W + j] || thin[(size_t)i * W + j]) && (i < M.si0 || i >= M.si0 + SH || j < M.sj0 || j >= M.sj0 + SW)) return false;
+    if (task == 1) {
+        // the padding is free but cut off from the room by the outer walls: the window must be sealed by a ring of blocked cells
+        for (int i = 0; i < SH; i++)
+            for (int j = 0; j < SW; j++)
+                if ((i == 0 || j == 0 || i == SH - 1 || j == SW - 1) && (freec[(size_t)(M.si0 + i) * W + M.sj0 + j] || thin[(size_t)(M.si0 + i) * W + M.sj0 + j])) return false;
+    } else {
+        // every free cell lies inside the window (the padding outside it is obstacle), so the window holds all that is needed
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++)
+                if ((freec[(size_t)i * W + j] || thin[(size_t)i * W + j]) && (i < M.si0 || i >= M.si0 + SH || j < M.sj0 || j >= M.sj0 + SW)) return false;
+    }
     std::vector<int> ii, jj;
     bd_edt_indices(freec, H, W, ii, jj);
     const int words = (SH * SW + 31) / 32;
@@ -293,6 +324,41 @@ static bool bd_build_maps(const std::vector<std::vector<P2>> &obstacles, double 
             M.edt[(size_t)w * 2] = (unsigned short)a; M.edt[(size_t)w * 2 + 1] = (unsigned short)b;
             M.small_free[w] = small[w] ? 0 : 1;
         }
+    if (task == 1) {
+        // create_global_shortest_path_to_goal_points (area_clearing.py:1055-1082), float32 arithmetic as numpy does it
+        const size_t N = (size_t)H * W;
+        std::vector<float> g(N, INFINITY), img;
+        const float ppm32 = (float)ppm;
+        for (int q = 0; q < G->ngoal; q++) {
+            long long gi = (long long)std::floor((double)H / 2 - G->goals[q][1] * ppm), gj = (long long)std::floor((double)W / 2 + G->goals[q][0] * ppm);
+            gi = gi < 0 ? 0 : (gi > H - 1 ? H - 1 : gi); gj = gj < 0 ? 0 : (gj > W - 1 ? W - 1 : gj);
+            bd_spfa(freec, H, W, ii[(size_t)gi * W + gj], jj[(size_t)gi * W + gj], img);
+            for (size_t k = 0; k < N; k++) { const float v = img[k] / ppm32; if (v < g[k]) g[k] = v; }
+        }
+        const double div2 = (std::sqrt(2.0) * (double)local_px) / ppm;
+        float mx = -INFINITY, mn = INFINITY;
+        for (size_t k = 0; k < N; k++) { g[k] = (float)((double)g[k] / div2); if (g[k] > mx) mx = g[k]; if (g[k] < mn) mn = g[k]; }
+        const float scale = (float)G->scale_max;
+        for (size_t k = 0; k < N; k++) g[k] = (g[k] - mn) / (mx - mn) * scale;
+        M.recept.assign((size_t)SH * SW, 0.0f);
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < W; j++) {
+                const double x = ((double)j - (double)W / 2) / ppm, y = ((double)H / 2 - (double)i) / ppm;
+                const size_t k = (size_t)i * W + j;
+                if (!ac_contains_point(G->bd, G->nbd, x, y)) g[k] = 0.0f;
+                if (!ac_contains_point(G->ob, G->nob, x, y)) g[k] = 1.0f;
+                g[k] = g[k] + (1.0f - (freec[k] ? 1.0f : 0.0f));
+                const bool inwin = i >= M.si0 && i < M.si0 + SH && j >= M.sj0 && j < M.sj0 + SW;
+                if (inwin) M.recept[(size_t)(i - M.si0) * SW + (j - M.sj0)] = g[k];
+                else {   // the kernels use a closed form outside the window: 1, and 2 within the dilation radius of the (all-wall) border
+                    const int wi = i - M.si0, wj = j - M.sj0;
+                    const int dy = wi < 0 ? -wi : (wi > SH - 1 ? wi - (SH - 1) : 0), dx = wj < 0 ? -wj : (wj > SW - 1 ? wj - (SW - 1) : 0);
+                    const float expect = (dx * dx + dy * dy <= rad * rad) ? 2.0f : 1.0f;
+                    if (g[k] != expect) return false;
+                }
+            }
+        return true;
+    }
     // receptacle map: spfa from the (snapped) receptacle cell, float32 scaling as numpy does it (box_delivery_env.py:1115-1129)
     long long ri = (long long)std::floor((double)H / 2 - recept_y * ppm), rj = (long long)std::floor((double)W / 2 + recept_x * ppm);
     ri = ri < 0 ? 0 : (ri > H - 1 ? H - 1 : ri); rj = rj < 0 ? 0 : (rj > W - 1 ? W - 1 : rj);

@@ -18,3 +18,9 @@ register(
     entry_point="benchpush_amd.envs.box_delivery:BoxDeliveryEnv",
     max_episode_steps=30000,
 )
+
+register(
+    id="area-clearing-v0",
+    entry_point="benchpush_amd.envs.area_clearing:AreaClearingEnv",
+    max_episode_steps=30000,
+)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 3
+#define BP_ABI_VERSION 4
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -168,7 +168,7 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * box-delivery-v0 (benchpush/environments/box_delivery/box_delivery_env.py, config.yaml).  A handle made by bp_bd_create is
- * driven by the same bp_reset / bp_step / bp_observe / bp_get_body_state / bp_check_errors / bp_destroy entry points:
+ * (task 0) is driven by the same bp_reset / bp_step / bp_observe / bp_get_body_state / bp_check_errors / bp_destroy entry points:
  *   actions  device double [E]: 'heading' action in [-1, 1] (box_delivery_env.py:706-723) or 'position' index into the local map;
  *            device double [E][2] = (linear, angular) speed for 'velocity' (:672-703), selected by bp_bd_config.action_type
  *   obs      device uint8 [E][local_px][local_px][4], channels last (box_delivery_env.py:1045-1059)
@@ -196,12 +196,26 @@ typedef struct bp_bd_config {
     double partial_rewards_scale, goal_reward, collision_penalty, non_movement_penalty, correct_direction_reward_scale;
     double ministep_size, sp_channel_scale;
     int32_t inactivity_cutoff, invert_receptacle_map, num_boxes, step_limit;
-    int32_t action_type, _pad;         /* agent.action_type: 0 heading, 1 position, 2 velocity */
+    int32_t action_type;               /* agent.action_type: 0 heading, 1 position, 2 velocity */
+    int32_t task;                      /* 0 box-delivery-v0; 1 area-clearing-v0 (environments/area_clearing/area_clearing.py:611-778) */
+    double omega_scale, v_scale, lfc;  /* apply_controller factors (3, 2 | 0.5, 5) and the DP look-ahead controller.Lfc (0 | 0.5) */
+    /* area-clearing only: velocity action scale, sim.t_max, the reward constants of area_clearing.py:37-49, DISTANCE_SCALE_MAX */
+    double yaw_rate_step;
+    int32_t t_max, num_goal_points, num_boundary_verts, num_outer_verts;
+    double boundary_penalty, box_cleared_reward, box_putback_penalty, truncation_penalty, terminal_reward, pushing_mult, distance_scale_max;
+    double boundary[8][2], outer_boundary[8][2];   /* env_cfg.boundary / outer_boundary (convex polygons) */
+    double footprint_verts[4][2];                  /* agent.footprint_vertices */
+    double goal_points[128][2];                    /* _compute_boundary_goals (:225-264) */
     double box_half, box_density;      /* boxes.box_size / 2, boxes.box_density */
     double robot_verts[4][2];          /* agent.vertices */
     double wheel_verts[4][4][2];       /* agent.wheel_vertices */
     double bumper_verts[4][2];         /* agent.front_bumper_vertices */
 } bp_bd_config;
+/* area-clearing-v0 uses the same entry points with bp_bd_config.task = 1: heading/position/velocity actions, obs uint8
+ * [E][224][224][4], info columns = x, y, theta, total_work, collision reward, diff_reward, box_completed_reward, box_count, ministeps,
+ * robot_hit_obstacle, sim steps, robot distance, t, #waypoints, work, pushing reward.  bp_bd_load then takes no receptacle polygon;
+ * static polygons (walls radius 0.1) get pymunk's default elasticity 0 and friction 0.99 (area_clearing.py:446-474).
+ * Replaces AreaClearingEnv.step / reset / generate_observation (:563-778,927-1120). */
 int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offset, int32_t device, bp_handle **out);
 /* `num_trials` episodes (host pointers): starts[T][3] robot start pose, boxes[T][nbox][3] = x, y, heading, and `nstatic` static
  * polygons per trial in generate_sim_bounds order (sim_utils.py:90-135): sverts[T][ns][4][2], scount[T][ns] (3 or 4 vertices),

@@ -423,6 +423,13 @@ typedef struct bd_params {
     int    num_boxes;
     int    step_limit;                     /* STEP_LIMIT 10000 */
     int    action_type;                    /* agent.action_type: 0 heading, 1 position, 2 velocity */
+    /* shared controller knobs (box-delivery: 3, 2, 0; area-clearing: 0.5, 5, controller.Lfc) */
+    int    task;                           /* 0 box-delivery-v0, 1 area-clearing-v0 (environments/area_clearing/area_clearing.py) */
+    double omega_scale, v_scale, lfc;      /* apply_controller factors (box_delivery_env.py:887-889 / area_clearing.py:903-906), DP Lfc */
+    /* area-clearing only */
+    double yaw_rate_step;                  /* max_yaw_rate_step (pi/2)/15, area_clearing.py:198 */
+    int    t_max;                          /* sim.t_max */
+    double boundary_penalty, box_cleared_reward, box_putback_penalty, truncation_penalty, terminal_reward, pushing_mult, distance_scale_max;
 } bd_params;
 
 typedef struct bd_env {
@@ -445,6 +452,9 @@ typedef struct bd_env {
     int *cleared;
     /* last step diagnostics */
     long last_substeps; int last_nwp; double last_wp[BD_MAXWP][3];
+    /* area-clearing */
+    int nbd, nob, ngoal; double bd_poly[16][2], ob_poly[16][2], goals[128][2], footprint[4][2];
+    int cleared_count, t; double *sprop;
 } bd_env;
 
 enum { BD_I_X = 0, BD_I_Y, BD_I_THETA, BD_I_CUM_DIST, BD_I_CUM_BOXES, BD_I_CUM_REWARD, BD_I_TOTAL_WORK, BD_I_MINISTEPS, BD_I_INACTIVITY,
@@ -530,7 +540,8 @@ static void bd_update_cspace(bd_env *D)
     size_t N = (size_t)D->H * D->W, SN = (size_t)D->SH * D->SW;
     float *small = (float *)calloc(SN, sizeof(float));
     float *obst = D->tmpf;
-    for (size_t i = 0; i < N; i++) obst[i] = 1.0f;
+    /* box-delivery pads with obstacle (create_padded_room_ones), area-clearing with free space (area_clearing.py:1092) */
+    for (size_t i = 0; i < N; i++) obst[i] = D->B.task == 1 ? 0.0f : 1.0f;
     for (int k = 0; k < D->nstatic; k++) {
         const shape_t *sh = &E->shapes[D->first_static_shape + k];
         if (sh->ctype != 3) continue;
@@ -542,9 +553,14 @@ static void bd_update_cspace(bd_env *D)
     for (int i = 0; i < D->SH; i++)
         for (int j = 0; j < D->SW; j++) obst[(size_t)(si + i) * D->W + (sj + j)] = small[(size_t)i * D->SW + j];
     float *dil = (float *)calloc(N, sizeof(float));
-    bd_dilate_disk(obst, D->H, D->W, (int)floor(D->B.robot_radius * D->B.ppm), dil);
+    int rad = (int)floor(D->B.robot_radius * D->B.ppm), rad_thin = (int)floor(D->B.robot_half_width * D->B.ppm);
+    if (D->B.task == 1) { /* area_clearing.py:1112-1117: disk(floor(robot_pixel_width / 4)) for both */
+        int rpw = (int)(2 * D->B.robot_radius * D->B.ppm);
+        rad = rad_thin = (int)floor((double)rpw / 4);
+    }
+    bd_dilate_disk(obst, D->H, D->W, rad, dil);
     for (size_t i = 0; i < N; i++) D->cspace[i] = 1.0f - dil[i];
-    bd_dilate_disk(obst, D->H, D->W, (int)floor(D->B.robot_half_width * D->B.ppm), dil);
+    bd_dilate_disk(obst, D->H, D->W, rad_thin, dil);
     for (size_t i = 0; i < N; i++) D->cspace_thin[i] = 1.0f - dil[i];
     bd_edt_indices(D->cspace, D->H, D->W, D->edt_i, D->edt_j);
     for (size_t i = 0; i < SN; i++) D->small_obstacle_free[i] = 1.0f - small[i];
@@ -637,7 +653,7 @@ static void bd_scale_sp_map(const bd_env *D, float *m)
     for (size_t i = 0; i < N; i++) {
         float v = m[i] / ppm32;
         v = (float)((double)v / div2);
-        v = v * scale32;
+        if (D->B.task != 1) v = v * scale32; /* area-clearing has no shortest_path_channel_scale (area_clearing.py:1046-1053) */
         m[i] = v;
     }
 }
@@ -657,6 +673,134 @@ static void bd_recept_map(bd_env *D)
             D->recept_map[k] = v;
         }
     }
+}
+
+/* shapely predicates for the convex polygons of the shipped area-clearing layouts (restated; shapely/GEOS is absent):
+ * Polygon.contains(Point): strictly inside; Polygon.intersects(Polygon): the closed sets share a point (separating axis) */
+static int ac_orient(int n, const double (*p)[2])
+{
+    double a = 0.0;
+    for (int i = 0; i < n; i++) { int j = (i + 1) % n; a += p[i][0] * p[j][1] - p[j][0] * p[i][1]; }
+    return a > 0 ? 1 : -1;
+}
+static int ac_contains_point(int n, const double (*p)[2], double x, double y)
+{
+    int o = ac_orient(n, p);
+    for (int i = 0; i < n; i++) {
+        int j = (i + 1) % n;
+        double cr = (p[j][0] - p[i][0]) * (y - p[i][1]) - (p[j][1] - p[i][1]) * (x - p[i][0]);
+        if (!(cr * o > 0)) return 0;
+    }
+    return 1;
+}
+static int ac_sep_axis(int na, const double (*a)[2], int nb, const double (*b)[2])
+{
+    int o = ac_orient(na, a);
+    for (int i = 0; i < na; i++) { /* is some edge of a a separating line: all of b strictly outside */
+        int j = (i + 1) % na;
+        int all_out = 1;
+        for (int k = 0; k < nb && all_out; k++) {
+            double cr = (a[j][0] - a[i][0]) * (b[k][1] - a[i][1]) - (a[j][1] - a[i][1]) * (b[k][0] - a[i][0]);
+            if (!(cr * o < 0)) all_out = 0;
+        }
+        if (all_out) return 1;
+    }
+    return 0;
+}
+static int ac_intersects(int na, const double (*a)[2], int nb, const double (*b)[2])
+{
+    return !(ac_sep_axis(na, a, nb, b) || ac_sep_axis(nb, b, na, a));
+}
+
+/* create_global_shortest_path_to_goal_points (area_clearing.py:1055-1082) into D->recept_map */
+static void ac_goal_map(bd_env *D)
+{
+    size_t N = (size_t)D->H * D->W;
+    float *g = D->recept_map;
+    for (size_t k = 0; k < N; k++) g[k] = INFINITY;
+    float *img = (float *)malloc(sizeof(float) * N);
+    float ppm32 = (float)D->B.ppm;
+    for (int q = 0; q < D->ngoal; q++) {
+        int i, j;
+        bd_pos_to_pix(D, D->goals[q][0], D->goals[q][1], &i, &j);
+        { int a = D->edt_i[(size_t)i * D->W + j], b = D->edt_j[(size_t)i * D->W + j]; i = a; j = b; }
+        bd_spfa_queue(D->cspace, D->H, D->W, i, j, img, NULL);
+        for (size_t k = 0; k < N; k++) { float v = img[k] / ppm32; if (v < g[k]) g[k] = v; }
+    }
+    double div2 = (sqrt(2.0) * (double)D->B.local_px) / D->B.ppm;
+    float mx = -INFINITY, mn = INFINITY;
+    for (size_t k = 0; k < N; k++) { g[k] = (float)((double)g[k] / div2); if (g[k] > mx) mx = g[k]; if (g[k] < mn) mn = g[k]; }
+    float scale = (float)D->B.distance_scale_max;
+    for (size_t k = 0; k < N; k++) g[k] = (g[k] - mn) / (mx - mn) * scale;
+    for (int i = 0; i < D->H; i++)
+        for (int j = 0; j < D->W; j++) {
+            double x, y; bd_pix_to_pos(D, i, j, &x, &y);
+            size_t k = (size_t)i * D->W + j;
+            if (!ac_contains_point(D->nbd, D->bd_poly, x, y)) g[k] = 0.0f;
+            if (!ac_contains_point(D->nob, D->ob_poly, x, y)) g[k] = 1.0f;
+        }
+    for (size_t k = 0; k < N; k++) g[k] = g[k] + (1.0f - D->cspace[k]);
+    free(img);
+}
+void orc_ac_set_geometry(bd_env *D, int nbd, const double *bd, int nob, const double *ob, int ng, const double *goals, const double *footprint,
+                         const double *sprop)
+{
+    D->nbd = nbd; D->nob = nob; D->ngoal = ng;
+    for (int i = 0; i < nbd; i++) { D->bd_poly[i][0] = bd[2 * i]; D->bd_poly[i][1] = bd[2 * i + 1]; }
+    for (int i = 0; i < nob; i++) { D->ob_poly[i][0] = ob[2 * i]; D->ob_poly[i][1] = ob[2 * i + 1]; }
+    for (int i = 0; i < ng; i++) { D->goals[i][0] = goals[2 * i]; D->goals[i][1] = goals[2 * i + 1]; }
+    for (int i = 0; i < 4; i++) { D->footprint[i][0] = footprint[2 * i]; D->footprint[i][1] = footprint[2 * i + 1]; }
+    free(D->sprop); D->sprop = NULL;
+    (void)sprop;
+}
+
+/* area-clearing update_global_overhead_map (area_clearing.py:968-1026) */
+static void bd_shape_px(const bd_env *D, const shape_t *sh, long *px, long *py);
+static void ac_world_px(const bd_env *D, int n, const double (*w)[2], long *px, long *py)
+{
+    int off = (int)(D->B.local_w * D->B.ppm / 2) + 10;
+    for (int i = 0; i < n; i++) {
+        long ix = (long)(int)(w[i][0] * D->B.ppm), iy = (long)(int)(w[i][1] * D->B.ppm);
+        ix += off; iy += off; iy = D->SH - iy;
+        px[i] = ix; py[i] = iy;
+    }
+}
+static void ac_update_overhead(bd_env *D)
+{
+    orc_env *E = D->E;
+    size_t SN = (size_t)D->SH * D->SW;
+    float *small = (float *)malloc(sizeof(float) * SN);
+    memcpy(small, D->small_obstacle_free, sizeof(float) * SN);
+    for (size_t q = 0; q < SN; q++) if (small[q] == 1.0f) small[q] = 1.0f / 8.0f;
+    long px[ORC_MAXV], py[ORC_MAXV];
+    double il = fabs(D->bd_poly[0][0]) * 2, iw = fabs(D->bd_poly[0][1]) * 2;
+    double th = fabs(D->ob_poly[0][0]) - fabs(D->bd_poly[0][0]);
+    double rects[4][4] = {{-il / 2 - th / 2, 0, th, iw}, {il / 2 + th / 2, 0, th, iw}, {0, -iw / 2 - th / 2, il + 2 * th, th}, {0, iw / 2 + th / 2, il + 2 * th, th}};
+    for (int r = 0; r < 4; r++) {
+        double x = rects[r][0], y = rects[r][1], l = rects[r][2], w = rects[r][3];
+        double poly[4][2] = {{x - l / 2, y - w / 2}, {x + l / 2, y - w / 2}, {x + l / 2, y + w / 2}, {x - l / 2, y + w / 2}};
+        ac_world_px(D, 4, poly, px, py);
+        bd_fill_poly(small, D->SH, D->SW, 4, px, py, 3.0f / 8.0f);
+    }
+    for (int k = 0; k < D->nbox; k++) {
+        const shape_t *sh = &E->shapes[D->first_box_shape + k];
+        bd_shape_px(D, sh, px, py);
+        bd_fill_poly(small, D->SH, D->SW, sh->n, px, py, D->cleared[k] ? 7.0f / 8.0f : 4.0f / 8.0f);
+    }
+    {
+        const body_t *b = &E->bodies[0];
+        double poly[4][2];
+        for (int i = 0; i < 4; i++) {
+            poly[i][0] = b->ta * D->footprint[i][0] + b->tc * D->footprint[i][1] + b->tx;
+            poly[i][1] = b->tb * D->footprint[i][0] + b->td * D->footprint[i][1] + b->ty;
+        }
+        ac_world_px(D, 4, poly, px, py);
+        bd_fill_poly(small, D->SH, D->SW, 4, px, py, 5.0f / 8.0f);
+    }
+    int si = (int)((double)D->H / 2 - (double)D->SH / 2), sj = (int)((double)D->W / 2 - (double)D->SW / 2);
+    for (int i = 0; i < D->SH; i++)
+        for (int j = 0; j < D->SW; j++) D->overhead[(size_t)(si + i) * D->W + (sj + j)] = small[(size_t)i * D->SW + j];
+    free(small);
 }
 
 /* update_global_overhead_map (box_delivery_env.py:1177-1207) */
@@ -733,7 +877,7 @@ void orc_bd_observe(bd_env *D, uint8_t *obs)
     const body_t *rb = &E->bodies[0];
     int lp = D->B.local_px;
     size_t LN = (size_t)lp * lp;
-    bd_update_overhead(D);
+    if (D->B.task == 1) ac_update_overhead(D); else bd_update_overhead(D);
     float *ch = (float *)malloc(sizeof(float) * LN);
     /* 0: overhead */
     bd_local_map(D, D->overhead, rb->p.x, rb->p.y, rb->a, ch);
@@ -750,14 +894,14 @@ void orc_bd_observe(bd_env *D, uint8_t *obs)
         bd_local_map(D, D->robot_map, rb->p.x, rb->p.y, rb->a, ch);
         float mn = ch[0];
         for (size_t k = 1; k < LN; k++) if (ch[k] < mn) mn = ch[k];
-        for (size_t k = 0; k < LN; k++) obs[4 * k + 2] = (uint8_t)((ch[k] - mn) * 255.0f);
+        for (size_t k = 0; k < LN; k++) obs[4 * k + 2] = (uint8_t)((int)((ch[k] - mn) * 255.0f) & 0xFF); /* numpy astype(uint8): truncate, wrap mod 256 */
     }
     /* 3: shortest path to the receptacle */
     {
         bd_local_map(D, D->recept_map, rb->p.x, rb->p.y, rb->a, ch);
         float mn = ch[0];
         for (size_t k = 1; k < LN; k++) if (ch[k] < mn) mn = ch[k];
-        for (size_t k = 0; k < LN; k++) obs[4 * k + 3] = (uint8_t)((ch[k] - mn) * 255.0f);
+        for (size_t k = 0; k < LN; k++) obs[4 * k + 3] = (uint8_t)((int)((ch[k] - mn) * 255.0f) & 0xFF);
     }
     free(ch);
 }
@@ -876,6 +1020,7 @@ int orc_bd_reset(bd_env *D, const double *start, const double *robot_verts, cons
         int hn = convex_hull(scount[k], tmp, hull);
         shape_t *s = &E->shapes[si];
         s->body = bi; s->r = srad[k]; s->e = 0.01; s->u = 1.0; s->ctype = stype[k];
+        if (D->B.task == 1) { s->e = 0.0; s->u = 0.99; } /* area_clearing.py:446-448,472-474: pymunk default elasticity 0, friction 0.99 */
         shape_set_verts(s, hn, hull);
     }
     E->nb = nb; E->ns = nsh;
@@ -890,7 +1035,8 @@ int orc_bd_reset(bd_env *D, const double *start, const double *robot_verts, cons
     D->nalive = nbox;
     D->inactivity = 0; D->cum_boxes = 0; D->cum_distance = 0.0; D->cum_reward = 0.0; D->total_work = 0.0;
     bd_update_cspace(D);
-    bd_recept_map(D);
+    if (D->B.task == 1) ac_goal_map(D); else bd_recept_map(D);
+    D->cleared_count = 0; D->t = 0;
     double dts = D->B.ctrl_dt / D->B.steps;
     for (int k = 0; k < 1000; k++) space_step(E, dts); /* box_delivery_env.py:284-285 */
     /* prev_boxes = CostMap.get_obs_from_poly(self.boxes) */
@@ -911,7 +1057,7 @@ long orc_bd_trace_count(void) { return orc_bd_trace_n; }
 /* DP controller state (dp.py): only what ideal_control / advance use */
 typedef struct { int valid; double cx[2], cy[2]; double plen; double al; double spx, spy; } bd_dp;
 
-static void bd_dp_init(bd_dp *dp, double x, double y, const double wp[][3])
+static void bd_dp_init(bd_dp *dp, double x, double y, const double wp[][3], double lfc)
 {
     dp->valid = 1;
     dp->cx[0] = wp[0][0]; dp->cx[1] = wp[1][0]; dp->cy[0] = wp[0][1]; dp->cy[1] = wp[1][1];
@@ -920,9 +1066,88 @@ static void bd_dp_init(bd_dp *dp, double x, double y, const double wp[][3])
     /* TargetCourse.init_setpoint: nearest of the two points (np.hypot + argmin), Lfc = 0 */
     double d0 = bd_dist2(x, y, dp->cx[0], dp->cy[0]), d1 = bd_dist2(x, y, dp->cx[1], dp->cy[1]);
     int ind = (d1 < d0) ? 1 : 0;
-    /* while Lfc > dist: never (Lfc == 0 and dist >= 0) */
+    /* look-ahead (dp.py:78-83); with Lfc == 0 (box-delivery) the loop never runs */
+    while (lfc > bd_dist2(x, y, dp->cx[ind], dp->cy[ind])) { if (ind + 1 >= 2) break; ind++; }
     dp->al = dp->plen; /* path_length[min(len - 1, ind)] with len == 1 */
     dp->spx = dp->cx[ind]; dp->spy = dp->cy[ind];
+}
+
+/* AreaClearingEnv.step after the movement (area_clearing.py:691-778): `steps` more sim steps, completion test, rewards */
+enum { AC_I_X = 0, AC_I_Y, AC_I_THETA, AC_I_TOTAL_WORK, AC_I_COLL_REWARD, AC_I_DIFF_REWARD, AC_I_BOX_REWARD, AC_I_BOX_COUNT, AC_I_MINISTEPS,
+       AC_I_HIT, AC_I_SUBSTEPS, AC_I_ROBOT_DIST, AC_I_T, AC_I_NWP, AC_I_WORK, AC_I_PUSH_REWARD, AC_I_COUNT };
+static void ac_finish_step(bd_env *D, double robot_distance, double ih, long total_sub, int nwp, uint8_t *obs, double *reward,
+                           int *terminated, int *truncated, double *info)
+{
+    orc_env *E = D->E;
+    const bd_params *B = &D->B;
+    body_t *rb = &E->bodies[0];
+    double dts = B->ctrl_dt / B->steps;
+    for (int k = 0; k < B->steps; k++) { space_step(E, dts); total_sub++; }
+    double collision_penalty = E->robot_hit ? B->boundary_penalty : 0;
+    /* updated_obstacles = CostMap.get_obs_from_poly(self.box_shapes) */
+    double (*now)[4][2] = malloc(sizeof(double) * 8 * (size_t)(D->nbox + 1));
+    for (int k = 0; k < D->nbox; k++) {
+        const shape_t *sh = &E->shapes[D->first_box_shape + k];
+        vec wv[4]; bd_box_world_verts(E, sh, wv);
+        for (int i = 0; i < 4; i++) { now[k][i][0] = wv[i].x; now[k][i][1] = wv[i].y; }
+    }
+    /* boxes_completed (area_clearing.py:1122-1140) */
+    int num_completed = 0;
+    for (int k = 0; k < D->nbox; k++) {
+        int inter = ac_intersects(D->nbd, D->bd_poly, 4, now[k]);
+        if (!inter) num_completed++;
+        D->cleared[k] = !inter;
+    }
+    int all_completed = num_completed == D->nbox;
+    /* obs_to_goal_difference (metrics.py:73-94) */
+    double diff_reward = 0.0;
+    for (int k = 0; k < D->nbox; k++) {
+        const double (*pa)[2] = (const double (*)[2])(D->prev_boxes + 8 * (size_t)k);
+        if (!ac_intersects(D->nbd, D->bd_poly, 4, pa)) continue;
+        double ax, ay, bx, by;
+        poly_centroid_np(4, D->prev_boxes + 8 * (size_t)k, &ax, &ay);
+        poly_centroid_np(4, &now[k][0][0], &bx, &by);
+        double min_a = INFINITY, min_b = INFINITY;
+        for (int g = 0; g < D->ngoal; g++) {
+            double da = bd_dist2(ax, ay, D->goals[g][0], D->goals[g][1]), db = bd_dist2(bx, by, D->goals[g][0], D->goals[g][1]);
+            if (da < min_a) min_a = da;
+            if (db < min_b) min_b = db;
+        }
+        diff_reward += min_a - min_b;
+    }
+    double pushing_reward = diff_reward * B->pushing_mult;
+    double box_reward;
+    if (num_completed > D->cleared_count) { box_reward = fabs((double)(num_completed - D->cleared_count)) * B->box_cleared_reward; D->t = 0; }
+    else box_reward = fabs((double)(num_completed - D->cleared_count)) * B->box_putback_penalty;
+    D->cleared_count = num_completed;
+    double nonmovement_penalty = 0; /* NONMOVEMENT_PENALTY = 0 */
+    double work = 0.0;
+    for (int k = 0; k < D->nbox; k++) {
+        const double *prev = D->prev_boxes + 8 * (size_t)k;
+        double area = poly_area_np(4, prev), ax, ay, bx, by;
+        poly_centroid_np(4, prev, &ax, &ay);
+        poly_centroid_np(4, &now[k][0][0], &bx, &by);
+        work += sqrt((ax - bx) * (ax - bx) + (ay - by) * (ay - by)) * area;
+    }
+    D->total_work += work;
+    memcpy(D->prev_boxes, now, sizeof(double) * 8 * (size_t)D->nbox);
+    int term = all_completed;
+    double r = box_reward + collision_penalty + pushing_reward + nonmovement_penalty;
+    int trunc = D->t >= B->t_max;
+    if (trunc) r += B->truncation_penalty;
+    else if (term) r += B->terminal_reward;
+    *reward = r; *terminated = term; *truncated = trunc;
+    if (info) {
+        info[AC_I_X] = rb->p.x; info[AC_I_Y] = rb->p.y; info[AC_I_THETA] = rb->a; info[AC_I_TOTAL_WORK] = D->total_work; info[AC_I_COLL_REWARD] = -work;
+        info[AC_I_DIFF_REWARD] = diff_reward; info[AC_I_BOX_REWARD] = box_reward; info[AC_I_BOX_COUNT] = num_completed;
+        info[AC_I_MINISTEPS] = (B->action_type == 2) ? 1.0 : robot_distance / 2.5; info[AC_I_HIT] = E->robot_hit; info[AC_I_SUBSTEPS] = (double)total_sub;
+        info[AC_I_ROBOT_DIST] = robot_distance; info[AC_I_T] = D->t; info[AC_I_NWP] = nwp; info[AC_I_WORK] = work; info[AC_I_PUSH_REWARD] = pushing_reward;
+    }
+    (void)ih;
+    if (obs) orc_bd_observe(D, obs);
+    E->robot_hit = 0; /* area_clearing.py:776 */
+    D->last_substeps = total_sub;
+    free(now);
 }
 
 /* BoxDeliveryEnv.step (box_delivery_env.py:634-830); action2 is the angular speed of 'velocity' actions */
@@ -937,12 +1162,12 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
     const bd_params *B = &D->B;
     body_t *rb = &E->bodies[0];
     double dts = B->ctrl_dt / B->steps;
-    E->robot_hit = 0;
+    if (B->task == 1) D->t += 1; else E->robot_hit = 0;
     int robot_boxes = 0; double robot_reward = 0.0;
     double ix = rb->p.x, iy = rb->p.y, ih = bd_restrict_heading(rb->a);
     /* initial box distances */
     double *init_d = (double *)malloc(sizeof(double) * (size_t)(D->nbox + 1));
-    for (int q = 0; q < D->nalive; q++) {
+    for (int q = 0; q < (B->task == 1 ? 0 : D->nalive); q++) {
         int k = D->box_order[q];
         const body_t *bb = &E->bodies[1 + k];
         init_d[k] = bd_shortest_path_distance(D, bb->p.x, bb->p.y, B->recept_x, B->recept_y);
@@ -950,7 +1175,14 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
     double robot_distance = 0.0;
     long total_sub = 0;
     int nwp = 0;
-    if (B->action_type == 2) {
+    if (B->action_type == 2 && B->task == 1) {
+        /* area-clearing velocity control (area_clearing.py:660-667): set once, the common `steps` sim steps follow */
+        double sn_, cs_; bp_sincos(rb->a, &sn_, &cs_);
+        rb->w = B->yaw_rate_step * action2 / 2;
+        double sv = B->target_speed * action;
+        rb->v = V(cs_ * sv + -sn_ * 0.0, sn_ * sv + cs_ * 0.0);
+        D->last_nwp = 0;
+    } else if (B->action_type == 2) {
         /* velocity control (box_delivery_env.py:672-703) */
         double lin = action, angv = action2;
         if (fabs(lin) >= B->target_speed) lin = B->target_speed * (double)((lin > 0) - (lin < 0));
@@ -1021,7 +1253,7 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
             /* controller (box_delivery_env.py:867-885) */
             if (!dp.valid) {
                 double two[2][3] = {{wpp[path0][0], wpp[path0][1], 0}, {wpp[path0 + 1][0], wpp[path0 + 1][1], 0}};
-                bd_dp_init(&dp, prevx, prevy, two);
+                bd_dp_init(&dp, prevx, prevy, two, B->lfc);
             }
             double theta_d = bp_atan2(dp.spy - prevy, dp.spx - prevx);
             double theta_e = theta_d - prevh;
@@ -1035,9 +1267,9 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
             dp.al += B->target_speed * B->ctrl_dt;
             { int ind = (dp.plen < dp.al) ? 1 : 0; dp.spx = dp.cx[ind]; dp.spy = dp.cy[ind]; }
             /* apply_controller */
-            rb->w = omega * 3;
-            if (!done_turning) rb->v = V((gvx * 0) * 2, (gvy * 0) * 2);
-            else rb->v = V(gvx * 2, gvy * 2);
+            rb->w = omega * B->omega_scale;   /* omega*3 | omega/2 */
+            if (!done_turning) rb->v = V((gvx * 0) * B->v_scale, (gvy * 0) * B->v_scale);
+            else rb->v = V(gvx * B->v_scale, gvy * B->v_scale);
             space_step(E, dts);
             total_sub++;
             px = rb->p.x; py = rb->p.y; ph = bd_restrict_heading(rb->a);
@@ -1061,6 +1293,7 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
         }
     }
     } /* action_type */
+    if (B->task == 1) { free(init_d); ac_finish_step(D, robot_distance, ih, total_sub, nwp, obs, reward, terminated, truncated, info); return; }
     /* step_simulation_until_still (box_delivery_env.py:990-1023) */
     {
         int np_ = 0; double *prevp = (double *)malloc(sizeof(double) * 2 * (size_t)(D->nbox + 2));

@@ -21,7 +21,10 @@ class BdParams(C.Structure):
                 ("non_movement_penalty", C.c_double), ("correct_direction_reward_scale", C.c_double),
                 ("use_correct_direction_reward", C.c_int), ("inactivity_cutoff", C.c_int), ("ministep_size", C.c_double),
                 ("sp_channel_scale", C.c_double), ("invert_receptacle_map", C.c_int), ("num_boxes", C.c_int), ("step_limit", C.c_int),
-                ("action_type", C.c_int)]
+                ("action_type", C.c_int), ("task", C.c_int), ("omega_scale", C.c_double), ("v_scale", C.c_double), ("lfc", C.c_double),
+                ("yaw_rate_step", C.c_double), ("t_max", C.c_int), ("boundary_penalty", C.c_double), ("box_cleared_reward", C.c_double),
+                ("box_putback_penalty", C.c_double), ("truncation_penalty", C.c_double), ("terminal_reward", C.c_double),
+                ("pushing_mult", C.c_double), ("distance_scale_max", C.c_double)]
 
 
 _ready = False
@@ -51,6 +54,7 @@ def bdlib():
         L.orc_bd_last_waypoints.argtypes = [vp, vp]
         L.orc_bd_shortest_path.restype = ci
         L.orc_bd_shortest_path.argtypes = [vp, vp, vp, ci, vp]
+        L.orc_ac_set_geometry.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp]
         L.orc_atan2.restype = cd
         L.orc_atan2.argtypes = [cd, cd]
         L.orc_pymod.restype = cd
@@ -153,6 +157,37 @@ class OracleBoxDelivery:
         out = np.zeros((64, 2), np.float64)
         n = self.L.orc_bd_shortest_path(self.h, _p(np.ascontiguousarray(s, np.float64)), _p(np.ascontiguousarray(t, np.float64)), int(check_straight), _p(out))
         return out[:n]
+
+
+AC_INFO_KEYS = ["x", "y", "theta", "total_work", "collision_reward", "diff_reward", "box_completed_reward", "box_count", "ministeps",
+                "robot_hit_obstacle", "substeps", "robot_distance", "t", "num_waypoints", "work", "pushing_reward"]
+
+
+class OracleAreaClearing(OracleBoxDelivery):
+    """area-clearing-v0 on the same restated engine (area_clearing.py:563-778)."""
+
+    def __init__(self, phys_params, ac_params, cfg):
+        class _Shim:   # OracleBoxDelivery reads cfg.agent.* and cfg.boxes.*
+            pass
+        shim = _Shim()
+        shim.agent = cfg.agent
+        shim.boxes = _Shim()
+        shim.boxes.box_size = 2 * float(cfg.obstacle_size)
+        shim.boxes.box_density = float(cfg.sim.obstacle_density)
+        super().__init__(phys_params, ac_params, shim)
+        from benchpush_amd import area_clearing_scenario as A
+        lay = A.env_layout(cfg)
+        bd = np.ascontiguousarray(lay.boundary, np.float64)
+        ob = np.ascontiguousarray(lay.outer_boundary, np.float64)
+        gp = np.ascontiguousarray(A.goal_points(cfg), np.float64)
+        fp = np.ascontiguousarray(cfg.agent.footprint_vertices, np.float64)
+        self.goal_points = gp
+        self.L.orc_ac_set_geometry(self.h, len(bd), _p(bd), len(ob), _p(ob), len(gp), _p(gp), _p(fp), None)
+
+    def step(self, action, observe=True):
+        obs, r, t, tr, info = super().step(action, observe)
+        vals = [info[k] for k in BD_INFO_KEYS]
+        return obs, r, t, tr, dict(zip(AC_INFO_KEYS, vals))
 
 
 # ---- primitive hooks (unit tests) ----
