@@ -17,15 +17,16 @@ try:  # pragma: no cover - not installed in the build image
 except ImportError:
     _Base = object
 
-__all__ = ["BatchedVecEnv", "make_ship_ice_vec_env", "make_maze_vec_env"]
+__all__ = ["BatchedVecEnv", "make_ship_ice_vec_env", "make_maze_vec_env", "make_box_delivery_vec_env", "make_area_clearing_vec_env"]
 
 
 class BatchedVecEnv(_Base):
-    def __init__(self, batched_env, info_keys, max_episode_steps=None, to_numpy=True):
+    def __init__(self, batched_env, info_keys, max_episode_steps=None, to_numpy=True, action_shape=()):
         self.env = batched_env
         self.num_envs = batched_env.num_envs
         self.observation_space = spaces.Box(low=0, high=255, shape=batched_env.obs_shape, dtype=np.uint8)
-        self.action_space = spaces.Box(low=-1, high=1, shape=(), dtype=np.float32)
+        self.action_space = spaces.Box(low=-1, high=1, shape=action_shape, dtype=np.float32)
+        self._adim = int(np.prod(action_shape)) if len(action_shape) else 1
         self.info_keys = list(info_keys)
         self.max_episode_steps = max_episode_steps
         self.to_numpy = to_numpy
@@ -43,8 +44,8 @@ class BatchedVecEnv(_Base):
         return self._out(obs)
 
     def step_async(self, actions):
-        a = torch.as_tensor(np.asarray(actions, dtype=np.float32).reshape(self.num_envs)) if not torch.is_tensor(actions) else actions
-        self._actions = a.reshape(self.num_envs).to(torch.float32).to(torch.float64)
+        a = torch.as_tensor(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._adim)) if not torch.is_tensor(actions) else actions
+        self._actions = a.reshape(self.num_envs * self._adim).to(torch.float32).to(torch.float64)
 
     def step_wait(self):
         obs, rew, term, trunc, info = self.env.step(self._actions)
@@ -52,7 +53,8 @@ class BatchedVecEnv(_Base):
         trunc_b = torch.zeros_like(term, dtype=torch.bool)
         if self.max_episode_steps is not None:  # gym's TimeLimit (ids registered with max_episode_steps)
             trunc_b = (self._steps >= self.max_episode_steps) & ~term.bool()
-        done = term.bool() | trunc_b
+        trunc_b = trunc_b | (trunc.bool() & ~term.bool())   # truncation reported by the env itself (box-delivery, area-clearing)
+        done = term.bool() | trunc.bool() | trunc_b
         info_h = info.cpu().numpy()
         done_h = done.cpu().numpy()
         trunc_h = trunc_b.cpu().numpy()
@@ -100,3 +102,15 @@ def make_ship_ice_vec_env(num_envs, cfg=None, **kw):
 def make_maze_vec_env(num_envs, cfg=None, **kw):
     from .maze_namo import MAZE_INFO_KEYS, BatchedMazeEnv
     return BatchedVecEnv(BatchedMazeEnv(num_envs, cfg=cfg, **kw), MAZE_INFO_KEYS, max_episode_steps=400)
+
+
+def make_box_delivery_vec_env(num_envs, cfg=None, **kw):
+    from .box_delivery import BD_INFO_KEYS, BatchedBoxDeliveryEnv
+    env = BatchedBoxDeliveryEnv(num_envs, cfg=cfg, **kw)
+    return BatchedVecEnv(env, BD_INFO_KEYS, max_episode_steps=30000, action_shape=(env.action_dim,))
+
+
+def make_area_clearing_vec_env(num_envs, cfg=None, **kw):
+    from .area_clearing import AC_INFO_KEYS, BatchedAreaClearingEnv
+    env = BatchedAreaClearingEnv(num_envs, cfg=cfg, **kw)
+    return BatchedVecEnv(env, AC_INFO_KEYS, max_episode_steps=30000, action_shape=(env.action_dim,))

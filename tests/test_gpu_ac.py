@@ -71,3 +71,25 @@ def test_area_clearing_gym_adapter_and_metric():
     assert len(info["obs"]) == 10 and len(info["box_completed_statuses"]) == 10 and isinstance(r, float)
     assert len(metric.effort_scores) == 1 and 0 < metric.effort_scores[0] <= 1.0 + 1e-9
     g.close()
+
+
+def test_vec_env_and_on_device_policy_rollout():
+    """SB3-shaped VecEnv over box-delivery (auto-reset, terminal_observation) and a torch policy consuming the device observations."""
+    import torch.nn as nn
+    from benchpush_amd.envs.vec_env import make_area_clearing_vec_env, make_box_delivery_vec_env
+    venv = make_box_delivery_vec_env(3, num_trials=3)
+    obs = venv.reset()
+    assert obs.shape == (3, 224, 224, 4) and obs.dtype == np.uint8
+    obs, rew, dones, infos = venv.step(np.array([[0.1], [-0.4], [0.8]], np.float32))
+    assert obs.shape == (3, 224, 224, 4) and rew.shape == (3,) and len(infos) == 3 and "cumulative_distance" in infos[0]
+    venv.close()
+    venv = make_area_clearing_vec_env(4, num_trials=2, to_numpy=False) if False else make_area_clearing_vec_env(4, num_trials=2)
+    venv.to_numpy = False
+    obs = venv.reset()
+    policy = nn.Sequential(nn.Flatten(), nn.Linear(224 * 224 * 4, 1), nn.Tanh()).to(obs.device)
+    with torch.no_grad():
+        for _ in range(2):
+            act = policy(obs.float() / 255.0)
+            obs, rew, dones, infos = venv.step(act)
+    assert obs.is_cuda and obs.dtype == torch.uint8 and rew.is_cuda
+    venv.close()
