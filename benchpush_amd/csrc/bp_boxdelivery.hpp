@@ -543,7 +543,7 @@ __device__ __forceinline__ d2 bd_local_to_world(const EnvCtx &E, int i, int q)
     return mk2((r.x * lv.x + (-r.y) * lv.y) + tx, (r.y * lv.x + r.x * lv.y) + ty);
 }
 
-__global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
+__global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
 {
     const int env = (D.order != nullptr) ? D.order[blockIdx.x] : (int)blockIdx.x;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -573,51 +573,52 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
     S.robot_hit = (B.task == 1) ? (int)sf[4] : 0;
     double robot_distance = 0.0;
     unsigned total_sub = 0;
-    if (B.action_type == 2 && B.task == 1) {
-        // ---- area-clearing velocity control (area_clearing.py:660-667): set once; the common sim steps follow ----
-        const d2 r = E.rot[0];
-        const double sv = B.target_speed * sf[6];
-        if (lane < P.nkin) {
-            L.sw[lane] = mk2(B.yaw_rate_step * sf[7] / 2, L.sw[lane].y);
-            L.sv[lane] = mk2(r.x * sv + -r.y * 0.0, r.y * sv + r.x * 0.0);
-        }
-        __syncthreads();
-    } else if (B.action_type == 2) {
-        // ---- velocity control (box_delivery_env.py:672-703) ----
-        double lin = sf[6];
-        const double angv = sf[7];
-        if (__builtin_fabs(lin) >= B.target_speed) lin = B.target_speed * (double)((lin > 0) - (lin < 0));
-        for (int k = 0; k < P.steps; k++) {
-            const d2 r = E.rot[0]; // (cos, sin) of body.angle, refreshed by the previous sim step
+    // One loop with a single substep call site (the physics is one large inlined function); the phase selects what happens
+    // before and after each sim step:
+    //   PATH   execute_robot_path (box_delivery_env.py:891-988 / area_clearing.py:800-901)
+    //   VEL    box-delivery velocity control (box_delivery_env.py:672-703): re-aim every sim step, stop at the first boundary hit
+    //   FIXED  area-clearing: `steps` sim steps with the last commanded twist (area_clearing.py:691-693)
+    //   STILL  box-delivery step_simulation_until_still (box_delivery_env.py:990-1023)
+    enum { PH_PATH = 0, PH_VEL, PH_FIXED, PH_STILL, PH_DONE };
+    int phase = PH_PATH;
+    // path-execution state.  Wave-uniform doubles live in VGPRs, so only what cannot be re-read is kept across the sim step:
+    // waypoints / set-point candidates are re-read from the waypoint list (scalar loads), the pose from the body arrays.
+    int wi = 1, path0 = 0;
+    double prev_hd = 0.0, plen = 0, al = 0;
+    bool done_turning = false, dp_valid = false, sp_one = false;
+    int sim_steps = 0, kcount = 0;
+    // until-still state
+    const int nalive = Q.nalive[env];
+    const unsigned char *order = Q.order + (size_t)env * BD_MAXBOX;
+    d2 prevp = mk2(0.0, 0.0); // lane q < nalive: box order[q]; lane nalive: robot
+    bool have_prev = false, still_done = false;
+    const int first_static = B.first_box + B.nbox;
+    const int nstat = E.nb - first_static;
+    if (B.action_type == 2) {
+        if (B.task == 1) {
+            // area-clearing velocity control (area_clearing.py:660-667): set once; the common sim steps follow
+            const d2 r = E.rot[0];
+            const double sv = B.target_speed * sf[6];
             if (lane < P.nkin) {
-                L.sw[lane] = mk2(angv, L.sw[lane].y);
-                L.sv[lane] = mk2(r.x * lin + -r.y * 0.0, r.y * lin + r.x * 0.0);
+                L.sw[lane] = mk2(B.yaw_rate_step * sf[7] / 2, L.sw[lane].y);
+                L.sv[lane] = mk2(r.x * sv + -r.y * 0.0, r.y * sv + r.x * 0.0);
             }
             __syncthreads();
-            substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
-            total_sub++;
-            if (S.robot_hit) break;
-        }
-        robot_distance = bd_dist2(ix, iy, E.pxy[0].x, E.pxy[0].y);
-    } else {
-        // ---- execute_robot_path (box_delivery_env.py:891-988) ----
-        double px = ix, py = iy, ph = ih;
-        int wi = 1, path0 = 0;
-        double pwx = wp[0], pwy = wp[1];
-        double prev_hd = 0.0;
-        bool done_turning = false, dp_valid = false;
-        int sim_steps = 0;
-        double cx0 = 0, cy0 = 0, cx1 = 0, cy1 = 0, plen = 0, al = 0, spx = 0, spy = 0;
-        for (;;) {
+            phase = PH_FIXED;
+        } else phase = PH_VEL;
+    }
+    while (phase != PH_DONE) {
+        // ---------------- before the sim step ----------------
+        if (phase == PH_PATH) {
 #ifdef BP_PROF
             const unsigned long long _tc0 = __builtin_amdgcn_s_memtime();
 #endif
-            const double prevx = px, prevy = py, prevh = ph;
-            const double wpx_ = wp[3 * wi], wpy_ = wp[3 * wi + 1], wph_ = wp[3 * wi + 2];
-            const double hd = bd_hdiff(ph, wph_);
+            const double prevx = E.pxy[0].x, prevy = E.pxy[0].y, prevh = bd_restrict(E.ang[0]); // pose left by the last sim step
+            const double hd = bd_hdiff(prevh, wp[3 * wi + 2]);
             if (!(__builtin_fabs(hd) > 15 * (BP_PI / 180.0) && __builtin_fabs(hd - prev_hd) > 0.001)) done_turning = true;
-            if (!dp_valid) { // DP(...) -> TargetCourse.init_setpoint (dp.py:67-88), Lfc = 0
-                cx0 = wp[3 * path0]; cy0 = wp[3 * path0 + 1]; cx1 = wp[3 * path0 + 3]; cy1 = wp[3 * path0 + 4];
+            prev_hd = hd; // prev_heading_diff of the next iteration (only read above)
+            const double cx0 = wp[3 * path0], cy0 = wp[3 * path0 + 1], cx1 = wp[3 * path0 + 3], cy1 = wp[3 * path0 + 4];
+            if (!dp_valid) { // DP(...) -> TargetCourse.init_setpoint (dp.py:67-88)
                 const double dx = cx1 - cx0, dy = cy1 - cy0;
                 plen = __builtin_sqrt(dx * dx + dy * dy);
                 const double d0 = bd_dist2(prevx, prevy, cx0, cy0), d1 = bd_dist2(prevx, prevy, cx1, cy1);
@@ -625,9 +626,10 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
                 // look-ahead (dp.py:78-83): only ever advances from point 0 to point 1; never runs with Lfc == 0
                 if (!one && B.lfc > d0) one = true;
                 al = plen;
-                spx = one ? cx1 : cx0; spy = one ? cy1 : cy0;
+                sp_one = one;
                 dp_valid = true;
             }
+            const double spx = sp_one ? cx1 : cx0, spy = sp_one ? cy1 : cy0;
             // ideal_control (dp.py:217-248)
             const double theta_d = bd_atan2(spy - prevy, spx - prevx);
             double theta_e = theta_d - prevh;
@@ -640,8 +642,8 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
             bp_sincos(prevh, sy_, cy_);
             const double gvx = cy_ * B.target_speed + -sy_ * 0.0, gvy = sy_ * B.target_speed + cy_ * 0.0;
             al += B.target_speed * B.ctrl_dt;  // TargetCourse.advance
-            { const bool one = plen < al; spx = one ? cx1 : cx0; spy = one ? cy1 : cy0; }
-            // apply_controller (box_delivery_env.py:887-889)
+            sp_one = plen < al;
+            // apply_controller (box_delivery_env.py:887-889 / area_clearing.py:903-906)
             if (lane < P.nkin) {
                 L.sw[lane] = mk2(omega * B.omega_scale, L.sw[lane].y);
                 L.sv[lane] = done_turning ? mk2(gvx * B.v_scale, gvy * B.v_scale) : mk2((gvx * 0) * B.v_scale, (gvy * 0) * B.v_scale);
@@ -650,35 +652,17 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
 #ifdef BP_PROF
             _t_ctrl += __builtin_amdgcn_s_memtime() - _tc0;
 #endif
-            substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
-            total_sub++;
-            px = E.pxy[0].x; py = E.pxy[0].y; ph = bd_restrict(E.ang[0]);
-            prev_hd = hd;
-            if (bd_dist2(pwx, pwy, px, py) > 0.05 && S.robot_hit) break;
-            if (bd_dist2(px, py, wpx_, wpy_) < 0.6 && __builtin_fabs(ph - wph_) < 10 * (BP_PI / 180.0)) {
-                robot_distance += bd_dist2(pwx, pwy, px, py);
-                if (wi == nwp - 1) break;
-                wi++;
-                pwx = wp[3 * (wi - 1)]; pwy = wp[3 * (wi - 1) + 1];
-                done_turning = false; dp_valid = false; path0++;
+        } else if (phase == PH_VEL) {
+            const d2 r = E.rot[0]; // (cos, sin) of body.angle, refreshed by the previous sim step
+            double lin = sf[6];
+            const double angv = sf[7];
+            if (__builtin_fabs(lin) >= B.target_speed) lin = B.target_speed * (double)((lin > 0) - (lin < 0));
+            if (lane < P.nkin) {
+                L.sw[lane] = mk2(angv, L.sw[lane].y);
+                L.sv[lane] = mk2(r.x * lin + -r.y * 0.0, r.y * lin + r.x * 0.0);
             }
-            sim_steps++;
-            if (sim_steps > B.step_limit) break;
-        }
-    }
-    if (B.task == 1) {
-        // ---- area-clearing: `steps` more sim steps with the last commanded velocity (area_clearing.py:691-693) ----
-        for (int k = 0; k < P.steps; k++) { substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false); total_sub++; }
-    } else {
-        // ---- step_simulation_until_still (box_delivery_env.py:990-1023) ----
-        const int nalive = Q.nalive[env];
-        const unsigned char *order = Q.order + (size_t)env * BD_MAXBOX;
-        d2 prevp = mk2(0.0, 0.0); // lane q < nalive: box order[q]; lane nalive: robot
-        bool have_prev = false, done = false;
-        int sim_steps = 0;
-        const int first_static = B.first_box + B.nbox;
-        const int nstat = E.nb - first_static;
-        while (!done) {
+            __syncthreads();
+        } else if (phase == PH_STILL) {
             // boxes with a vertex strictly inside an obstacle shape are moved to the nearest free cell
             unsigned long long stuck = 0ull;
             const int items = nalive * 4 * nstat;
@@ -724,13 +708,42 @@ __global__ __launch_bounds__(64) void k_bd_physics(const DevParams P, const DevP
             if (have_prev) {
                 // python loop with break: the comparison is pure, so "any" gives the same answer
                 const bool moved = lane <= nalive && bd_dist2(prevp.x, prevp.y, cur.x, cur.y) > 0.005;
-                done = ballot(moved) == 0;
+                still_done = ballot(moved) == 0;
             }
             prevp = cur; have_prev = true;
-            substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
-            total_sub++;
+        }
+        // ---------------- the sim step ----------------
+        substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
+        total_sub++;
+        // ---------------- after the sim step ----------------
+        const int after_move = (B.task == 1) ? PH_FIXED : PH_STILL;
+        if (phase == PH_PATH) {
+            const double px = E.pxy[0].x, py = E.pxy[0].y, ph = bd_restrict(E.ang[0]);
+            const double pwx = wp[3 * (wi - 1)], pwy = wp[3 * (wi - 1) + 1]; // robot_prev_waypoint_position
+            const double wpx_ = wp[3 * wi], wpy_ = wp[3 * wi + 1], wph_ = wp[3 * wi + 2];
+            bool leave = false;
+            if (bd_dist2(pwx, pwy, px, py) > 0.05 && S.robot_hit) leave = true;
+            else {
+                if (bd_dist2(px, py, wpx_, wpy_) < 0.6 && __builtin_fabs(ph - wph_) < 10 * (BP_PI / 180.0)) {
+                    robot_distance += bd_dist2(pwx, pwy, px, py);
+                    if (wi == nwp - 1) leave = true;
+                    else { wi++; done_turning = false; dp_valid = false; path0++; }
+                }
+                if (!leave) { sim_steps++; if (sim_steps > B.step_limit) leave = true; }
+            }
+            if (leave) { phase = after_move; sim_steps = 0; kcount = 0; }
+        } else if (phase == PH_VEL) {
+            kcount++;
+            if (S.robot_hit || kcount >= P.steps) {
+                robot_distance = bd_dist2(ix, iy, E.pxy[0].x, E.pxy[0].y);
+                phase = after_move; sim_steps = 0; kcount = 0;
+            }
+        } else if (phase == PH_FIXED) {
+            kcount++;
+            if (kcount >= P.steps) phase = PH_DONE;
+        } else { // PH_STILL
             sim_steps++;
-            if (sim_steps > B.step_limit) break;
+            if (still_done || sim_steps > B.step_limit) phase = PH_DONE;
         }
     }
     __syncthreads();

@@ -70,7 +70,7 @@ struct LdsCtx {
     unsigned *ev_key;          // [BP_EVCAP] shapeA << 16 | shapeB
     d2 *ev_d;                  // [BP_EVCAP][3] normal, r1, r2 of contact 0
 };
-#define BP_EVCAP 16
+#define BP_EVCAP 32
 #define BP_MBOX 16
 #define BP_NSLOT 96
 
