@@ -9,7 +9,9 @@
  * skimage.draw.line, skimage.measure.approximate_polygon, skimage.morphology.disk/binary_dilation.  Their published
  * algorithms are restated below from memory of the upstream sources.  PINNED against the real library in this container
  * (tests/test_bd_cpu.py): scipy.ndimage.rotate(order=0, reshape=True), scipy.ndimage.distance_transform_edt(return_indices),
- * scipy.ndimage.binary_dilation (same operator as skimage's), numpy float32 arithmetic of the observation channels.
+ * scipy.ndimage.binary_dilation (same operator as skimage's), numpy float32 arithmetic of the observation channels; and against
+ * golden vectors produced by the reference's own classes (tests/golden/make_golden_controller.py, tests/test_controller_golden.py):
+ * DP.ideal_control / TargetCourse set-point logic, PositionController.get_waypoints_to_spatial_action (straight-line branch).
  *
  * Reference call sites restated (paths relative to /root/reference/benchpush):
  *   BoxDeliveryEnv.step / reset                 environments/box_delivery/box_delivery_env.py:578-830
@@ -1072,6 +1074,77 @@ static void bd_dp_init(bd_dp *dp, double x, double y, const double wp[][3], doub
     dp->spx = dp->cx[ind]; dp->spy = dp->cy[ind];
 }
 
+/* PositionController.get_waypoints_to_spatial_action (position_controller.py:56-123): waypoints + headings for a local-map pixel */
+static int bd_plan(bd_env *D, int x_pixel, int y_pixel, double ix, double iy, double ih, double wpp[][2], double *wph, double *move_sign_out)
+{
+    const bd_params *B = &D->B;
+    int nwp; double move_sign;
+        double xm = -B->local_w / 2 + (double)x_pixel / B->ppm;
+        double ym = B->local_w / 2 - (double)y_pixel / B->ppm;
+        double sld = sqrt(xm * xm + ym * ym);
+        double turn = bp_atan2(-xm, ym);
+        double slh = bd_restrict_heading(ih + turn);
+        double sh_, ch_; bp_sincos(slh, &sh_, &ch_);
+        double tx = ix + sld * ch_, ty = iy + sld * sh_;
+        double dfx = tx - ix, dfy = ty - iy;
+        double ratio_x = 1, ratio_y = 1;
+        double sgx = (tx > 0) - (tx < 0), sgy = (ty > 0) - (ty < 0);
+        double bound_x = sgx * B->room_length / 2, bound_y = sgy * B->room_width / 2;
+        if (fabs(tx) > fabs(bound_x)) ratio_x = (bound_x - ix) / (tx - ix);
+        if (fabs(ty) > fabs(bound_y)) ratio_y = (bound_y - iy) / (ty - iy);
+        double ratio = ratio_y < ratio_x ? ratio_y : ratio_x; /* python min(a, b): b if b < a else a */
+        tx = ix + ratio * dfx; ty = iy + ratio * dfy;
+        nwp = bd_shortest_path(D, ix, iy, tx, ty, 1, wpp);
+        wph[0] = 0.0; /* None */
+        for (int i = 1; i < nwp; i++)
+            wph[i] = bd_restrict_heading(bp_atan2(wpp[i][1] - wpp[i - 1][1], wpp[i][0] - wpp[i - 1][0]));
+        double dte = bd_dist2(wpp[nwp - 2][0], wpp[nwp - 2][1], wpp[nwp - 1][0], wpp[nwp - 1][1]);
+        double signed_dist = dte - B->robot_radius;
+        move_sign = (signed_dist > 0) - (signed_dist < 0);
+        if (nwp > 2 && signed_dist < 0) {
+            wpp[nwp - 2][0] = wpp[nwp - 1][0]; wpp[nwp - 2][1] = wpp[nwp - 1][1];
+            wph[nwp - 2] = bd_restrict_heading(bp_atan2(wpp[nwp - 2][1] - wpp[nwp - 3][1], wpp[nwp - 2][0] - wpp[nwp - 3][0]));
+            move_sign = 1;
+        }
+    *move_sign_out = move_sign;
+    return nwp;
+}
+int orc_bd_plan(bd_env *D, int x_pixel, int y_pixel, const double *pose, double *out, double *move_sign)
+{
+    double wpp[BD_MAXWP][2], wph[BD_MAXWP];
+    int n = bd_plan(D, x_pixel, y_pixel, pose[0], pose[1], pose[2], wpp, wph, move_sign);
+    for (int i = 0; i < n; i++) { out[3 * i] = wpp[i][0]; out[3 * i + 1] = wpp[i][1]; out[3 * i + 2] = wph[i]; }
+    return n;
+}
+
+/* DP.ideal_control + get_setpoint (dp.py:217-248,194-204,104-107) for the current pose; returns omega and the global velocity */
+static void bd_dp_control(bd_dp *dp, double x, double y, double h, double target_speed, double ctrl_dt, double *omega, double *gvx, double *gvy)
+{
+    double theta_d = bp_atan2(dp->spy - y, dp->spx - x);
+    double theta_e = theta_d - h;
+    double se, ce; bp_sincos(theta_e, &se, &ce);
+    theta_e = bp_atan2(se, ce);
+    double om = 1.0 * theta_e;
+    om = om / ctrl_dt;
+    double sy_, cy_; bp_sincos(h, &sy_, &cy_);
+    *gvx = cy_ * target_speed + -sy_ * 0.0; *gvy = sy_ * target_speed + cy_ * 0.0;
+    *omega = om;
+    dp->al += target_speed * ctrl_dt; /* TargetCourse.advance(target_speed, dt) */
+    { int ind = (dp->plen < dp->al) ? 1 : 0; dp->spx = dp->cx[ind]; dp->spy = dp->cy[ind]; }
+}
+/* test hook: run the controller over a recorded pose sequence; out[n][5] = omega, vx, vy, setpoint x, setpoint y (after the call) */
+void orc_bd_controller_trace(const double *wp2, double lfc, double target_speed, double ctrl_dt, int n, const double *poses, double *out)
+{
+    bd_dp dp; dp.valid = 0;
+    double two[2][3] = {{wp2[0], wp2[1], 0}, {wp2[2], wp2[3], 0}};
+    for (int k = 0; k < n; k++) {
+        double x = poses[3 * k], y = poses[3 * k + 1], h = poses[3 * k + 2];
+        if (!dp.valid) bd_dp_init(&dp, x, y, two, lfc);
+        bd_dp_control(&dp, x, y, h, target_speed, ctrl_dt, &out[5 * k], &out[5 * k + 1], &out[5 * k + 2]);
+        out[5 * k + 3] = dp.spx; out[5 * k + 4] = dp.spy;
+    }
+}
+
 /* AreaClearingEnv.step after the movement (area_clearing.py:691-778): `steps` more sim steps, completion test, rewards */
 enum { AC_I_X = 0, AC_I_Y, AC_I_THETA, AC_I_TOTAL_WORK, AC_I_COLL_REWARD, AC_I_DIFF_REWARD, AC_I_BOX_REWARD, AC_I_BOX_COUNT, AC_I_MINISTEPS,
        AC_I_HIT, AC_I_SUBSTEPS, AC_I_ROBOT_DIST, AC_I_T, AC_I_NWP, AC_I_WORK, AC_I_PUSH_REWARD, AC_I_COUNT };
@@ -1204,37 +1277,8 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
     int x_pixel = (int)((double)B->local_px / 2 + x_movement * B->ppm);
     int y_pixel = (int)((double)B->local_px / 2 - y_movement * B->ppm);
     if (B->action_type == 1) { long idx = (long)action; y_pixel = (int)(idx / B->local_px); x_pixel = (int)(idx % B->local_px); }
-    /* PositionController.get_waypoints_to_spatial_action (position_controller.py:56-123) */
     double wpp[BD_MAXWP][2]; double wph[BD_MAXWP]; double move_sign;
-    {
-        double xm = -B->local_w / 2 + (double)x_pixel / B->ppm;
-        double ym = B->local_w / 2 - (double)y_pixel / B->ppm;
-        double sld = sqrt(xm * xm + ym * ym);
-        double turn = bp_atan2(-xm, ym);
-        double slh = bd_restrict_heading(ih + turn);
-        double sh_, ch_; bp_sincos(slh, &sh_, &ch_);
-        double tx = ix + sld * ch_, ty = iy + sld * sh_;
-        double dfx = tx - ix, dfy = ty - iy;
-        double ratio_x = 1, ratio_y = 1;
-        double sgx = (tx > 0) - (tx < 0), sgy = (ty > 0) - (ty < 0);
-        double bound_x = sgx * B->room_length / 2, bound_y = sgy * B->room_width / 2;
-        if (fabs(tx) > fabs(bound_x)) ratio_x = (bound_x - ix) / (tx - ix);
-        if (fabs(ty) > fabs(bound_y)) ratio_y = (bound_y - iy) / (ty - iy);
-        double ratio = ratio_y < ratio_x ? ratio_y : ratio_x; /* python min(a, b): b if b < a else a */
-        tx = ix + ratio * dfx; ty = iy + ratio * dfy;
-        nwp = bd_shortest_path(D, ix, iy, tx, ty, 1, wpp);
-        wph[0] = 0.0; /* None */
-        for (int i = 1; i < nwp; i++)
-            wph[i] = bd_restrict_heading(bp_atan2(wpp[i][1] - wpp[i - 1][1], wpp[i][0] - wpp[i - 1][0]));
-        double dte = bd_dist2(wpp[nwp - 2][0], wpp[nwp - 2][1], wpp[nwp - 1][0], wpp[nwp - 1][1]);
-        double signed_dist = dte - B->robot_radius;
-        move_sign = (signed_dist > 0) - (signed_dist < 0);
-        if (nwp > 2 && signed_dist < 0) {
-            wpp[nwp - 2][0] = wpp[nwp - 1][0]; wpp[nwp - 2][1] = wpp[nwp - 1][1];
-            wph[nwp - 2] = bd_restrict_heading(bp_atan2(wpp[nwp - 2][1] - wpp[nwp - 3][1], wpp[nwp - 2][0] - wpp[nwp - 3][0]));
-            move_sign = 1;
-        }
-    }
+    nwp = bd_plan(D, x_pixel, y_pixel, ix, iy, ih, wpp, wph, &move_sign);
     (void)move_sign; /* only feeds robot_new_position, which the reference computes and never uses */
     D->last_nwp = nwp;
     for (int i = 0; i < nwp && i < BD_MAXWP; i++) { D->last_wp[i][0] = wpp[i][0]; D->last_wp[i][1] = wpp[i][1]; D->last_wp[i][2] = wph[i]; }
@@ -1255,17 +1299,8 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
                 double two[2][3] = {{wpp[path0][0], wpp[path0][1], 0}, {wpp[path0 + 1][0], wpp[path0 + 1][1], 0}};
                 bd_dp_init(&dp, prevx, prevy, two, B->lfc);
             }
-            double theta_d = bp_atan2(dp.spy - prevy, dp.spx - prevx);
-            double theta_e = theta_d - prevh;
-            double se, ce; bp_sincos(theta_e, &se, &ce);
-            theta_e = bp_atan2(se, ce);
-            double omega = 1.0 * theta_e;
-            omega = omega / B->ctrl_dt;
-            double sy_, cy_; bp_sincos(prevh, &sy_, &cy_);
-            double gvx = cy_ * B->target_speed + -sy_ * 0.0, gvy = sy_ * B->target_speed + cy_ * 0.0;
-            /* get_setpoint -> TargetCourse.advance(target_speed, dt) */
-            dp.al += B->target_speed * B->ctrl_dt;
-            { int ind = (dp.plen < dp.al) ? 1 : 0; dp.spx = dp.cx[ind]; dp.spy = dp.cy[ind]; }
+            double omega, gvx, gvy;
+            bd_dp_control(&dp, prevx, prevy, prevh, B->target_speed, B->ctrl_dt, &omega, &gvx, &gvy);
             /* apply_controller */
             rb->w = omega * B->omega_scale;   /* omega*3 | omega/2 */
             if (!done_turning) rb->v = V((gvx * 0) * B->v_scale, (gvy * 0) * B->v_scale);
@@ -1440,6 +1475,8 @@ void orc_bd_get_maps(const bd_env *D, float *cspace, float *cspace_thin, int *ed
     if (overhead) memcpy(overhead, D->overhead, N * sizeof(float));
 }
 orc_env *orc_bd_physics(bd_env *D) { return D->E; }
+/* test hook: all-free configuration space (the straight-line branch of the position controller, tests/test_controller_golden.py) */
+void orc_bd_set_all_free(bd_env *D) { size_t N = (size_t)D->H * D->W; for (size_t i = 0; i < N; i++) { D->cspace[i] = 1.0f; D->cspace_thin[i] = 1.0f; D->edt_i[i] = (int)(i / D->W); D->edt_j[i] = (int)(i % D->W); } }
 int orc_bd_num_alive(const bd_env *D) { return D->nalive; }
 void orc_bd_get_alive(const bd_env *D, int *out) { for (int k = 0; k < D->nbox; k++) out[k] = D->box_alive[k]; }
 int orc_bd_last_waypoints(const bd_env *D, double *out)

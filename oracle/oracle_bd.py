@@ -54,6 +54,10 @@ def bdlib():
         L.orc_bd_last_waypoints.argtypes = [vp, vp]
         L.orc_bd_shortest_path.restype = ci
         L.orc_bd_shortest_path.argtypes = [vp, vp, vp, ci, vp]
+        L.orc_bd_controller_trace.argtypes = [vp, cd, cd, cd, ci, vp, vp]
+        L.orc_bd_plan.restype = ci
+        L.orc_bd_plan.argtypes = [vp, ci, ci, vp, vp, C.POINTER(cd)]
+        L.orc_bd_set_all_free.argtypes = [vp]
         L.orc_ac_set_geometry.argtypes = [vp, ci, vp, ci, vp, ci, vp, vp, vp]
         L.orc_atan2.restype = cd
         L.orc_atan2.argtypes = [cd, cd]
@@ -255,3 +259,30 @@ def atan2(y, x):
 
 def pymod(a, b):
     return bdlib().orc_pymod(float(a), float(b))
+
+
+def controller_trace(wp2, lfc, target_speed, dt, poses):
+    """DP controller over a pose sequence: rows = omega, vx, vy, setpoint x, setpoint y."""
+    L = bdlib()
+    w = np.ascontiguousarray(wp2, np.float64); ps = np.ascontiguousarray(poses, np.float64)
+    out = np.zeros((len(ps), 5), np.float64)
+    L.orc_bd_controller_trace(_p(w), float(lfc), float(target_speed), float(dt), len(ps), _p(ps), _p(out))
+    return out
+
+
+def plan_on_free_map(phys_params, bd_params, x_pixel, y_pixel, pose):
+    """get_waypoints_to_spatial_action on an all-free configuration space: (waypoints [n, 3], move_sign)."""
+    L = bdlib()
+    p = OrcParams()
+    for k, v in phys_params.items():
+        setattr(p, k, v)
+    b = BdParams()
+    for k, v in bd_params.items():
+        setattr(b, k, v)
+    h = L.orc_bd_create(C.byref(p), C.byref(b))
+    L.orc_bd_set_all_free(h)
+    out = np.zeros((64, 3), np.float64)
+    ms = C.c_double()
+    n = L.orc_bd_plan(h, int(x_pixel), int(y_pixel), _p(np.ascontiguousarray(pose, np.float64)), _p(out), C.byref(ms))
+    L.orc_bd_destroy(h)
+    return out[:n], ms.value
