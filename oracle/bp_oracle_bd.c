@@ -11,7 +11,9 @@
  * (tests/test_bd_cpu.py): scipy.ndimage.rotate(order=0, reshape=True), scipy.ndimage.distance_transform_edt(return_indices),
  * scipy.ndimage.binary_dilation (same operator as skimage's), numpy float32 arithmetic of the observation channels; and against
  * golden vectors produced by the reference's own classes (tests/golden/make_golden_controller.py, tests/test_controller_golden.py):
- * DP.ideal_control / TargetCourse set-point logic, PositionController.get_waypoints_to_spatial_action (straight-line branch).
+ * DP.ideal_control / TargetCourse set-point logic, PositionController.get_waypoints_to_spatial_action (straight-line branch); and
+ * by the reference's BoxDeliveryEnv / AreaClearingEnv classes themselves (tests/golden/make_golden_env_methods.py): episode
+ * generators, robot_state_channel, get_local_map, execute_robot_path in free space.
  *
  * Reference call sites restated (paths relative to /root/reference/benchpush):
  *   BoxDeliveryEnv.step / reset                 environments/box_delivery/box_delivery_env.py:578-830
@@ -1145,6 +1147,78 @@ void orc_bd_controller_trace(const double *wp2, double lfc, double target_speed,
     }
 }
 
+/* execute_robot_path (box_delivery_env.py:891-988 / area_clearing.py:800-901): returns the distance credited to the robot */
+static double bd_execute_path(bd_env *D, double wpp[][2], const double *wph, int nwp, double ix, double iy, double ih, long *total_sub_io)
+{
+    orc_env *E = D->E;
+    const bd_params *B = &D->B;
+    body_t *rb = &E->bodies[0];
+    double dts = B->ctrl_dt / B->steps;
+    double robot_distance = 0.0;
+    long total_sub = *total_sub_io;
+        double px = ix, py = iy, ph = ih;
+        int wi = 1, path0 = 0; /* path0: index of self.path[0] in the waypoint list (self.path = self.path[1:]) */
+        double pwx = wpp[0][0], pwy = wpp[0][1];
+        double prev_hd = 0.0; int done_turning = 0; long sim_steps = 0;
+        bd_dp dp; dp.valid = 0;
+        for (;;) {
+            double prevx = px, prevy = py, prevh = ph;
+            double hd = bd_heading_diff(ph, wph[wi]);
+            if (fabs(hd) > 15 * (M_PI / 180.0) && fabs(hd - prev_hd) > 0.001) { /* TURN_STEP_SIZE = np.radians(15) */ }
+            else done_turning = 1;
+            /* controller (box_delivery_env.py:867-885) */
+            if (!dp.valid) {
+                double two[2][3] = {{wpp[path0][0], wpp[path0][1], 0}, {wpp[path0 + 1][0], wpp[path0 + 1][1], 0}};
+                bd_dp_init(&dp, prevx, prevy, two, B->lfc);
+            }
+            double omega, gvx, gvy;
+            bd_dp_control(&dp, prevx, prevy, prevh, B->target_speed, B->ctrl_dt, &omega, &gvx, &gvy);
+            /* apply_controller */
+            rb->w = omega * B->omega_scale;   /* omega*3 | omega/2 */
+            if (!done_turning) rb->v = V((gvx * 0) * B->v_scale, (gvy * 0) * B->v_scale);
+            else rb->v = V(gvx * B->v_scale, gvy * B->v_scale);
+            space_step(E, dts);
+            total_sub++;
+            px = rb->p.x; py = rb->p.y; ph = bd_restrict_heading(rb->a);
+            if (orc_bd_trace && sim_steps >= orc_bd_trace_from && orc_bd_trace_n < orc_bd_trace_cap) {
+                double *o = orc_bd_trace + 4 * (size_t)orc_bd_trace_n++;
+                o[0] = px; o[1] = py; o[2] = rb->a; o[3] = (double)E->nactive;
+            }
+            prev_hd = hd;
+            if (bd_dist2(pwx, pwy, px, py) > 0.05) { /* MOVE_STEP_SIZE */
+                if (E->robot_hit) break;
+            }
+            if (bd_dist2(px, py, wpp[wi][0], wpp[wi][1]) < 0.6 && fabs(ph - wph[wi]) < 10 * (M_PI / 180.0)) {
+                robot_distance += bd_dist2(pwx, pwy, px, py);
+                if (wi == nwp - 1) break;
+                wi++;
+                pwx = wpp[wi - 1][0]; pwy = wpp[wi - 1][1];
+                done_turning = 0; dp.valid = 0; path0++;
+            }
+            sim_steps++;
+            if (sim_steps > B->step_limit) break;
+        }
+    *total_sub_io = total_sub;
+    return robot_distance;
+}
+/* test hook: run the path execution for given waypoints [n][3] = x, y, heading from the robot's current pose;
+ * out[6] = robot_distance, turn angle, x, y, angle, sim steps */
+void orc_bd_execute_path(bd_env *D, int n, const double *wp, double *out)
+{
+    orc_env *E = D->E;
+    body_t *rb = &E->bodies[0];
+    double wpp[BD_MAXWP][2], wph[BD_MAXWP];
+    for (int i = 0; i < n; i++) { wpp[i][0] = wp[3 * i]; wpp[i][1] = wp[3 * i + 1]; wph[i] = wp[3 * i + 2]; }
+    double ix = rb->p.x, iy = rb->p.y, ih = bd_restrict_heading(rb->a);
+    long sub = 0;
+    E->robot_hit = 0;
+    out[0] = bd_execute_path(D, wpp, wph, n, ix, iy, ih, &sub);
+    out[1] = bd_heading_diff(ih, bd_restrict_heading(rb->a));
+    out[2] = rb->p.x; out[3] = rb->p.y; out[4] = rb->a; out[5] = (double)sub;
+}
+/* test hook: get_local_map of an arbitrary padded-room image (float32 [H][W]) for a pose */
+void orc_bd_local_map(bd_env *D, const float *gmap, double x, double y, double h, float *out) { bd_local_map(D, gmap, x, y, h, out); }
+
 /* AreaClearingEnv.step after the movement (area_clearing.py:691-778): `steps` more sim steps, completion test, rewards */
 enum { AC_I_X = 0, AC_I_Y, AC_I_THETA, AC_I_TOTAL_WORK, AC_I_COLL_REWARD, AC_I_DIFF_REWARD, AC_I_BOX_REWARD, AC_I_BOX_COUNT, AC_I_MINISTEPS,
        AC_I_HIT, AC_I_SUBSTEPS, AC_I_ROBOT_DIST, AC_I_T, AC_I_NWP, AC_I_WORK, AC_I_PUSH_REWARD, AC_I_COUNT };
@@ -1282,51 +1356,7 @@ void orc_bd_step2(bd_env *D, double action, double action2, uint8_t *obs, double
     (void)move_sign; /* only feeds robot_new_position, which the reference computes and never uses */
     D->last_nwp = nwp;
     for (int i = 0; i < nwp && i < BD_MAXWP; i++) { D->last_wp[i][0] = wpp[i][0]; D->last_wp[i][1] = wpp[i][1]; D->last_wp[i][2] = wph[i]; }
-    /* execute_robot_path (box_delivery_env.py:891-988) */
-    {
-        double px = ix, py = iy, ph = ih;
-        int wi = 1, path0 = 0; /* path0: index of self.path[0] in the waypoint list (self.path = self.path[1:]) */
-        double pwx = wpp[0][0], pwy = wpp[0][1];
-        double prev_hd = 0.0; int done_turning = 0; long sim_steps = 0;
-        bd_dp dp; dp.valid = 0;
-        for (;;) {
-            double prevx = px, prevy = py, prevh = ph;
-            double hd = bd_heading_diff(ph, wph[wi]);
-            if (fabs(hd) > 15 * (M_PI / 180.0) && fabs(hd - prev_hd) > 0.001) { /* TURN_STEP_SIZE = np.radians(15) */ }
-            else done_turning = 1;
-            /* controller (box_delivery_env.py:867-885) */
-            if (!dp.valid) {
-                double two[2][3] = {{wpp[path0][0], wpp[path0][1], 0}, {wpp[path0 + 1][0], wpp[path0 + 1][1], 0}};
-                bd_dp_init(&dp, prevx, prevy, two, B->lfc);
-            }
-            double omega, gvx, gvy;
-            bd_dp_control(&dp, prevx, prevy, prevh, B->target_speed, B->ctrl_dt, &omega, &gvx, &gvy);
-            /* apply_controller */
-            rb->w = omega * B->omega_scale;   /* omega*3 | omega/2 */
-            if (!done_turning) rb->v = V((gvx * 0) * B->v_scale, (gvy * 0) * B->v_scale);
-            else rb->v = V(gvx * B->v_scale, gvy * B->v_scale);
-            space_step(E, dts);
-            total_sub++;
-            px = rb->p.x; py = rb->p.y; ph = bd_restrict_heading(rb->a);
-            if (orc_bd_trace && sim_steps >= orc_bd_trace_from && orc_bd_trace_n < orc_bd_trace_cap) {
-                double *o = orc_bd_trace + 4 * (size_t)orc_bd_trace_n++;
-                o[0] = px; o[1] = py; o[2] = rb->a; o[3] = (double)E->nactive;
-            }
-            prev_hd = hd;
-            if (bd_dist2(pwx, pwy, px, py) > 0.05) { /* MOVE_STEP_SIZE */
-                if (E->robot_hit) break;
-            }
-            if (bd_dist2(px, py, wpp[wi][0], wpp[wi][1]) < 0.6 && fabs(ph - wph[wi]) < 10 * (M_PI / 180.0)) {
-                robot_distance += bd_dist2(pwx, pwy, px, py);
-                if (wi == nwp - 1) break;
-                wi++;
-                pwx = wpp[wi - 1][0]; pwy = wpp[wi - 1][1];
-                done_turning = 0; dp.valid = 0; path0++;
-            }
-            sim_steps++;
-            if (sim_steps > B->step_limit) break;
-        }
-    }
+    robot_distance = bd_execute_path(D, wpp, wph, nwp, ix, iy, ih, &total_sub);
     } /* action_type */
     if (B->task == 1) { free(init_d); ac_finish_step(D, robot_distance, ih, total_sub, nwp, obs, reward, terminated, truncated, info); return; }
     /* step_simulation_until_still (box_delivery_env.py:990-1023) */

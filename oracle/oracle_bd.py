@@ -54,6 +54,8 @@ def bdlib():
         L.orc_bd_last_waypoints.argtypes = [vp, vp]
         L.orc_bd_shortest_path.restype = ci
         L.orc_bd_shortest_path.argtypes = [vp, vp, vp, ci, vp]
+        L.orc_bd_execute_path.argtypes = [vp, ci, vp, vp]
+        L.orc_bd_local_map.argtypes = [vp, vp, cd, cd, cd, vp]
         L.orc_bd_controller_trace.argtypes = [vp, cd, cd, cd, ci, vp, vp]
         L.orc_bd_plan.restype = ci
         L.orc_bd_plan.argtypes = [vp, ci, ci, vp, vp, C.POINTER(cd)]
@@ -156,6 +158,20 @@ class OracleBoxDelivery:
         out = np.zeros((64, 3), np.float64)
         n = self.L.orc_bd_last_waypoints(self.h, _p(out))
         return out[:n]
+
+    def execute_path(self, waypoints):
+        """Run execute_robot_path for waypoints [n, 3] from the current pose: dict(robot_distance, turn_angle, final, sim_steps)."""
+        w = np.ascontiguousarray(waypoints, np.float64)
+        out = np.zeros(6, np.float64)
+        self.L.orc_bd_execute_path(self.h, len(w), _p(w), _p(out))
+        return dict(robot_distance=out[0], turn_angle=out[1], final=out[2:5].copy(), sim_steps=int(out[5]))
+
+    def local_map(self, gmap, x, y, h):
+        g = np.ascontiguousarray(gmap, np.float32)
+        assert g.shape == (self.H, self.W)
+        out = np.zeros((self.lp, self.lp), np.float32)
+        self.L.orc_bd_local_map(self.h, _p(g), float(x), float(y), float(h), _p(out))
+        return out
 
     def shortest_path(self, s, t, check_straight=False):
         out = np.zeros((64, 2), np.float64)
