@@ -10,7 +10,8 @@
  * /root/reference and from this image) and for the skimage.draw.polygon / cv2.line raster
  * rules (unpinned third-party, absent).  The numpy-only pieces (poly_area, poly_centroid,
  * total_work_done, goal-distance crop, window arithmetic) ARE pinned by golden vectors
- * generated from the reference itself (tests/golden/).
+ * generated from the reference itself (tests/golden/), and the step loop's control / yaw / boundary / reward / termination logic is
+ * pinned against the reference's ShipIceEnv / MazeNAMO classes running on a stand-in space (tests/golden/make_golden_step_logic.py).
  *
  * What is restated, with the reference call sites it follows (paths relative to /root/reference):
  *   - ShipIceEnv.step / reset / reward / termination   benchpush/environments/ship_ice_nav/ship_ice_env.py:223-355
@@ -1737,6 +1738,8 @@ void orc_get_shape_states(const orc_env *E, double *out)
         o[0] = b->p.x; o[1] = b->p.y; o[2] = b->a; o[3] = b->v.x; o[4] = b->v.y; o[5] = b->w; o[6] = b->vb.x; o[7] = b->vb.y; o[8] = b->wb;
     }
 }
+/* test hook: replace the normalised goal map (tests/test_step_logic_golden.py injects the same map into the reference class) */
+void orc_maze_set_dist_map(orc_env *E, const double *m) { memcpy(E->dist_map, m, sizeof(double) * (size_t)E->map_h * E->map_w); }
 void orc_maze_maps(const orc_env *E, double *dist_norm, double *dist_raw, double *wall)
 {
     size_t n = (size_t)E->map_h * E->map_w;

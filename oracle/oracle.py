@@ -77,6 +77,7 @@ def lib():
         L.orc_maze_observe.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_get_shape_states.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_maze_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_maze_set_dist_map.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_nd_rotate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_observe_global.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.orc_bench.restype = C.c_double
@@ -298,6 +299,9 @@ class OracleMaze:
         info = np.zeros(len(MAZE_INFO_KEYS), np.float64)
         self.L.orc_maze_step(self.h, float(action), _p(obs) if observe else None, C.byref(r), C.byref(t), _p(info))
         return obs, r.value, bool(t.value), dict(zip(MAZE_INFO_KEYS, info.tolist()))
+
+    def set_dist_map(self, m):
+        self.L.orc_maze_set_dist_map(self.h, _p(np.ascontiguousarray(m, np.float64)))
 
     def shape_states(self):
         out = np.zeros((self.ns, 9), np.float64)
