@@ -1505,6 +1505,17 @@ void orc_bd_get_maps(const bd_env *D, float *cspace, float *cspace_thin, int *ed
     if (overhead) memcpy(overhead, D->overhead, N * sizeof(float));
 }
 orc_env *orc_bd_physics(bd_env *D) { return D->E; }
+/* current world vertices of every shape (body.local_to_world of the hull vertices): out[ns][4][2], counts[ns] */
+void orc_bd_world_verts(bd_env *D, double *out, int *counts)
+{
+    orc_env *E = D->E;
+    for (int s2 = 0; s2 < E->ns; s2++) {
+        const shape_t *sh = &E->shapes[s2];
+        vec wv[ORC_MAXV]; bd_box_world_verts(E, sh, wv);
+        counts[s2] = sh->n;
+        for (int i = 0; i < sh->n && i < 4; i++) { out[(size_t)s2 * 8 + 2 * i] = wv[i].x; out[(size_t)s2 * 8 + 2 * i + 1] = wv[i].y; }
+    }
+}
 /* test hook: all-free configuration space (the straight-line branch of the position controller, tests/test_controller_golden.py) */
 void orc_bd_set_all_free(bd_env *D) { size_t N = (size_t)D->H * D->W; for (size_t i = 0; i < N; i++) { D->cspace[i] = 1.0f; D->cspace_thin[i] = 1.0f; D->edt_i[i] = (int)(i / D->W); D->edt_j[i] = (int)(i % D->W); } }
 int orc_bd_num_alive(const bd_env *D) { return D->nalive; }

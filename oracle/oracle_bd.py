@@ -54,6 +54,7 @@ def bdlib():
         L.orc_bd_last_waypoints.argtypes = [vp, vp]
         L.orc_bd_shortest_path.restype = ci
         L.orc_bd_shortest_path.argtypes = [vp, vp, vp, ci, vp]
+        L.orc_bd_world_verts.argtypes = [vp, vp, vp]
         L.orc_bd_execute_path.argtypes = [vp, ci, vp, vp]
         L.orc_bd_local_map.argtypes = [vp, vp, cd, cd, cd, vp]
         L.orc_bd_controller_trace.argtypes = [vp, cd, cd, cd, ci, vp, vp]
@@ -158,6 +159,24 @@ class OracleBoxDelivery:
         out = np.zeros((64, 3), np.float64)
         n = self.L.orc_bd_last_waypoints(self.h, _p(out))
         return out[:n]
+
+    def plan(self, spatial_action):
+        """get_waypoints_to_spatial_action for a local-map pixel index from the robot's current pose: (waypoints [n, 3], move_sign)."""
+        st = self.shape_states()[0]
+        pose = np.array([st[0], st[1], float(np.mod(st[2] + np.pi, 2 * np.pi) - np.pi)], np.float64)
+        pose[2] = bdlib().orc_pymod(st[2] + np.pi, 2 * np.pi) - np.pi
+        row, col = divmod(int(spatial_action), self.lp)
+        out = np.zeros((64, 3), np.float64)
+        ms = C.c_double()
+        n = self.L.orc_bd_plan(self.h, col, row, _p(pose), _p(out), C.byref(ms))
+        return out[:n], ms.value
+
+    def world_verts(self):
+        """Current world vertices of every shape: list of [n, 2] arrays (robot main, 4 wheels, bumper, boxes, statics)."""
+        out = np.zeros((self.ns, 4, 2), np.float64)
+        cnt = np.zeros(self.ns, np.int32)
+        self.L.orc_bd_world_verts(self.h, _p(out), _p(cnt))
+        return [out[i, : cnt[i]].copy() for i in range(self.ns)]
 
     def execute_path(self, waypoints):
         """Run execute_robot_path for waypoints [n, 3] from the current pose: dict(robot_distance, turn_angle, final, sim_steps)."""
