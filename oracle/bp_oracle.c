@@ -1738,6 +1738,10 @@ void orc_get_shape_states(const orc_env *E, double *out)
         o[0] = b->p.x; o[1] = b->p.y; o[2] = b->a; o[3] = b->v.x; o[4] = b->v.y; o[5] = b->w; o[6] = b->vb.x; o[7] = b->vb.y; o[8] = b->wb;
     }
 }
+/* test hooks: the restated skimage.draw.polygon / cv2.line rasterisers on a caller-owned image (tests/golden/make_golden_obs_pipeline.py
+ * plugs them into the reference's OccupancyGrid in place of the absent libraries) */
+void orc_draw_polygon(int n, const double *r, const double *c, int H, int W, double *img, double val) { draw_polygon(n, r, c, H, W, 1, img, val); }
+void orc_cv_line(double *img, int H, int W, long x1, long y1, long x2, long y2, double val) { cv_line(img, H, W, x1, y1, x2, y2, val); }
 /* test hook: replace the normalised goal map (tests/test_step_logic_golden.py injects the same map into the reference class) */
 void orc_maze_set_dist_map(orc_env *E, const double *m) { memcpy(E->dist_map, m, sizeof(double) * (size_t)E->map_h * E->map_w); }
 void orc_maze_maps(const orc_env *E, double *dist_norm, double *dist_raw, double *wall)

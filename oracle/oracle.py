@@ -78,6 +78,8 @@ def lib():
         L.orc_get_shape_states.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_maze_maps.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_maze_set_dist_map.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_draw_polygon.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double]
+        L.orc_cv_line.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_double]
         L.orc_nd_rotate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_observe_global.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
         L.orc_bench.restype = C.c_double
@@ -326,3 +328,21 @@ def nd_rotate(img, c, s, cval):
     out = np.zeros_like(img)
     lib().orc_nd_rotate(_p(img), img.shape[0], float(c), float(s), float(cval), _p(out))
     return out
+
+
+def draw_polygon(r, c, shape=None):
+    """Restated skimage.draw.polygon: (rr, cc) of the pixels inside the polygon with vertex rows r / columns c."""
+    r = np.ascontiguousarray(r, np.float64); c = np.ascontiguousarray(c, np.float64)
+    if shape is None:
+        shape = (max(int(np.ceil(r.max())) + 2, 1), max(int(np.ceil(c.max())) + 2, 1))
+    img = np.zeros((int(shape[0]), int(shape[1])), np.float64)
+    lib().orc_draw_polygon(len(r), _p(r), _p(c), img.shape[0], img.shape[1], _p(img), 1.0)
+    rr, cc = np.nonzero(img)
+    return rr, cc
+
+
+def cv_line(img, pt1, pt2, color):
+    """Restated cv2.line (thickness 1, 8-connected) on a float64 image, in place."""
+    assert img.dtype == np.float64 and img.flags["C_CONTIGUOUS"]
+    lib().orc_cv_line(_p(img), img.shape[0], img.shape[1], int(pt1[0]), int(pt1[1]), int(pt2[0]), int(pt2[1]), float(color))
+    return img
