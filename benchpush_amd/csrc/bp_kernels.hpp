@@ -216,6 +216,13 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
                                          : (D.order != nullptr ? D.order[blockIdx.x] : (int)blockIdx.x);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = lane_id();
+#if 1
+    // heaviest-first dispatch: the first workgroups carry the envs that set the launch time -> issue priority over their SIMD mates
+    if (mode == MODE_STEP && D.order != nullptr) {
+        if (blockIdx.x < gridDim.x / 4) __builtin_amdgcn_s_setprio(3);
+        else if (blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     if (mode == MODE_RESET && !tmpl && mask != nullptr && mask[env] == 0) return;
     const int nbcap = P.nbcap;
 

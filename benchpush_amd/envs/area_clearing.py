@@ -16,7 +16,7 @@ from .. import _lib
 from ..area_clearing_scenario import area_clearing_params, area_clearing_physics_params, env_layout, generate_trials, goal_points
 from ..config import default_cfg, merge_user_cfg
 from ..gym_shim import Env, spaces
-from .box_delivery import BatchedBoxDeliveryEnv
+from .box_delivery import BatchedBoxDeliveryEnv, low_dim_observation
 
 __all__ = ["BatchedAreaClearingEnv", "AreaClearingEnv", "AC_INFO_KEYS"]
 AC_INFO_KEYS = ["x", "y", "theta", "total_work", "collision_reward", "diff_reward", "box_completed_reward", "box_count", "ministeps",
@@ -29,8 +29,6 @@ def _ac_cfg(cfg):
         raise FileNotFoundError(f"Environment config {c.env} not found")   # area_clearing.py:105-108
     if c.agent.action_type not in ("heading", "position", "velocity"):
         raise ValueError("agent.action_type must be heading, position or velocity")
-    if c.low_dim_state:
-        raise NotImplementedError("low-dimensional observations are outside the accelerated path")
     return c
 
 
@@ -102,7 +100,12 @@ class AreaClearingEnv(Env):
         else:
             self.action_space = spaces.Box(low=-1, high=1, shape=(1,), dtype=np.float32)
         self.observation_shape = self._b.obs_shape
-        self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
+        self.low_dim_state = self.cfg.low_dim_state
+        if self.low_dim_state:                            # area_clearing.py:212-215
+            self.fixed_trial_idx = self.cfg.fixed_trial_idx
+            self.observation_space = spaces.Box(low=-10, high=30, shape=(self.cfg.num_obstacles * 2,), dtype=np.float32)
+        else:
+            self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
         self.episode_idx = None
         self.box_clearance_statuses = [False] * self.num_box
 
@@ -126,14 +129,13 @@ class AreaClearingEnv(Env):
         return [bool(sep(bd, np.asarray(b)) or sep(np.asarray(b), bd)) for b in boxes]
 
     def _low_dim(self, boxes):
-        out = np.zeros(len(boxes) * 2)
-        for i, b in enumerate(boxes):
-            d1 = sum(b[k][0] * b[k - 1][1] for k in range(len(b))); d2 = sum(b[k][1] * b[k - 1][0] for k in range(len(b)))
-            area = 0.5 * abs(d1 - d2)
-            cx = sum((b[k][0] + b[k - 1][0]) * (b[k][0] * b[k - 1][1] - b[k - 1][0] * b[k][1]) for k in range(len(b))) / (6 * area)
-            cy = sum((b[k][1] + b[k - 1][1]) * (b[k][0] * b[k - 1][1] - b[k - 1][0] * b[k][1]) for k in range(len(b))) / (6 * area)
-            out[2 * i], out[2 * i + 1] = abs(cx), abs(cy)
-        return out
+        return low_dim_observation(boxes)
+
+    def _result(self, info):
+        """low_dim_state: the vector is the observation; otherwise it rides along in info (area_clearing.py:599-606,766-772)."""
+        if self.low_dim_state:
+            return info.pop("low_level_observation")
+        return self._b.obs[0].cpu().numpy()
 
     def reset(self, seed=None, options=None):
         self.episode_idx = 0 if self.episode_idx is None else self.episode_idx + 1
@@ -144,7 +146,7 @@ class AreaClearingEnv(Env):
         info = {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)), "total_work": 0, "obs": boxes, "box_count": 0,
                 "boundary": self.boundary_vertices, "walls": self.walls, "static_obstacles": self.static_obstacles,
                 "goal_positions": self.goal_points, "low_level_observation": self._low_dim(boxes)}
-        return self._b.obs[0].cpu().numpy(), info
+        return self._result(info), info
 
     def step(self, action):
         a = torch.tensor(np.asarray(action, dtype=np.float64).reshape(-1)[: self._b.action_dim], dtype=torch.float64)
@@ -156,7 +158,7 @@ class AreaClearingEnv(Env):
                 "collision reward": float(it[4]), "diff_reward": float(it[5]), "box_completed_reward": float(it[6]), "obs": boxes,
                 "box_completed_statuses": self.box_clearance_statuses, "box_count": int(it[7]), "ministeps": float(it[8]),
                 "low_level_observation": self._low_dim(boxes)}
-        return (self._b.obs[0].cpu().numpy(), float(self._b.reward[0].item()), bool(self._b.terminated[0].item()),
+        return (self._result(info), float(self._b.reward[0].item()), bool(self._b.terminated[0].item()),
                 bool(self._b.truncated[0].item()), info)
 
     def render(self, mode="human", close=False):

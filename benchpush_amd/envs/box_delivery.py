@@ -18,6 +18,7 @@ from .. import _lib
 from ..box_delivery_scenario import box_delivery_params, box_delivery_physics_params, generate_trials
 from ..config import default_cfg, merge_user_cfg
 from ..gym_shim import Env, spaces
+from ..scenario import poly_centroid
 from .ship_ice import BatchedShipIceEnv, _ptr
 
 __all__ = ["BatchedBoxDeliveryEnv", "BoxDeliveryEnv", "BD_INFO_KEYS"]
@@ -28,8 +29,8 @@ def _bd_cfg(cfg):
     c = merge_user_cfg(default_cfg("box_delivery"), cfg)
     if c.agent.action_type not in ("heading", "position", "velocity"):
         raise ValueError("agent.action_type must be heading, position or velocity")
-    if c.teleop_mode or c.low_dim_state:
-        raise NotImplementedError("teleop / low-dimensional modes are outside the accelerated path")
+    if c.teleop_mode:
+        raise NotImplementedError("teleop mode (keyboard / pygame) is outside the accelerated path")
     return c
 
 
@@ -107,6 +108,14 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
         return alive, wp, nwp
 
 
+def low_dim_observation(polys):
+    """generate_observation_low_dim (box_delivery_env.py:1025-1037, area_clearing.py:908-919): |centroid| of each polygon, flattened."""
+    out = np.zeros(len(polys) * 2)
+    for i, p in enumerate(polys):
+        out[2 * i: 2 * i + 2] = poly_centroid(p)
+    return out
+
+
 class BoxDeliveryEnv(Env):
     """Reference-shaped single environment (E = 1): reset()/step() returns and info keys of box_delivery_env.py:578-830."""
 
@@ -125,7 +134,12 @@ class BoxDeliveryEnv(Env):
         else:
             self.action_space = spaces.Box(low=0, high=lp * lp, dtype=np.float32)
         self.observation_shape = self._b.obs_shape
-        self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
+        self.low_dim_state = self.cfg.low_dim_state
+        if self.low_dim_state:                            # box_delivery_env.py:166-169
+            self.fixed_trial_idx = self.cfg.fixed_trial_idx
+            self.observation_space = spaces.Box(low=-10, high=30, shape=(self.num_boxes * 2,), dtype=np.float32)
+        else:
+            self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
         self.episode_idx = None
         self.t = 0
         self.box_clearance_statuses = [False] * self.num_boxes
@@ -150,7 +164,10 @@ class BoxDeliveryEnv(Env):
         self._b.reset()
         self.t = 0
         boxes, alive = self._boxes()
-        return self._b.obs[0].cpu().numpy(), self._info(self._b.info[0].cpu().numpy(), boxes, alive)
+        # low_dim_state: reset() returns <|centroid| of every box> (box_delivery_env.py:606-607,1025-1037); step() always returns the
+        # image observation (box_delivery_env.py:807)
+        obs = low_dim_observation(boxes) if self.low_dim_state else self._b.obs[0].cpu().numpy()
+        return obs, self._info(self._b.info[0].cpu().numpy(), boxes, alive)
 
     def step(self, action):
         self.t += 1

@@ -18,6 +18,7 @@ from .. import _lib
 from ..config import default_cfg, maze_physics_params, maze_walls, merge_user_cfg
 from ..gym_shim import Env, spaces
 from ..maze_scenario import generate_layout
+from ..scenario import poly_centroid
 from .ship_ice import BatchedShipIceEnv, _ptr
 
 __all__ = ["BatchedMazeEnv", "MazeNAMO", "default_layouts"]
@@ -109,10 +110,13 @@ class MazeNAMO(Env):
         self.min_linear_speed = 0.0
         self.max_yaw_rate_step = (np.pi / 2) / 15
         self.action_space = spaces.Box(low=-1, high=1, dtype=np.float64)
-        if self.low_dim_state:
-            raise NotImplementedError("low-dimensional maze observations are outside the accelerated path")
         self.observation_shape = self._b.obs_shape
-        self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
+        if self.low_dim_state:  # maze_NAMO_env.py:106-112
+            self.fixed_trial_idx = self.cfg.fixed_trial_idx
+            n = (self.cfg.num_obstacles + 1) * 2 if self.cfg.randomize_obstacles else 8
+            self.observation_space = spaces.Box(low=-10, high=30, shape=(n,), dtype=np.float64)
+        else:
+            self.observation_space = spaces.Box(low=0, high=255, shape=self.observation_shape, dtype=np.uint8)
         self.goal = self._b.goal
         self.total_work = [0, []]
         self.wall_collision = False
@@ -126,6 +130,18 @@ class MazeNAMO(Env):
         nbox = len(self._b.layouts[0]["centres"])
         return [verts[i, : cnt[i]].copy() for i in range(n0, n0 + nbox)]
 
+    def _low_dim(self, obstacles, it):
+        """generate_observation_low_dim (maze_NAMO_env.py:488-504): <robot x, y, |centroid| of obstacles 1..n-1 at pairs 1..n-1>; like
+        the reference's loop, obstacle 0 is never written and the last pair stays zero."""
+        out = np.zeros((len(obstacles) + 1) * 2)
+        out[0], out[1] = float(it[0]), float(it[1])
+        for i in range(1, len(obstacles)):
+            out[2 * i: 2 * i + 2] = poly_centroid(obstacles[i])
+        return out
+
+    def _observation(self, obstacles, it):
+        return self._low_dim(obstacles, it) if self.low_dim_state else self._b.obs[0].cpu().numpy()
+
     def reset(self, seed=None, options=None):
         self.episode_idx = 0 if self.episode_idx is None else self.episode_idx + 1
         self._b.reset()
@@ -137,7 +153,7 @@ class MazeNAMO(Env):
         self.obstacles = obstacles
         info = {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)), "total_work": self.total_work[0],
                 "obs": obstacles, "box_count": 0, "goal_dt": self._goal_dt, "m_to_pix_scale": self.cfg.occ.m_to_pix_scale}
-        return self._b.obs[0].cpu().numpy(), info
+        return self._observation(obstacles, it), info
 
     def step(self, action):
         self.t += 1
@@ -154,7 +170,7 @@ class MazeNAMO(Env):
         info = {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)), "total_work": self.total_work[0],
                 "collision reward": float(it[5]), "scaled collision reward": float(it[6]), "dist increment reward": float(it[7]),
                 "trial_success": bool(it[8]), "obs": obstacles}
-        return self._b.obs[0].cpu().numpy(), reward, terminated, False, info
+        return self._observation(obstacles, it), reward, terminated, False, info
 
     def update_path(self, new_path, scatter=False):
         self.path = new_path
