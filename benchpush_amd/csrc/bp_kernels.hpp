@@ -632,6 +632,10 @@ __global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const Dev
 // ------------------------------------------------------------------------------------------------------------
 #define OBS_THREADS 256
 #define OBS_MAXCAND 96      // floes whose pixel AABB meets the 150x150 window (6 m x 6 m; typically 15-40)
+#ifndef OBS_SNAP_Y
+#define OBS_SNAP_Y 1e-6     // a vertex this close to a raster row sends the row to the per-pixel test
+#define OBS_SNAP_X 1e-6     // a crossing this close to a pixel centre is decided by the exact test on that pixel
+#endif
 
 // skimage._shared.geometry.point_in_polygon restated (third-party, unpinned): non-zero = inside / edge / vertex.
 // The crossing tests `(x0*y1 - x1*y0) / (y1 - y0) > 0` (`< 0`) are evaluated as sign tests: for the finite,
@@ -726,11 +730,38 @@ __device__ __forceinline__ bool on_line(const LineSpec &s, long long x, long lon
     long long t, m, dmaj, dmin;
     if (!s.vert) { t = ax; m = ay; dmaj = s.dx; dmin = s.dy; }
     else { t = ay; m = ax; dmaj = s.dy; dmin = s.dx; }
-    if (t < 0 || t > dmaj) return false;
+    if (t < 0 || t > dmaj || m < 0 || m > dmin) return false; // m_t lies in [0, dmin]
     if (dmaj == 0) return m == 0;
     const long long mt = (2 * dmin * t + dmaj - 1) / (2 * dmaj);
     return m == mt;
 }
+
+// Sequential-sum restatements of poly_area / poly_centroid on split coordinate arrays (same operation order as the *_seq forms)
+__device__ __forceinline__ d2 poly_centroid_xy(const double *x, const double *y, int n)
+{
+    double d1 = 0.0, d2_ = 0.0;
+    for (int i = 0; i < n; i++) {
+        const int p = (i - 1 + n) % n;
+        d1 += x[i] * y[p];
+        d2_ += y[i] * x[p];
+    }
+    const double A = 0.5 * __builtin_fabs(d1 - d2_);
+    double sx = 0.0, sy = 0.0;
+    for (int i = 0; i < n; i++) {
+        const int p = (i - 1 + n) % n;
+        const double u = x[i] * y[p] - x[p] * y[i];
+        sx += (x[i] + x[p]) * u;
+        sy += (y[i] + y[p]) * u;
+    }
+    const double f = 1.0 / (6.0 * A);
+    return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
+}
+
+// Flag bits of the LDS window image
+#define OBS_F_OCC 1u
+#define OBS_F_SHIP 2u
+#define OBS_F_LINE 4u
+#define OBS_F_HEAD 8u
 
 __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                          unsigned char *__restrict__ obs)
@@ -747,18 +778,20 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
     const int npix = LH * LW;
 
     extern __shared__ double2 obs_smem[];
-    // LDS: occupancy image [npix] u8 | goal-distance row table [LH] u8 | candidate polygons (raster coordinates)
-    unsigned char *s_occ = (unsigned char *)obs_smem;
-    unsigned char *s_edt = s_occ + ((npix + 15) & ~15);
+    // LDS: window image of flag bits [npix] u8 | goal-distance row table [LH] u8 | candidate polygons (world, then raster coordinates)
+    unsigned char *s_img = (unsigned char *)obs_smem;
+    unsigned char *s_edt = s_img + ((npix + 15) & ~15);
     double *s_px = (double *)(s_edt + ((LH + 15) & ~15));   // [OBS_MAXCAND][BP_MAXV]
     double *s_py = s_px + OBS_MAXCAND * BP_MAXV;
-    __shared__ int s_ncand;
-    __shared__ int s_bbx[OBS_MAXCAND][4]; // window-clipped pixel box: r0, r1, c0, c1 (global raster coordinates)
+    __shared__ int s_npass;
+    __shared__ unsigned short s_list[OBS_MAXCAND];
+    __shared__ int s_bbx[OBS_MAXCAND][4]; // window-clipped pixel box: r0, r1, c0, c1 (global raster coordinates); r1 < r0: not a candidate
     __shared__ unsigned char s_cn[OBS_MAXCAND];
+    __shared__ int s_roff[OBS_MAXCAND + 1]; // first (candidate, row) item of each candidate
     __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
     __shared__ int s_fcnt, s_fbb[4];
-    if (tid == 0) s_ncand = 0;
-    for (int w = tid; w < (npix + 3) / 4; w += OBS_THREADS) ((unsigned *)s_occ)[w] = 0u;
+    if (tid == 0) s_npass = 0;
+    for (int w = tid; w < (npix + 3) / 4; w += OBS_THREADS) ((unsigned *)s_img)[w] = 0u;
     __syncthreads();
 
     const d2 sp = D.pxy[eb];
@@ -770,30 +803,14 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
     const int gi0 = (int)((double)(0 + wy) - ((double)LH / 2)), gj0 = (int)((double)(0 + wx) - ((double)LW / 2));
     const int gi1 = gi0 + LH - 1, gj1 = gj0 + LW - 1;
     const int bh = (int)(P.map_h * P.m_to_pix), bw = (int)(P.map_w * P.m_to_pix);
-    // ---- candidate floes: |centroid| range culling (occupancy_map.py:44-49) + pixel box vs window ----
+    // ---- 1. conservative pre-test on the body AABBs (min/max of the same world vertices, grown by the shape radius): a floe whose
+    //         AABB, grown by a pixel, misses the window cannot pass the exact pixel-box test of step 3 -> its vertices are not read
     for (int s = 1 + tid; s < nb; s += OBS_THREADS) {
-        const int n = nv[s];
-        const d2 *v = wv + (size_t)s * BP_MAXV;
-        const d2 c = poly_centroid_seq(v, n);
-        const double cx = __builtin_fabs(c.x), cy = __builtin_fabs(c.y);
-        if (__builtin_fabs(sp.x - cx) > P.obs_range || __builtin_fabs(sp.y - cy) > P.obs_range) continue;
-        double rmin = v[0].y * P.m_to_pix, rmax = rmin, cmin = v[0].x * P.m_to_pix, cmax = cmin;
-        for (int i = 1; i < n; i++) {
-            const double r = v[i].y * P.m_to_pix, cc = v[i].x * P.m_to_pix;
-            rmin = fmin(rmin, r); rmax = fmax(rmax, r); cmin = fmin(cmin, cc); cmax = fmax(cmax, cc);
-        }
-        long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
-        long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
-        if (maxr > bh - 1) maxr = bh - 1;
-        if (maxc > bw - 1) maxc = bw - 1;
-        if (maxr < gi0 || minr > gi1 || maxc < gj0 || minc > gj1 || maxr < minr || maxc < minc) continue;
-        const int slot = atomicAdd(&s_ncand, 1);
-        if (slot < OBS_MAXCAND) {
-            s_bbx[slot][0] = (int)max(minr, (long long)gi0); s_bbx[slot][1] = (int)min(maxr, (long long)gi1);
-            s_bbx[slot][2] = (int)max(minc, (long long)gj0); s_bbx[slot][3] = (int)min(maxc, (long long)gj1);
-            s_cn[slot] = (unsigned char)n;
-            for (int i = 0; i < n; i++) { s_px[slot * BP_MAXV + i] = v[i].x * P.m_to_pix; s_py[slot * BP_MAXV + i] = v[i].y * P.m_to_pix; }
-        }
+        const double4 b = D.bb[eb + s];
+        if (__builtin_floor(b.y * P.m_to_pix) - 1.0 > (double)gi1 || __builtin_ceil(b.w * P.m_to_pix) + 1.0 < (double)gi0 ||
+            __builtin_floor(b.x * P.m_to_pix) - 1.0 > (double)gj1 || __builtin_ceil(b.z * P.m_to_pix) + 1.0 < (double)gj0) continue;
+        const int slot = atomicAdd(&s_npass, 1);
+        if (slot < OBS_MAXCAND) s_list[slot] = (unsigned short)s;
     }
     // ---- ship footprint polygon in grid coordinates (vertices outside the grid are dropped, occupancy_map.py:318-325)
     LineSpec line;
@@ -838,49 +855,150 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
         s_edt[li] = e;
     }
     __syncthreads();
-    const int ncand = min(s_ncand, OBS_MAXCAND);
-    if (tid == 0 && s_ncand > OBS_MAXCAND) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
-    // ---- occupancy: skimage.draw.polygon of each candidate over its (window-clipped) pixel box, into LDS ----
-    for (int k = 0; k < ncand; k++) {
-        const int r0 = s_bbx[k][0], r1 = s_bbx[k][1], c0 = s_bbx[k][2], c1 = s_bbx[k][3];
-        const int wbox = c1 - c0 + 1, npx = (r1 - r0 + 1) * wbox;
+    const int ncand = min(s_npass, OBS_MAXCAND);
+    if (tid == 0 && s_npass > OBS_MAXCAND) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+    // ---- 2. world vertices of the pre-test survivors -> LDS, one (floe, vertex) item per thread ----
+    for (int idx = tid; idx < ncand * BP_MAXV; idx += OBS_THREADS) {
+        const int k = idx / BP_MAXV, q = idx - k * BP_MAXV;
+        const int s = s_list[k];
+        const int n = nv[s];
+        if (q == 0) s_cn[k] = (unsigned char)n;
+        if (q < n) { const d2 v = wv[(size_t)s * BP_MAXV + q]; s_px[idx] = v.x; s_py[idx] = v.y; }
+    }
+    __syncthreads();
+    // ---- 3. exact candidate test, one floe per thread: |centroid| range culling (occupancy_map.py:44-49) + pixel box vs window;
+    //         the vertices are converted to raster coordinates in place ----
+    if (tid < ncand) {
+        const int k = tid;
+        const int n = s_cn[k];
+        double *xp = s_px + k * BP_MAXV, *yp = s_py + k * BP_MAXV;
+        bool keep = true;
+        const d2 c = poly_centroid_xy(xp, yp, n);
+        const double cx = __builtin_fabs(c.x), cy = __builtin_fabs(c.y);
+        if (__builtin_fabs(sp.x - cx) > P.obs_range || __builtin_fabs(sp.y - cy) > P.obs_range) keep = false;
+        double rmin = BP_INF, rmax = -BP_INF, cmin = BP_INF, cmax = -BP_INF;
+        for (int i = 0; i < n; i++) {
+            const double r = yp[i] * P.m_to_pix, cc = xp[i] * P.m_to_pix;
+            xp[i] = cc; yp[i] = r;
+            rmin = fmin(rmin, r); rmax = fmax(rmax, r); cmin = fmin(cmin, cc); cmax = fmax(cmax, cc);
+        }
+        long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
+        long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
+        if (maxr > bh - 1) maxr = bh - 1;
+        if (maxc > bw - 1) maxc = bw - 1;
+        if (maxr < gi0 || minr > gi1 || maxc < gj0 || minc > gj1 || maxr < minr || maxc < minc) keep = false;
+        if (keep) {
+            s_bbx[k][0] = (int)max(minr, (long long)gi0); s_bbx[k][1] = (int)min(maxr, (long long)gi1);
+            s_bbx[k][2] = (int)max(minc, (long long)gj0); s_bbx[k][3] = (int)min(maxc, (long long)gj1);
+        } else { s_bbx[k][0] = 0; s_bbx[k][1] = -1; s_bbx[k][2] = 0; s_bbx[k][3] = -1; }
+    }
+    __syncthreads();
+    // ---- 4. occupancy: skimage.draw.polygon of each candidate, one (candidate, raster row) item per thread.
+    // The hulls are convex, so a row's inside pixels form one span between the two edges that straddle the row.  With every
+    // vertex at least OBS_SNAP_Y away from the row, point_in_polygon's crossing tests have the sign of (X - x) * dy for the
+    // crossing abscissa X of an edge (error ~1e-13 px), so pixels strictly between the two crossings are inside and the others
+    // outside; a crossing within OBS_SNAP_X of a pixel centre is decided by the exact test on that pixel.  Rows that have a
+    // vertex within OBS_SNAP_Y (vertex / edge rules of point_in_polygon) or not exactly two crossings fall back to the exact
+    // test on every pixel of the row.  Result: identical to testing every pixel of the box (the oracle does that).
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < ncand; k++) { s_roff[k] = acc; acc += max(0, s_bbx[k][1] - s_bbx[k][0] + 1); }
+        s_roff[ncand] = acc;
+    }
+    __syncthreads();
+    const int nitems = s_roff[ncand];
+    for (int it = tid; it < nitems; it += OBS_THREADS) {
+        int k = 0;
+        {   // last k with s_roff[k] <= it (candidates without rows repeat their successor's offset and are skipped by "last")
+            int lo = 0, hi = ncand - 1;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_roff[mid] <= it) lo = mid; else hi = mid - 1; }
+            k = lo;
+        }
+        const int gi = s_bbx[k][0] + (it - s_roff[k]);
+        if (gi < 0 || gi >= Hg || gi > s_bbx[k][1]) continue;
+        const int c0 = max(s_bbx[k][2], 0), c1 = min(s_bbx[k][3], Wg - 1);
         const int n = s_cn[k];
         const double *xp = s_px + k * BP_MAXV, *yp = s_py + k * BP_MAXV;
+        const double y = (double)gi;
+        bool slow = false;
+        int ncross = 0;
+        double xa = 0.0, xb = 0.0;
+        double x1 = xp[n - 1], y1 = yp[n - 1] - y;
+        for (int i = 0; i < n; i++) {
+            const double x0 = xp[i], y0 = yp[i] - y;
+            if (__builtin_fabs(y0) < OBS_SNAP_Y) slow = true;
+            if ((y0 > 0) != (y1 > 0)) {
+                const double X = x0 - y0 * ((x1 - x0) / (y1 - y0));
+                if (ncross == 0) xa = X; else xb = X;
+                ncross++;
+            }
+            x1 = x0; y1 = y0;
+        }
+        unsigned char *row = s_img + (gi - gi0) * LW - gj0;
+        if (slow || (ncross != 0 && ncross != 2)) {
+            for (int gj = c0; gj <= c1; gj++) if (pip_arrays(xp, yp, n, (double)gj, y)) row[gj] = OBS_F_OCC;
+            continue;
+        }
+        if (ncross == 0) continue;
+        const double xl = fmin(xa, xb), xr = fmax(xa, xb);
+        int first, last;
+        {
+            const double rl = __builtin_rint(xl);
+            if (__builtin_fabs(xl - rl) < OBS_SNAP_X) first = pip_arrays(xp, yp, n, rl, y) ? (int)rl : (int)rl + 1;
+            else first = (int)__builtin_ceil(xl);
+            const double rr = __builtin_rint(xr);
+            if (__builtin_fabs(xr - rr) < OBS_SNAP_X) last = pip_arrays(xp, yp, n, rr, y) ? (int)rr : (int)rr - 1;
+            else last = (int)__builtin_floor(xr);
+        }
+        first = max(first, c0); last = min(last, c1);
+        for (int gj = first; gj <= last; gj++) row[gj] = OBS_F_OCC;
+    }
+    __syncthreads();
+    // ---- 5. footprint (skimage.draw.polygon of the hull outline, exact test over its pixel box) and heading line -> flag bits.
+    //         Writers of one phase all store "previous bits | own bit" to a byte, so concurrent stores agree. ----
+    if (s_fcnt > 0) {
+        const int r0 = max(s_fbb[0], max(gi0, 0)), r1 = min(s_fbb[1], min(gi1, Hg - 1));
+        const int c0 = max(s_fbb[2], max(gj0, 0)), c1 = min(s_fbb[3], min(gj1, Wg - 1));
+        const int wbox = c1 - c0 + 1, npx = (r1 >= r0 && c1 >= c0) ? (r1 - r0 + 1) * wbox : 0;
         for (int q = tid; q < npx; q += OBS_THREADS) {
             const int rr = q / wbox, cc = q - rr * wbox;
             const int gi = r0 + rr, gj = c0 + cc;
-            if (gi < 0 || gi >= Hg || gj < 0 || gj >= Wg) continue;
-            if (pip_arrays(xp, yp, n, (double)gj, (double)gi)) s_occ[(gi - gi0) * LW + (gj - gj0)] = 255;
+            if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) s_img[(gi - gi0) * LW + (gj - gj0)] |= OBS_F_SHIP;
         }
     }
     __syncthreads();
-    // ---- compose the four channels, 4 pixels per 32-bit store ----
+    if (line.valid) {   // cv2.line: pixel t of the 8-connected walk, t = 0 .. dmaj (closed form of on_line)
+        const long long dmaj = line.vert ? line.dy : line.dx, dmin = line.vert ? line.dx : line.dy;
+        for (long long t = tid; t <= dmaj; t += OBS_THREADS) {
+            const long long mt = (dmaj == 0) ? 0 : (2 * dmin * t + dmaj - 1) / (2 * dmaj);
+            const long long ax = line.vert ? mt : t, ay = line.vert ? t : mt;
+            const long long gj = line.x0 + ax * line.sx, gi = line.y0 + ay * line.sy;
+            if (gi >= gi0 && gi <= gi1 && gj >= gj0 && gj <= gj1 && gi >= 0 && gi < Hg && gj >= 0 && gj < Wg)
+                s_img[((int)gi - gi0) * LW + ((int)gj - gj0)] |= OBS_F_LINE;
+        }
+    }
+    __syncthreads();
+    if (tid == 0 && hpy >= gi0 && hpy <= gi1 && hpx >= gj0 && hpx <= gj1) s_img[((int)hpy - gi0) * LW + ((int)hpx - gj0)] |= OBS_F_HEAD;
+    __syncthreads();
+    // ---- 6. compose the four channels from the flag image, 4 pixels per 32-bit store ----
+    //   ch0: in map 127, ship 255, out of map 0; ch1: row value, out of map 255; ch2: line 127, head 255; ch3: occupied 255
     const size_t plane = (size_t)npix;
     unsigned *o32 = (unsigned *)(obs + (size_t)env * BP_OBS_C * plane);
     const int nwords = npix / 4; // 150*150 is a multiple of 4 (checked on the host)
     for (int w = tid; w < nwords; w += OBS_THREADS) {
-        unsigned w0 = 0, w1 = 0, w2 = 0;
-        for (int b = 0; b < 4; b++) {
+        const unsigned f = ((const unsigned *)s_img)[w];
+        unsigned inb = 0, e = 0;
+        for (int b = 0; b < 4; b++) {   // a word may straddle two window rows
             const int px = 4 * w + b;
             const int li = px / LW, lj = px - li * LW;
             const int gi = gi0 + li, gj = gj0 + lj;
-            const bool inb = !(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg);
-            unsigned f = 0, e = 255, orn = 0;
-            if (inb) {
-                f = 127;
-                if (s_fcnt > 0 && gi >= s_fbb[0] && gi <= s_fbb[1] && gj >= s_fbb[2] && gj <= s_fbb[3]) {
-                    if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) f = 255;
-                }
-                e = s_edt[li];
-                if (on_line(line, gj, gi)) orn = 127;
-                if (gj == hpx && gi == hpy) orn = 255;
-            }
-            w0 |= f << (8 * b); w1 |= e << (8 * b); w2 |= orn << (8 * b);
+            if (!(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg)) { inb |= 0xFFu << (8 * b); e |= (unsigned)s_edt[li] << (8 * b); }
         }
-        o32[w] = w0;
-        o32[nwords + w] = w1;
-        o32[2 * nwords + w] = w2;
-        o32[3 * nwords + w] = ((const unsigned *)s_occ)[w];
+        const unsigned ship = (f >> 1) & 0x01010101u, ln = (f >> 2) & 0x01010101u, hd = (f >> 3) & 0x01010101u;
+        o32[w] = inb & (0x7F7F7F7Fu + ship * 0x80u);
+        o32[nwords + w] = e | ~inb;
+        o32[2 * nwords + w] = inb & ((ln & ~hd) * 127u + hd * 255u);
+        o32[3 * nwords + w] = (f & 0x01010101u) * 255u;
     }
 }
 

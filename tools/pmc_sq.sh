@@ -10,6 +10,7 @@ sq = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('gpurun_out/pmcx/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         sq[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
-for k in ('k_physics_step',):
-    print(k, ' '.join('%s=%.4g' % (c, sum(v[-4:])/len(v[-4:])) for c, v in sorted(sq[k].items())))
+import os
+for k in os.environ.get('PMC_KERNELS', 'k_physics_step').split(','):
+    print(k, ' '.join('%s=%.4g' % (c, sorted(v)[-1] if os.environ.get('PMC_MAX') else sum(v[-4:])/len(v[-4:])) for c, v in sorted(sq[k].items())))
 PY
