@@ -123,8 +123,16 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # BP_BENCH_BACKEND=gloo is a plumbing check of the N > 1 path on a box with fewer GPUs than ranks (ranks share devices and the
+        # two collectives run on CPU copies); the measured configuration is the default: one rank per GPU over RCCL
+        backend = os.environ.get("BP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+            dist.init_process_group(backend)
+    coll_device = torch.device("cuda", local_rank) if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
 
@@ -194,12 +202,12 @@ def main():
     env.enable_timing(False)
     env.check_errors()
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
     # episode metrics cross GPUs once, after the timed region (RCCL all-gather over xGMI)
-    local = torch.stack([ep_done.sum(), ep_success.sum()]).to(torch.float64).reshape(1, 2)
+    local = torch.stack([ep_done.sum(), ep_success.sum()]).to(torch.float64).reshape(1, 2).to(coll_device)
     allm = allgather_episode_metrics(local, dist)
     total_envs = E * world
     value = total_envs * K / tmax
