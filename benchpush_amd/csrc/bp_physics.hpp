@@ -13,6 +13,7 @@
 // sub-step, so they are carried over instead of recomputed (exactness argument in DESIGN.md section 4).
 #pragma once
 #include "bp_device.hpp"
+#include <type_traits>
 
 // Optional in-kernel phase timers (diagnostic build only: -DBP_PROF).  Stamps go to D.prof, which nothing else reads.
 #ifdef BP_PROF
@@ -806,6 +807,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     }
     PROF_ACC(7)
     // ---- 6d. sequential impulses (cpArbiterApplyImpulse) ------------------------------------------------------
+    // two copies of the loop: with and without bias terms (wave-uniform, fixed for the sub-step) -> no per-contact uniform branches
+    auto iterate = [&](auto bias_tag) {
+    constexpr bool AB = decltype(bias_tag)::value;
     for (int it = 0; it < P.iterations; it++) {
         bool changed = false;
         for (int lvl = 1; lvl <= nlevels; lvl++) {
@@ -814,7 +818,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
                 d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
                 d2 vba = mk2(0.0, 0.0), vbb = mk2(0.0, 0.0);
-                if (any_bias) { vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
+                if (AB) { vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
                 const d2 n = A.n;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -829,7 +833,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         const double vrt = vdot(vr, vperp(n));
                         const double jbnOld = c ? A.jBias1 : A.jBias0;
                         double jBias = jbnOld;
-                        if (any_bias) { // with no bias term anywhere every bias impulse stays exactly 0
+                        if (AB) { // with no bias term anywhere every bias impulse stays exactly 0
                             const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
                             const d2 vb2 = vadd(vbb, vmul(vperp(r2), wb2.y));
                             const double vbn = vdot(vsub(vb2, vb1), n);
@@ -846,7 +850,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         changed = changed || (jnAcc != jnOld) || (jtAcc != jtOld) || (jBias != jbnOld);
                         if (c) { A.jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
                         else   { A.jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
-                        if (any_bias) {
+                        if (AB) {
                             const d2 jb = vmul(n, jBias - jbnOld);
                             const d2 jbneg = vneg(jb);
                             vba = vadd(vba, vmul(jbneg, A.ma));
@@ -858,8 +862,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
                     }
                 }
-                if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; if (any_bias) L.sb[A.slotA] = vba; }
-                if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; if (any_bias) L.sb[A.slotB] = vbb; }
+                if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; if (AB) L.sb[A.slotA] = vba; }
+                if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; if (AB) L.sb[A.slotB] = vbb; }
             }
             lds_sync();
         }
@@ -867,6 +871,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         // the remaining iterations would repeat it exactly
         if (!ballot(changed)) break;
     }
+    };
+    if (any_bias) iterate(std::true_type{}); else iterate(std::false_type{});
     PROF_ACC(8)
     // ---- 7. post-solve bookkeeping for ship(0) x floe arbiters, ascending key order ------------------------------
     {
