@@ -82,7 +82,7 @@ def load():
         pass
     path = LIB_PATH
     if os.environ.get("BP_PROF") == "1":  # diagnostic build with in-kernel phase timers (tools/prof_phases.py)
-        path = LIB_PATH.replace(".so", "_prof.so")
+        path = os.environ.get("BP_PROF_LIB", LIB_PATH.replace(".so", "_prof.so"))
     L = C.CDLL(path)
     vp = C.c_void_p
     L.bp_abi_version.restype = C.c_int32

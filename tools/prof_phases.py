@@ -29,6 +29,7 @@ for t in range(STEPS):
         print("step %d: kernel cycles(100MHz ticks?) mean %.0f max %.0f (env %d)" % (t, tot.mean(), tot.max(), worst))
         for who, row in (("mean", p.mean(0)), ("worst", p[worst])):
             print("  %s: " % who + " ".join("%s=%.1f%%" % (n, 100 * row[i] / row[23]) for i, n in enumerate(names)))
+            print("        cycles per sub-step: " + " ".join("%s=%.0f" % (n, row[i] / 400) for i, n in enumerate(names)) + " total=%.0f" % (row[23] / 400))
             print("        per-substep: nmv=%.2f refresh=%.3f fullpairs=%.2f nact=%.2f levels=%.2f nwarm=%.2f" % (
                 row[16] / 400, row[17] / 400, row[18] / 400, row[19] / 400, row[20] / 400, row[21] / 400))
     env.reset(term)
