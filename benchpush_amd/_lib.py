@@ -20,9 +20,14 @@ INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scale
              "n_contact_pts", "n_first_contact"]
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_load_maze", "bp_get_goal_map", "bp_reset", "bp_step", "bp_step_physics",
-           "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_nb_cap", "bp_obs_height",
+           "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_costmap_update", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_last_error",
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state"]
+
+
+class BpCostmapConfig(C.Structure):
+    _fields_ = [("scale", C.c_double), ("m", C.c_int32), ("n", C.c_int32), ("alpha", C.c_double), ("ship_mass", C.c_double),
+                ("horizon", C.c_double), ("margin", C.c_int32), ("pad_", C.c_int32)]
 
 
 class BpConfig(C.Structure):
@@ -102,6 +107,7 @@ def load():
     L.bp_get_world_polys.argtypes = [vp, vp, vp, vp]
     L.bp_get_body_state.argtypes = [vp, vp, vp]
     L.bp_get_low_dim_obs.argtypes = [vp, vp, vp]
+    L.bp_costmap_update.argtypes = [vp, C.POINTER(BpCostmapConfig), vp, C.c_double, vp, vp]
     for n in ("bp_nb_cap", "bp_obs_height", "bp_obs_width"):
         getattr(L, n).argtypes = [vp]
         getattr(L, n).restype = C.c_int32

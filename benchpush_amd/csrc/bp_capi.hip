@@ -568,6 +568,25 @@ int bp_get_body_state(bp_handle *h, double *out, void *stream)
     HIPCHK(h, hipGetLastError());
     return BP_OK;
 }
+int bp_costmap_update(bp_handle *h, const bp_costmap_config *cfg, const double *ship_pos_y, double vs, double *out, void *stream)
+{
+    if (!h || !cfg || !out) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_costmap_update before bp_load_scenarios/bp_reset");
+    if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_EINVAL, "bp_costmap_update: ship-ice handles only");
+    const int H = (int)(cfg->m * cfg->scale), W = (int)(cfg->n * cfg->scale);
+    if (!(cfg->scale > 0) || H <= 0 || W <= 0 || cfg->margin < 0 || 2 * cfg->margin > W) return fail(h, BP_EINVAL, "bp_costmap_update: bad grid");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)h->num_envs * H * W;
+    const int nblk = (int)std::min<size_t>((total + 255) / 256, 65535);
+    hipLaunchKernelGGL(k_costmap_init, dim3(nblk), dim3(256), 0, st, out, h->num_envs, H, W, (int)cfg->margin);
+    const int groups = (h->P.nbcap - h->P.nkin + 3) / 4;
+    if (groups > 0)
+        hipLaunchKernelGGL(k_costmap, dim3(h->num_envs, groups), dim3(256), 0, st, h->P, h->D, cfg->scale, H, W, cfg->alpha, cfg->ship_mass,
+                           cfg->horizon > 0 ? cfg->horizon * cfg->scale : 0.0, ship_pos_y, vs, out);
+    HIPCHK(h, hipGetLastError());
+    return BP_OK;
+}
 int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream)
 {
     if (!h || !out) return BP_EINVAL;

@@ -1267,3 +1267,95 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe_global(const DevParams 
         o[plane + cidx] = f;
     }
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Planner cost map (common/cost_map.py:27-126,284-287): kinetic-energy-loss cost of every floe, max-combined per cell.
+// k_costmap_init clears the maps and writes the boundary columns; k_costmap handles one floe per wavefront:
+// scale, horizon cull, resample_vertices(decimals=0), skimage.draw.polygon over the floe's pixel box (pass 1: pixel
+// count and coordinate sums -> pixel centroid; pass 2: cost), poly_radius, poly_area, and an atomic max per cell on the
+// (non-negative) float64 bit pattern -- max is exact, so the order of the floes does not matter.
+// ------------------------------------------------------------------------------------------------------------
+#define BP_MAX_COST 1e10
+__global__ __launch_bounds__(256) void k_costmap_init(double *__restrict__ out, int E, int H, int W, int margin)
+{
+    const size_t total = (size_t)E * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % W);
+        out[i] = (margin && (j < margin || j >= W - margin)) ? BP_MAX_COST : 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void k_costmap(const DevParams P, const DevPtrs D, const double scale, const int H, const int W,
+                                                 const double alpha, const double ship_mass, const double hz,
+                                                 const double *__restrict__ ship_pos_y, const double vs, double *__restrict__ out)
+{
+    const int env = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int s = P.nkin + blockIdx.y * 4 + wave;
+    if (s >= D.e_nb[env]) return;
+    __shared__ double s_c[4][BP_MAXV], s_r[4][BP_MAXV];
+    const size_t eb = (size_t)env * P.nbcap;
+    const int n0 = D.sc_nv[(size_t)D.e_trial[env] * P.nbcap + s];
+    const double spy = ship_pos_y ? ship_pos_y[env] : 0.0;
+    double ox = 0.0, oy = 0.0;
+    if (lane < n0) { const d2 v = D.wv[(eb + s) * BP_MAXV + lane]; ox = v.x * scale; oy = v.y * scale; }
+    if (hz != 0.0) {   // discard obstacles that lie entirely outside [ship_pos_y, ship_pos_y + horizon]
+        const bool inside = (lane < n0) && !(oy > (spy + hz) || oy < spy);
+        if (ballot(inside) == 0ull) return;
+    }
+    // resample_vertices(decimals=0): a vertex whose rounded coordinates repeat an earlier vertex's is dropped
+    const double rx = __builtin_rint(ox), ry = __builtin_rint(oy);
+    bool dup = false;
+    for (int j = 0; j < n0; j++) {
+        const double jx = __shfl(rx, j), jy = __shfl(ry, j);
+        if (j < lane && jx == rx && jy == ry) dup = true;
+    }
+    const bool keep = (lane < n0) && !dup;
+    const unsigned long long km = ballot(keep);
+    const int k = __popcll(km);
+    if (keep) { const int pos = popc_below(km, lane); s_c[wave][pos] = ox; s_r[wave][pos] = oy; }
+    lds_sync();
+    const double *c = s_c[wave], *r = s_r[wave];
+    double rmin = r[0], rmax = r[0], cmin = c[0], cmax = c[0];
+    for (int i = 1; i < k; i++) { rmin = fmin(rmin, r[i]); rmax = fmax(rmax, r[i]); cmin = fmin(cmin, c[i]); cmax = fmax(cmax, c[i]); }
+    long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
+    long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
+    if (maxr > H - 1) maxr = H - 1;
+    if (maxc > W - 1) maxc = W - 1;
+    if (maxr < minr || maxc < minc) return;
+    const int wbox = (int)(maxc - minc + 1), npx = (int)(maxr - minr + 1) * wbox;
+    // pass 1: pixels inside (skimage.draw.polygon) -> count and coordinate sums (integers: exact in any order)
+    long long cnt = 0, sr = 0, sc = 0;
+    for (int q = lane; q < npx; q += 64) {
+        const int rr = q / wbox, cc = q - rr * wbox;
+        const long long ri = minr + rr, ci = minc + cc;
+        if (pip_arrays(c, r, k, (double)ci, (double)ri)) { cnt++; sr += ri; sc += ci; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { cnt += __shfl_xor(cnt, off); sr += __shfl_xor(sr, off); sc += __shfl_xor(sc, off); }
+    if (cnt == 0) return;
+    const double cx = (double)sc / (double)cnt, cy = (double)sr / (double)cnt;
+    double rad = 0.0;   // poly_radius: largest vertex distance from the pixel centroid
+    for (int i = 0; i < k; i++) {
+        const double d = __builtin_sqrt((c[i] - cx) * (c[i] - cx) + (r[i] - cy) * (r[i] - cy));
+        if (i == 0 || d > rad) rad = d;
+    }
+    double d1 = 0.0, d2_ = 0.0;   // poly_area(vertices / scale), sequential sums
+    for (int i = 0; i < k; i++) {
+        const int p = (i - 1 + k) % k;
+        d1 += (c[i] / scale) * (r[p] / scale);
+        d2_ += (r[i] / scale) * (c[p] / scale);
+    }
+    const double mi = 0.5 * __builtin_fabs(d1 - d2_);
+    const double norm = alpha * ((vs * vs) * (mi * mi)) / (2 * (ship_mass + mi));
+    unsigned long long *o = (unsigned long long *)(out + (size_t)env * H * W);
+    for (int q = lane; q < npx; q += 64) {
+        const int rr = q / wbox, cc = q - rr * wbox;
+        const long long ri = minr + rr, ci = minc + cc;
+        if (pip_arrays(c, r, k, (double)ci, (double)ri)) {
+            const double dist = __builtin_sqrt(((double)ri - cy) * ((double)ri - cy) + ((double)ci - cx) * ((double)ci - cx));
+            const double nc = fmax(0.0, (rad * rad - dist * dist) / (rad * rad));
+            const double v = fmin(BP_MAX_COST, nc * norm);
+            atomicMax(&o[(size_t)ri * W + ci], (unsigned long long)__double_as_longlong(v + 0.0));
+        }
+    }
+}
+

@@ -157,6 +157,21 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_get_low_dim_obs(self.h, _ptr(out), self._stream()), "bp_get_low_dim_obs")
         return out
 
+    def cost_maps(self, scale, m, n, alpha=10.0, ship_mass=1.0, horizon=None, margin=1, ship_pos_y=None, vs=1.0, out=None):
+        """Planner cost maps of every env (CostMap(...).update(info['obs'], ship_pos_y, vs).cost_map, common/cost_map.py:27-126):
+        float64 [E, int(m*scale), int(n*scale)] on the device.  ship_pos_y: [E] tensor in cost-map units, or None for 0."""
+        H, W = int(m * scale), int(n * scale)
+        if out is None:
+            out = torch.empty((self.num_envs, H, W), dtype=torch.float64, device=self.device)
+        cfg = _lib.BpCostmapConfig(scale=float(scale), m=int(m), n=int(n), alpha=float(alpha), ship_mass=float(ship_mass),
+                                   horizon=float(horizon or 0.0), margin=int(margin), pad_=0)
+        spy = None
+        if ship_pos_y is not None:
+            spy = torch.as_tensor(ship_pos_y, dtype=torch.float64).to(self.device).reshape(self.num_envs).contiguous()
+        _lib.check(self.L, self.h, self.L.bp_costmap_update(self.h, C.byref(cfg), _ptr(spy) if spy is not None else None, float(vs),
+                                                            _ptr(out), self._stream()), "bp_costmap_update")
+        return out
+
     def num_bodies(self):
         out = np.zeros(self.num_envs, np.int32)
         _lib.check(self.L, self.h, self.L.bp_get_num_bodies(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_num_bodies")

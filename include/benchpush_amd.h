@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 4
+#define BP_ABI_VERSION 5
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -143,6 +143,21 @@ int bp_observe(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream
 /* Planner observation of ship-ice (cfg.egocentric_obs: false, ship_ice_env.py:96-99,394-406): device uint8
  * [E][2][map_h/0.2][map_w/0.2] = [5x5 block-mean occupancy of every floe, ship footprint on the 0.2 m grid]. */
 int bp_observe_global(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream);
+
+/* Planner cost map of ship-ice: CostMap.__init__ / boundary_cost / update / populate_costmap of
+ * benchpush/common/cost_map.py:27-126,284-287 evaluated on the environments' current obstacles (what the planners pass as
+ * info['obs'], lattice.py:78-79).  out: device double [E][(int)(m*scale)][(int)(n*scale)].  ship_pos_y: device double [E] in
+ * cost-map units (the planner passes ship_y*scale - max_ship_length/2) or NULL for 0; horizon <= 0 means horizon=None. */
+typedef struct bp_costmap_config {
+    double scale;       /* cells per metre (lattice_config.yaml:43) */
+    int32_t m, n;       /* channel height / width in metres */
+    double alpha;       /* collision cost weight */
+    double ship_mass;
+    double horizon;     /* metres ahead of ship_pos_y that are considered; <= 0: everything */
+    int32_t margin;     /* boundary columns set to 1e10 */
+    int32_t pad_;
+} bp_costmap_config;
+int bp_costmap_update(bp_handle *h, const bp_costmap_config *cfg, const double *ship_pos_y, double vs, double *out, void *stream);
 
 /* info['obs'] (cost_map.py:275-281): world-space hull vertices of every shape, device double [E][nb_cap][BP_MAXV][2],
  * counts device int32 [E][nb_cap] (index 0 = ship, then floes in trial order). */

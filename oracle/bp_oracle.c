@@ -1797,4 +1797,68 @@ void orc_observe_global(orc_env *E, double grid_m, uint8_t *obs)
     free(occ); free(foot);
 }
 
+/* ---- planner cost map: CostMap.__init__ / boundary_cost / update / populate_costmap (common/cost_map.py:27-126,284-287) over the
+ * environment's obstacles (info['obs'], cost_map.py:275-281).  out: [int(m*scale)][int(n*scale)] float64.
+ * horizon <= 0: no horizon (`horizon=None`).  The reference's `** 0.5` / `** 2` are evaluated as sqrt / products here. */
+#define ORC_MAX_COST 1e10
+void orc_costmap(const orc_env *E, double scale, int m, int n, double alpha, double ship_mass, double horizon, int margin,
+                 double ship_pos_y, double vs, double *out)
+{
+    const int H = (int)(m * scale), W = (int)(n * scale);
+    memset(out, 0, (size_t)H * W * sizeof(double));
+    if (margin) {
+        for (int i = 0; i < H; i++)
+            for (int j = 0; j < margin && j < W; j++) { out[(size_t)i * W + j] = ORC_MAX_COST; out[(size_t)i * W + (W - 1 - j)] = ORC_MAX_COST; }
+    }
+    const double hz = horizon > 0 ? horizon * scale : 0.0;
+    for (int s = 1; s < E->ns; s++) {
+        const shape_t *sh = &E->shapes[s];
+        double ox[ORC_MAXV], oy[ORC_MAXV];
+        int nn = sh->n;
+        for (int i = 0; i < nn; i++) { ox[i] = sh->wv[i].x * scale; oy[i] = sh->wv[i].y * scale; }
+        if (hz != 0.0) {
+            int all = 1;
+            for (int i = 0; i < nn; i++) if (!(oy[i] > (ship_pos_y + hz) || oy[i] < ship_pos_y)) all = 0;
+            if (all) continue;
+        }
+        /* resample_vertices(decimals=0): drop a vertex whose rounded coordinates repeat an earlier vertex's */
+        double c[ORC_MAXV], r[ORC_MAXV];
+        int k = 0;
+        for (int i = 0; i < nn; i++) {
+            int dup = 0;
+            for (int j = 0; j < i; j++) if (rint(ox[j]) == rint(ox[i]) && rint(oy[j]) == rint(oy[i])) dup = 1;
+            if (!dup) { c[k] = ox[i]; r[k] = oy[i]; k++; }
+        }
+        /* skimage.draw.polygon(ob[:,1], ob[:,0], shape) */
+        double rmin = r[0], rmax = r[0], cmin = c[0], cmax = c[0];
+        for (int i = 1; i < k; i++) { rmin = fmin(rmin, r[i]); rmax = fmax(rmax, r[i]); cmin = fmin(cmin, c[i]); cmax = fmax(cmax, c[i]); }
+        long minr = (long)fmax(0.0, rmin), maxr = (long)ceil(rmax), minc = (long)fmax(0.0, cmin), maxc = (long)ceil(cmax);
+        if (maxr > H - 1) maxr = H - 1;
+        if (maxc > W - 1) maxc = W - 1;
+        long cnt = 0, sr = 0, sc = 0;
+        for (long ri = minr; ri <= maxr; ri++)
+            for (long ci = minc; ci <= maxc; ci++)
+                if (point_in_polygon(k, c, r, (double)ci, (double)ri)) { cnt++; sr += ri; sc += ci; }
+        if (cnt == 0) continue;
+        const double cx = (double)sc / (double)cnt, cy = (double)sr / (double)cnt;
+        double rad = 0.0;   /* poly_radius (geometry/polygon.py:20-22) */
+        for (int i = 0; i < k; i++) {
+            const double d = sqrt((c[i] - cx) * (c[i] - cx) + (r[i] - cy) * (r[i] - cy));
+            if (i == 0 || d > rad) rad = d;
+        }
+        double xy[2 * ORC_MAXV];
+        for (int i = 0; i < k; i++) { xy[2 * i] = c[i] / scale; xy[2 * i + 1] = r[i] / scale; }
+        const double mi = poly_area_np(k, xy);
+        const double norm = alpha * ((vs * vs) * (mi * mi)) / (2 * (ship_mass + mi));
+        for (long ri = minr; ri <= maxr; ri++)
+            for (long ci = minc; ci <= maxc; ci++)
+                if (point_in_polygon(k, c, r, (double)ci, (double)ri)) {
+                    const double dist = sqrt(((double)ri - cy) * ((double)ri - cy) + ((double)ci - cx) * ((double)ci - cx));
+                    const double nc = fmax(0.0, (rad * rad - dist * dist) / (rad * rad));
+                    double *o = &out[(size_t)ri * W + ci];
+                    *o = fmin(ORC_MAX_COST, fmax(nc * norm, *o));
+                }
+    }
+}
+
 #include "bp_oracle_bd.c"

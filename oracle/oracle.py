@@ -82,6 +82,7 @@ def lib():
         L.orc_cv_line.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_long, C.c_long, C.c_long, C.c_long, C.c_double]
         L.orc_nd_rotate.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double, C.c_void_p]
         L.orc_observe_global.argtypes = [C.c_void_p, C.c_double, C.c_void_p]
+        L.orc_costmap.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_double, C.c_void_p]
         L.orc_bench.restype = C.c_double
         L.orc_bench.argtypes = [C.POINTER(OrcParams), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                 C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -146,6 +147,13 @@ class OracleShipIce:
         obs = np.zeros(shape, np.uint8)
         self.L.orc_observe_global(self.h, float(grid_m), _p(obs))
         return obs
+
+    def costmap(self, scale, m, n, alpha=10.0, ship_mass=1.0, horizon=None, margin=1, ship_pos_y=0.0, vs=1.0):
+        """CostMap(scale, m, n, alpha, ship_mass, horizon, margin).update(info['obs'], ship_pos_y, vs).cost_map (common/cost_map.py)."""
+        out = np.zeros((int(m * scale), int(n * scale)), np.float64)
+        self.L.orc_costmap(self.h, float(scale), int(m), int(n), float(alpha), float(ship_mass), float(horizon or 0.0), int(margin),
+                           float(ship_pos_y), float(vs), _p(out))
+        return out
 
     def info(self):
         info = np.zeros(len(INFO_KEYS), np.float64)
