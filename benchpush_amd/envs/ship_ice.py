@@ -9,6 +9,7 @@ PyTorch is used only for device memory and streams; all compute is in libbenchpu
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -16,7 +17,7 @@ import torch
 from .. import _lib
 from ..config import DotDict, default_cfg, merge_user_cfg, ship_ice_physics_params
 from ..gym_shim import Env, spaces
-from ..scenario import generate_ice_field, pack_trials
+from ..scenario import generate_ice_field, load_experiment, pack_trials
 
 __all__ = ["BatchedShipIceEnv", "ShipIceEnv", "default_trials"]
 
@@ -30,6 +31,23 @@ def default_trials(concentration, num_trials, base_seed=0, goal_y=9.0):
     """Synthetic stand-in for experiments_<conc>_100_r06_d40x12.pk (missing blobs): trial i <- seed base_seed+i."""
     kw = _CONC_GEN.get(round(float(concentration), 2), dict(min_r=0.40, max_r=0.58))
     return [generate_ice_field(float(concentration), base_seed + i, goal_y=goal_y, **kw) for i in range(num_trials)]
+
+
+def experiment_file(concentration, directory):
+    """The reference's file name for a concentration (ship_ice_env.py:76): ice_environments/experiments_<c*100>_100_r06_d40x12.pk."""
+    return os.path.join(directory, "experiments_" + str(int(concentration * 100)) + "_100_r06_d40x12.pk")
+
+
+def resolve_trials(cfg, num_trials=100, base_seed=0):
+    """Trials of an environment, like the reference's constructor (ship_ice_env.py:74-80): the pickled experiment file of the configured
+    concentration when one is available -- looked up in ``cfg.ice_environments_dir``, ``$BENCHPUSH_ICE_DIR`` and
+    ``benchpush_amd/ice_environments`` -- else the synthetic stand-in (the reference checkout ships the files as missing LFS blobs)."""
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ice_environments")
+    for d in (cfg.get("ice_environments_dir", None) if hasattr(cfg, "get") else None, os.environ.get("BENCHPUSH_ICE_DIR"), here):
+        if d and os.path.isfile(experiment_file(cfg.concentration, d)):
+            exp = load_experiment(experiment_file(cfg.concentration, d), cfg.concentration)
+            return [exp[k] for k in sorted(exp)]
+    return default_trials(cfg.concentration, num_trials, base_seed, goal_y=cfg.goal_y)
 
 
 def _ptr(t):
@@ -70,7 +88,7 @@ class BatchedShipIceEnv(_BatchedBase):
         self.goal = (0, self.cfg.goal_y)
         self.max_yaw_rate_step = (math.pi / 2) / 7
         if trials is None:
-            trials = default_trials(self.cfg.concentration, num_trials, base_seed, goal_y=self.cfg.goal_y)
+            trials = resolve_trials(self.cfg, num_trials, base_seed)
         if self.cfg.low_dim_state:  # ship_ice_env.py:190-191 pins one trial
             trials = [trials[self.cfg.fixed_trial_idx]]
         self.trials = trials

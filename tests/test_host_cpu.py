@@ -83,6 +83,29 @@ def test_experiment_schema_round_trips_through_pickle(tmp_path):
     assert set(trials[0]["obstacles"][0].keys()) >= {"vertices", "centre", "radius"}
 
 
+def test_experiment_file_of_the_reference_name_is_picked_up(tmp_path, monkeypatch):
+    """ship_ice_env.py:74-80: experiments_<c*100>_100_r06_d40x12.pk under ice_environments/ -- used when present, synthetic otherwise."""
+    import pickle
+    from benchpush_amd.config import default_cfg
+    from benchpush_amd.envs.ship_ice import experiment_file, resolve_trials
+    from benchpush_amd.scenario import generate_experiment
+    cfg = default_cfg("ship_ice")
+    cfg.concentration = 0.2
+    monkeypatch.delenv("BENCHPUSH_ICE_DIR", raising=False)
+    synthetic = resolve_trials(cfg, num_trials=3, base_seed=5)
+    assert len(synthetic) == 3
+    exp = generate_experiment(0.2, 4, base_seed=77, min_r=0.4, max_r=0.58)
+    path = experiment_file(0.2, str(tmp_path))
+    assert path.endswith("experiments_20_100_r06_d40x12.pk")
+    with open(path, "wb") as f:
+        pickle.dump(exp, f)
+    monkeypatch.setenv("BENCHPUSH_ICE_DIR", str(tmp_path))
+    got = resolve_trials(cfg, num_trials=3, base_seed=5)
+    assert len(got) == 4 and np.array_equal(got[2]["obstacles"][0]["vertices"], exp["exp"][0.2][2]["obstacles"][0]["vertices"])
+    cfg.concentration = 0.3                       # no file for this concentration -> synthetic
+    assert len(resolve_trials(cfg, num_trials=2)) == 2
+
+
 def test_gym_shim_registry_and_timelimit():
     from benchpush_amd import gym_shim
     if gym_shim.HAVE_GYMNASIUM:
