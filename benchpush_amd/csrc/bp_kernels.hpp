@@ -49,11 +49,11 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
     L.res_iB = (unsigned *)p; p += 4 * 64;
     L.res_jA = (unsigned *)p; p += 4 * 64;
     L.res_jB = (unsigned *)p; p += 4 * 64;
-    L.pl_off = (unsigned short *)p; p += 2 * 64;
+    L.pl_off = (unsigned short *)p; p += 2 * 128;  // [pair rank][side]
     L.pl_sa = (unsigned short *)p; p += 2 * 64;
     L.pl_sb = (unsigned short *)p; p += 2 * 64;
     L.pl_na = (unsigned char *)p; p += 64;
-    L.pl_nb = (unsigned char *)p; p += 64;   // scratch = 2560 B >= mailbox 16 * 96 B
+    L.pl_nb = (unsigned char *)p; p += 64;   // scratch = 2688 B >= mailbox 16 * 96 B
     L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
     L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
     L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;

@@ -367,8 +367,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         PROF_CNT(18, __popcll(cm))
         if (cm == 0) continue;
         // ---- 4a. face separations of every surviving pair: one (pair, plane) item per lane --------------------------
-        // A pair's planes never straddle a 64-item round (its block is moved to the next round if it would), so the
-        // per-round LDS atomics see all planes of a pair together.
+        // The planes of one (pair, side) never straddle a 64-item round (the block is moved to the next round if it would), so
+        // the per-round LDS atomics of a side's maximum see all its planes together; the two sides of a pair are independent
+        // maxima and may sit in different rounds.
         const int nc = __popcll(cm);
         const int myr = popc_below(cm, lane); // rank of this lane's pair among the survivors
         const int nA_l = valid ? nA_h : 0, nB_l = valid ? nB_h : 0;
@@ -379,37 +380,42 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             while (m) {
                 const int l = __ffsll((long long)m) - 1;
                 m &= m - 1;
-                const int c = __builtin_amdgcn_readlane(nA_l + nB_l, l);
-                if ((total & 63) + c > 64) total = (total + 63) & ~63;
+                const int cA = __builtin_amdgcn_readlane(nA_l, l), cB = __builtin_amdgcn_readlane(nB_l, l);
+                if ((total & 63) + cA > 64) total = (total + 63) & ~63;
+                const int offA = total;
+                total += cA;
+                if ((total & 63) + cB > 64) total = (total + 63) & ~63;
+                const int offB = total;
+                total += cB;
                 if (lane == l) {
-                    L.pl_off[r] = (unsigned short)total;
+                    L.pl_off[2 * r] = (unsigned short)offA; L.pl_off[2 * r + 1] = (unsigned short)offB;
                     L.pl_sa[r] = (unsigned short)sa; L.pl_sb[r] = (unsigned short)sb;
                     L.pl_na[r] = (unsigned char)nA_l; L.pl_nb[r] = (unsigned char)nB_l;
                     L.res_smA[r] = 0ull; L.res_smB[r] = 0ull; L.res_iA[r] = 0xFFFFFFFFu; L.res_iB[r] = 0xFFFFFFFFu;
                 }
-                total += c;
                 r++;
             }
         }
         lds_sync();
         for (int t0 = 0; t0 < total; t0 += 64) {
             const int t = t0 + lane;
-            int r = 0;
-            {   // largest r with pl_off[r] <= t
-                int lo = 0, hi = nc - 1;
+            int eb = 0;
+            {   // largest block (2 * rank + side) with pl_off[block] <= t
+                int lo = 0, hi = 2 * nc - 1;
                 while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)L.pl_off[mid] <= t) lo = mid; else hi = mid - 1; }
-                r = lo;
+                eb = lo;
             }
+            const int r = eb >> 1;
+            const bool onA = (eb & 1) == 0;
             const int pna = L.pl_na[r], pnb = L.pl_nb[r];
-            int fidx = t - (int)L.pl_off[r];
-            const bool tv = (fidx >= 0) && (fidx < pna + pnb);
-            const bool onA = fidx < pna;
+            int fidx = t - (int)L.pl_off[eb];
+            const bool tv = (fidx >= 0) && (fidx < (onA ? pna : pnb));
             unsigned long long skey = 0ull;
             int jm = 0;
             if (tv) {
                 const int psa = L.pl_sa[r], psb = L.pl_sb[r];
                 const int pbody = onA ? psa : psb, qbody = onA ? psb : psa;
-                const int f = onA ? fidx : fidx - pna;
+                const int f = fidx;
                 const int nq = onA ? pnb : pna;
                 const d2 fn = E.wn[pbody * BP_MAXV + f], fp = E.wv[pbody * BP_MAXV + f];
                 double mn = BP_INF;
