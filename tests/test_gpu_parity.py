@@ -86,6 +86,55 @@ def test_parity_goal_variant():
     _run_parity(E=2, conc=0.2, T=2, steps=8, seed=8, goal_y=19)
 
 
+def _edge_trials():
+    """Ragged / extreme scenario tables: an empty channel, one 20-vertex floe dead ahead, a triangle, a zero-area floe that the reference's
+    loader drops (ship_ice_env.py:205-209 via sim_utils), and a dense field -- all in one handle, so floe counts differ per trial."""
+    from benchpush_amd.scenario import generate_ice_field
+    ang = np.linspace(0, 2 * np.pi, 20, endpoint=False)
+    big = np.stack([6.0 + 0.7 * np.cos(ang), 2.6 + 0.7 * np.sin(ang)], 1)
+    tri = np.array([[5.2, 2.2], [6.8, 2.3], [6.1, 3.4]])
+    flat = np.array([[3.0, 5.0], [4.0, 5.0], [5.0, 5.0]])          # collinear: zero area
+    mk = lambda v: {"vertices": v, "centre": tuple(v.mean(0)), "radius": float(np.abs(v - v.mean(0)).max())}
+    start = (6.0, 1.0, np.pi / 2)
+    return [{"goal": (0, 9.0), "ship_state": start, "obstacles": []},
+            {"goal": (0, 9.0), "ship_state": start, "obstacles": [mk(big)]},
+            {"goal": (0, 9.0), "ship_state": start, "obstacles": [mk(tri), mk(flat)]},
+            generate_ice_field(0.5, 99, min_r=0.4, max_r=0.58)]
+
+
+def test_parity_empty_ragged_and_extreme_scenarios():
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
+    trials = _edge_trials()
+    E = 4
+    env = BatchedShipIceEnv(E, cfg={"concentration": 0.5}, trials=trials)
+    obs, info = env.reset()
+    orcs = _oracles(env, E)
+    for e, o in enumerate(orcs):
+        oo, _ = o.reset(trials[e])
+        assert np.array_equal(obs[e].cpu().numpy(), oo), ("reset obs", e)
+    nb = env.num_bodies()
+    assert nb[0] == 1 and nb[1] == 2 and nb[2] == 2 and nb[3] > 200      # the zero-area floe is dropped, like the reference does
+    rng = np.random.default_rng(17)
+    done_seen = np.zeros(E, bool)
+    for t in range(36):
+        a = np.where(np.arange(E) < 3, 0.0, rng.uniform(-1, 1, E)).astype(np.float32).astype(np.float64)
+        obs, rew, term, trunc, info = env.step(torch.from_numpy(a))
+        bs = env.body_state().cpu().numpy()
+        for e, o in enumerate(orcs):
+            if done_seen[e]:
+                continue
+            oo, orr, ot, oi = o.step(float(a[e]))
+            ob = o.bodies()
+            assert np.array_equal(bs[e, : len(ob)], ob), ("bodies", t, e)
+            assert np.array_equal(obs[e].cpu().numpy(), oo), ("obs", t, e)
+            assert float(rew[e]) == orr and bool(term[e]) == ot, ("reward/term", t, e)
+            assert np.array_equal(info[e].cpu().numpy(), np.array(list(oi.values()))), ("info", t, e)
+            done_seen[e] |= ot
+    assert done_seen[0]                      # the empty channel is crossed: 8 m at 0.3 m/s * 0.8 s per step = 34 steps
+    env.check_errors()
+    env.close()
+
+
 def test_world_polys_and_low_dim_match_oracle():
     from benchpush_amd.envs.ship_ice import default_trials
     trials = default_trials(0.2, 1, base_seed=4)
