@@ -24,6 +24,15 @@ for r in rows("stats/**/*kernel_stats.csv"):
 dur = defaultdict(list)
 for r in rows("stats/**/*kernel_trace.csv"):
     dur[r["Kernel_Name"].split("(")[0]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+# bench.py times the last K = 30 launches (the first W = 5 are warm-up and lighter): the figure to compare with its HIP-event time
+_tr = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows("stats/**/*kernel_trace.csv") if r["Kernel_Name"].startswith("k_physics_step"))
+if len(_tr) >= 30:
+    print("k_physics_step, last 30 launches of the trace (the timed region of bench.py): avg_ms=%.3f" % (sum(b - a for a, b in _tr[-30:]) / 30 / 1e6))
+    try:
+        print("bench.py's own HIP-event time for the same launches (bench_under_rocprof.json roofline.physics_ms): %.3f"
+              % json.load(open(os.path.join(out, "bench_under_rocprof.json")))["roofline"]["physics_ms"])
+    except Exception:
+        pass
 print("== kernel trace ==")
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
     print("%-50s n=%d avg_ms=%.3f min_ms=%.3f max_ms=%.3f" % (k[:50], len(v), sum(v) / len(v) / 1e6, min(v) / 1e6, max(v) / 1e6))
