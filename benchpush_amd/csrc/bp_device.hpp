@@ -173,6 +173,8 @@ __device__ __forceinline__ double key_f64(unsigned long long k)
     const unsigned long long b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
     return __builtin_bit_cast(double, b);
 }
-// LDS-only ordering point for a single-wave workgroup: LDS operations of one wave execute in order, so only the
-// compiler must be kept from moving LDS accesses across it (plus a drain of LGKM so values are in registers).
-__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS-only ordering point for a single-wave workgroup: the LDS operations of one wave execute in issue order, so a lane's ds_read
+// issued after another lane's ds_write / atomic sees it without any wait; only the compiler must be kept from moving accesses
+// across the point (it still inserts the s_waitcnt each register use needs).  Cross-lane communication through *global* memory
+// needs __syncthreads() (vmcnt drain) instead.
+__device__ __forceinline__ void lds_sync() { asm volatile("" ::: "memory"); }

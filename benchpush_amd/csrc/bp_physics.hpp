@@ -254,7 +254,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             L.tf[2 * lane + 1] = mk2(t.z, t.w);
             L.mvs[i] = now;
         }
-        __syncthreads();
+        lds_sync();
         const int cnt = min(64, S.nmv - k0);
         // world vertices / normals, one (body, vertex) item per lane; AABB through LDS atomic min/max on order-preserving
         // keys (min and max are exact, so the reduction order is irrelevant).  bbk aliases the narrow-phase scratch.
@@ -293,10 +293,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const double4 f = E.fat[i];
             L.rf[lane] = !(nbb.x >= f.x && nbb.y >= f.y && nbb.z <= f.z && nbb.w <= f.w);
         }
-        __syncthreads();
+        lds_sync();
         PROF_ACC(0)
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
         unsigned long long rm = ballot((lane < cnt) && L.rf[lane < cnt ? lane : 0]);
+        if (rm) __syncthreads(); // refresh_body reads the AABBs other lanes have just stored
         while (rm) {
             const int kk = __ffsll((long long)rm) - 1;
             rm &= rm - 1;
@@ -776,7 +777,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         S.prev_amask = amask;
     }
     PROF_CNT(21, __popcll(wmask))
-    __syncthreads();
+    lds_sync();
     // ---- 6b. velocity integrate: damping^dt == 0, no gravity/forces -> dynamic bodies' v, w := +0 ---------------
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {
         const int k = k0 + lane;
@@ -786,7 +787,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             if (sl != 255 && E.mass[i].x != 0.0) { L.sv[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(0.0, L.sw[sl].y); }
         }
     }
-    __syncthreads();
+    lds_sync();
     PROF_ACC(6)
     // ---- 6c. warm start (cpArbiterApplyCachedImpulse) -----------------------------------------------------------
     const double dt_coef = (prev_dt == 0.0) ? 0.0 : dt / prev_dt;
@@ -928,7 +929,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         if (x0 < 0.0 || x0 > P.map_w) S.boundary_violated = 1;
     }
-    __syncthreads();
+    lds_sync();
     // ---- next sub-step's moving list: bodies of active arbiters with a non-zero velocity, plus the ship ----------
     {
         bool wantA = false, wantB = false;
@@ -947,9 +948,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             }
         }
         if (wantA) L.owner[ba] = (unsigned short)(lane * 2);
-        __syncthreads();
+        lds_sync();
         if (wantB) L.owner[bbi] = (unsigned short)(lane * 2 + 1);
-        __syncthreads();
+        lds_sync();
         const bool gotA = wantA && L.owner[ba] == (unsigned short)(lane * 2);
         const bool gotB = wantB && L.owner[bbi] == (unsigned short)(lane * 2 + 1);
         const d2 v0 = L.sv[0], w0 = L.sw[0];
@@ -964,6 +965,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         S.nmv = shipmv + nA_ + __popcll(mB);
     }
     S.quiescent = (S.nmv == 0) && (wmask == 0);
-    __syncthreads();
+    lds_sync();
     PROF_ACC(9)
 }
