@@ -457,13 +457,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             if (smax > rsum) { M.newhint = useA ? iA : (nA + iB); touching = false; }
             else if (smax <= 0.0) { n = useA ? An[iA] : vneg(Bn[iB]); }
             else {
-                const int iA0 = (iA - 1 + nA) % nA;
+                const int iA0 = (iA == 0) ? nA - 1 : iA - 1;
                 const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
                 const d2 eA = vsub(bA, aA);
                 const double uA = vdot(vsub(qA, aA), eA), eeA = vdot(eA, eA);
                 const bool spanA = !(uA < 0.0) && !(uA > eeA);
                 const int kA = (uA < 0.0) ? iA0 : iA;
-                const int iB0 = (iB - 1 + nB) % nB;
+                const int iB0 = (iB == 0) ? nB - 1 : iB - 1;
                 const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
                 const d2 eB = vsub(bB, aB);
                 const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
@@ -510,12 +510,12 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 d2 e1a, e1b, e2a, e2b;
                 int e1ia, e1ib, e2ia, e2ib;
                 {
-                    const int i0 = (i1A - 1 + nA) % nA, i2 = (i1A + 1) % nA;
+                    const int i0 = (i1A == 0) ? nA - 1 : i1A - 1, i2 = (i1A + 1 == nA) ? 0 : i1A + 1;
                     if (vdot(n, An[i1A]) > vdot(n, An[i2])) { e1a = Av[i0]; e1ia = i0; e1b = Av[i1A]; e1ib = i1A; }
                     else { e1a = Av[i1A]; e1ia = i1A; e1b = Av[i2]; e1ib = i2; }
                 }
                 {
-                    const int i0 = (i1B - 1 + nB) % nB, i2 = (i1B + 1) % nB;
+                    const int i0 = (i1B == 0) ? nB - 1 : i1B - 1, i2 = (i1B + 1 == nB) ? 0 : i1B + 1;
                     if (vdot(nn, Bn[i1B]) > vdot(nn, Bn[i2])) { e2a = Bv[i0]; e2ia = i0; e2b = Bv[i1B]; e2ib = i1B; }
                     else { e2a = Bv[i1B]; e2ia = i1B; e2b = Bv[i2]; e2ib = i2; }
                 }
