@@ -228,18 +228,24 @@ __device__ __forceinline__ void bd_spfa(const BdParams &B, const BdLds &L, float
                 ok[k] = act && inb && bd_bit(L.freeb, nidx[k]);
                 old[k] = bd_ld(dist + nidx[k]);
             }
+            // all eight relaxations are issued before any result is used: one L2 round trip instead of eight (the result does not
+            // depend on the order: distances are the least fixed point, parents follow a local rule afterwards)
+            unsigned prevb[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const float nd = d + ((k & 1) ? 1.0f : SQ2);
-                if (ok[k] && nd < old[k]) {
-                    const unsigned nb_ = __float_as_uint(nd);
-                    const unsigned prev = atomicMin(du + nidx[k], nb_);
-                    if (nb_ < prev) {
-                        const int tq = ((int)nd) % 3;
-                        const int pos = atomicAdd(&L.qn[tq], 1);
-                        if (pos < BD_QCAP) L.q[tq * BD_QCAP + pos] = (unsigned short)nidx[k];
-                        else err |= BP_ERR_ARB_OVERFLOW;
-                    }
+                ok[k] = ok[k] && nd < old[k];
+                prevb[k] = 0u;
+                if (ok[k]) prevb[k] = atomicMin(du + nidx[k], __float_as_uint(nd));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float nd = d + ((k & 1) ? 1.0f : SQ2);
+                if (ok[k] && __float_as_uint(nd) < prevb[k]) {
+                    const int tq = ((int)nd) % 3;
+                    const int pos = atomicAdd(&L.qn[tq], 1);
+                    if (pos < BD_QCAP) L.q[tq * BD_QCAP + pos] = (unsigned short)nidx[k];
+                    else err |= BP_ERR_ARB_OVERFLOW;
                 }
             }
         }
