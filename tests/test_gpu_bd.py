@@ -141,3 +141,37 @@ def test_other_action_types_match_oracle(atype):
         _compare_step(env, oracles, acts, "%s %d" % (atype, t))
     env.check_errors()
     env.close()
+
+
+def test_full_size_properties_4096_envs():
+    """BASELINE.json configs[3] size (box-delivery-v0, 4096 envs, 12 boxes): oracle-free properties.  Envs that play the same trial with
+    the same actions must produce the same bits (env e plays trial e % T), counters are monotone, everything stays finite and in range."""
+    from benchpush_amd._lib import BD_INFO_KEYS
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    E, T = 4096, 8
+    env = BatchedBoxDeliveryEnv(E, cfg={"boxes": {"num_boxes_small": 12}}, num_trials=T)
+    obs, info = env.reset()
+    assert tuple(obs.shape) == (E, 224, 224, 4) and obs.dtype == torch.uint8
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    base = torch.rand((4, T), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1
+    k = {n: i for i, n in enumerate(BD_INFO_KEYS)}
+    prev_boxes = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+    prev_dist = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+    for t in range(4):
+        obs, rew, term, trunc, info = env.step(base[t].repeat(E // T))
+        v = obs.view(E // T, T, -1)
+        assert torch.equal(v, v[0:1].expand(E // T, -1, -1))
+        assert torch.equal(info.view(E // T, T, -1), info.view(E // T, T, -1)[0:1].expand(E // T, -1, -1))
+        assert torch.isfinite(info).all() and torch.isfinite(rew).all()
+        assert (info[:, k["cumulative_boxes"]] >= prev_boxes).all() and (info[:, k["cumulative_boxes"]] <= 12).all()
+        assert (info[:, k["cumulative_distance"]] >= prev_dist).all()
+        assert (info[:, k["ministeps"]] >= 0).all()
+        prev_boxes, prev_dist = info[:, k["cumulative_boxes"]].clone(), info[:, k["cumulative_distance"]].clone()
+        assert not (term | trunc).any() or True
+        live = ~(term | trunc).bool()
+        prev_boxes[~live] = 0
+        prev_dist[~live] = 0
+        env.reset(term | trunc)
+    env.check_errors()
+    env.close()
