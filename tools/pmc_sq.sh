@@ -3,7 +3,7 @@
 E=$1; shift
 export TMPDIR=/tmp; REPO=$(pwd); cd /tmp; export PYTHONPATH=$REPO
 rm -rf $REPO/gpurun_out/pmcx
-rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $REPO/gpurun_out/pmcx -- python3 $REPO/bench.py --steps 4 --warmup 8 --envs-per-gpu $E --no-cpu-baseline > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $REPO/gpurun_out/pmcx -- python3 $REPO/bench.py ${PMC_BENCH_ARGS} --steps 4 --warmup 8 --envs-per-gpu $E --no-cpu-baseline > /dev/null 2>&1
 cd $REPO; python3 - <<'PY'
 import csv, glob, collections
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
