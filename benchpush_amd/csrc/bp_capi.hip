@@ -109,7 +109,7 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     P.map_w = cfg->map_w; P.map_h = cfg->map_h; P.goal_y = cfg->goal_y; P.m_to_pix = cfg->m_to_pix;
     P.beta = cfg->beta; P.boundary_penalty = cfg->boundary_penalty; P.terminal_reward = cfg->terminal_reward;
     P.local_w = cfg->local_w; P.local_h = cfg->local_h; P.vshift = cfg->vshift; P.obs_range = cfg->obs_range;
-    P.skin = 0.25;
+    P.skin = 0.06;  // Verlet skin of the neighbour lists (m): a tuning knob only, the lists are an exact broadphase for any value
     P.env_kind = cfg->env_kind;
     P.nkin = (cfg->env_kind == BP_ENV_MAZE) ? 1 + cfg->num_wheels : 1;
     P.goal_x = cfg->goal_x; P.goal_reach = cfg->goal_reach; P.k_increment = cfg->k_increment;
