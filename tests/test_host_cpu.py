@@ -25,6 +25,16 @@ def test_cabi_library_exports_every_declared_symbol():
     assert set(_lib.EXPORTS) <= declared | {"bp_debug_trace"}
 
 
+def test_header_is_plain_c_and_cxx():
+    """include/benchpush_amd.h is the drop-in boundary: it must compile as C99 and as C++ on its own (no torch / HIP types)."""
+    import subprocess
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "benchpush_amd.h")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", hdr])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", hdr])
+    code = re.sub(r"/\*.*?\*/", "", open(hdr).read(), flags=re.S)          # comments may mention them; declarations must not
+    assert "torch" not in code.lower() and "hipStream_t" not in code and "#include <hip" not in code
+
+
 def test_cabi_fails_loudly_without_gpu(ship_cfg):
     import torch
     if torch.cuda.is_available():
