@@ -495,13 +495,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 int i1A = 0, i1B = 0;
                 {
                     double mx = -BP_INF;
-#pragma unroll 5
+#pragma unroll 10
                     for (int q = 0; q < VL; q++) { // slots >= nA repeat vertex 0: equal, cannot win the strict '>'
                         const double d = vdot(Av[q < nA ? q : 0], n);
                         if (d > mx) { mx = d; i1A = q; }
                     }
                     mx = -BP_INF;
-#pragma unroll 5
+#pragma unroll 10
                     for (int q = 0; q < VL; q++) {
                         const double d = vdot(Bv[q < nB ? q : 0], nn);
                         if (d > mx) { mx = d; i1B = q; }
