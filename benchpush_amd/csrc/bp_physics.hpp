@@ -454,35 +454,34 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const double smax = useA ? sA : sB;
             bool touching = true;
             d2 n = mk2(0, 0);
+            // every vertex / normal the three cases below can need is fetched up front: one round trip instead of a dependent chain
+            const int iA0 = (iA == 0) ? nA - 1 : iA - 1, iB0 = (iB == 0) ? nB - 1 : iB - 1;
+            const d2 nAi = An[iA], nBi = Bn[iB];
+            const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
+            const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
             if (smax > rsum) { M.newhint = useA ? iA : (nA + iB); touching = false; }
-            else if (smax <= 0.0) { n = useA ? An[iA] : vneg(Bn[iB]); }
+            else if (smax <= 0.0) { n = useA ? nAi : vneg(nBi); }
             else {
-                const int iA0 = (iA == 0) ? nA - 1 : iA - 1;
-                const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
                 const d2 eA = vsub(bA, aA);
                 const double uA = vdot(vsub(qA, aA), eA), eeA = vdot(eA, eA);
                 const bool spanA = !(uA < 0.0) && !(uA > eeA);
-                const int kA = (uA < 0.0) ? iA0 : iA;
-                const int iB0 = (iB == 0) ? nB - 1 : iB - 1;
-                const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
                 const d2 eB = vsub(bB, aB);
                 const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
                 const bool spanB = !(uB < 0.0) && !(uB > eeB);
-                const int kB = (uB < 0.0) ? iB0 : iB;
                 if (useA) {
-                    if (spanA) n = An[iA];
-                    else if (sB > 0.0 && spanB) n = vneg(Bn[iB]);
+                    if (spanA) n = nAi;
+                    else if (sB > 0.0 && spanB) n = vneg(nBi);
                     else {
-                        const d2 pp = vsub(Bv[jA], Av[kA]);
+                        const d2 pp = vsub(qA, (uA < 0.0) ? aA : bA);
                         const double dl = vlen(pp);
                         if (dl > rsum) touching = false;
                         n = vmul(pp, 1.0 / (dl + BP_DBL_MIN));
                     }
                 } else {
-                    if (spanB) n = vneg(Bn[iB]);
-                    else if (sA > 0.0 && spanA) n = An[iA];
+                    if (spanB) n = vneg(nBi);
+                    else if (sA > 0.0 && spanA) n = nAi;
                     else {
-                        const d2 pp = vsub(Bv[kB], Av[jB]);
+                        const d2 pp = vsub((uB < 0.0) ? aB : bB, qB);
                         const double dl = vlen(pp);
                         if (dl > rsum) touching = false;
                         n = vmul(pp, 1.0 / (dl + BP_DBL_MIN));
