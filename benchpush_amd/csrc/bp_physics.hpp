@@ -828,7 +828,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 const d2 n = A.n;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
-                    if (c < A.count) {
+                    if (c == 0 || A.count > 1) { // an arbiter always has its first contact
                         const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
                         const double nMass = c ? A.nMass1 : A.nMass0, tMass = c ? A.tMass1 : A.tMass0;
                         const double bias = c ? A.bias1 : A.bias0, bounce = c ? A.bounce1 : A.bounce0;
