@@ -6,7 +6,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libbenchpush_hip.so")
 SOURCES = ["bp_capi.hip"]
-HEADERS = ["bp_device.hpp", "bp_physics.hpp", "bp_kernels.hpp", "bp_host_geom.hpp", os.path.join("..", "..", "include", "benchpush_amd.h")]
+
+
+def _headers():
+    """Every header the translation unit can see: csrc/*.hpp plus the public C header."""
+    import glob
+    return sorted(glob.glob(os.path.join(CSRC, "*.hpp"))) + [os.path.join(_HERE, "..", "include", "benchpush_amd.h")]
+
 # -ffp-contract=off / -fno-fast-math: the physics must round exactly like the binary64 reference arithmetic.
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared", "-std=c++17",
                "-Wno-unused-value"]
@@ -16,8 +22,7 @@ def needs_build():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
+    for p in [os.path.join(CSRC, f) for f in SOURCES] + _headers():
         if os.path.exists(p) and os.path.getmtime(p) > t:
             return True
     return False

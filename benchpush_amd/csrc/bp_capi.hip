@@ -24,6 +24,8 @@ struct bp_handle {
     bool steps_done = false;
     bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
+    int pack = 0;          // ship-ice step kernel: K envs per wavefront (4 / 2), 0 = one env per wavefront (k_physics_step)
+    size_t pack_lds = 0;
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -254,6 +256,26 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    // packed step kernel (bp_physics_pack.hpp, K envs per wavefront): ship-ice only, opt-in with BP_PACK=2|4 -- bit-identical
+    // to k_physics_step but slower at 4096 envs (profiles/r02_pack/README.md), so one env per wavefront stays the default
+    h->pack = 0;
+    if (h->P.env_kind == BP_ENV_SHIP_ICE && h->P.nkin == 1 && nbcap < 16384) {
+        bool plain = true; // one kinematic shape (index 0), dynamic shapes without groups otherwise
+        for (int t = 0; t < T && plain; t++)
+            for (int b = 0; b < (int)trials[t].size(); b++) {
+                const int kd = trials[t][b].kind;
+                const int bt = (kd >> 16) & 3, grp = (kd >> 8) & 0xFF;
+                if (grp != 0 || bt != (b == 0 ? 1 : 0)) { plain = false; break; }
+            }
+        int want = 0;
+        if (const char *ev = getenv("BP_PACK")) want = atoi(ev);
+        if (plain && (want == 2 || want == 4) && pk_lds_bytes(want, nbcap) <= 40 * 1024) {
+            h->pack = want;
+            h->pack_lds = pk_lds_bytes(want, nbcap);
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(4, nbcap)));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(2, nbcap)));
+        }
+    }
     if (!settle) return BP_OK;
     h->maze8 = (h->P.env_kind == BP_ENV_MAZE);
     for (int v : h_nv) if (v > 8) h->maze8 = false;
@@ -426,6 +448,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         if (mode == MODE_STEP) h->steps_done = true;
         if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (mode == MODE_STEP && h->pack == 4 && h->D.dbg == nullptr)
+            hipLaunchKernelGGL(k_physics_step_pack4, dim3((h->num_envs + 3) / 4), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (mode == MODE_STEP && h->pack == 2 && h->D.dbg == nullptr)
+            hipLaunchKernelGGL(k_physics_step_pack2, dim3((h->num_envs + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (mode == MODE_STEP)
             hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (h->resettle && h->maze8)

@@ -566,6 +566,8 @@ __global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict_
     }
 }
 
+#include "bp_physics_pack.hpp"
+
 // reset() from the settled per-trial template (ship_ice_env.py:223-249 is a pure function of the trial when
 // random_start is off): copy the template state of trial (global_env_id + episode) % T into the env.
 template <typename T>

@@ -20,10 +20,12 @@
 #define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
 #define PROF_ACC(slot) { unsigned long long _n = __builtin_amdgcn_s_memtime(); S.prof[slot] += _n - _pt; _pt = _n; }
 #define PROF_CNT(slot, v) { S.prof[slot] += (unsigned long long)(v); }
+#define PROF_MAX(slot, v) { if ((unsigned long long)(v) > S.prof[slot]) S.prof[slot] = (unsigned long long)(v); }
 #else
 #define PROF_DECL
 #define PROF_ACC(slot)
 #define PROF_CNT(slot, v)
+#define PROF_MAX(slot, v)
 #endif
 
 struct ArbReg {
@@ -680,6 +682,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
 
     PROF_ACC(5)
     PROF_CNT(19, __popcll(amask))
+    PROF_MAX(11, __popcll(ballot(A.key != ARB_FREE_KEY)))
+    PROF_MAX(12, __popcll(amask))
+    PROF_MAX(14, S.nslots)
+    PROF_MAX(15, S.nmv)
     PROF_CNT(20, S.nlevels)
     // ---- 6a. prestep (cpArbiterPreStep) -----------------------------------------------------------------------
     if (active) {
@@ -776,6 +782,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         S.prev_amask = amask;
     }
     PROF_CNT(21, __popcll(wmask))
+    PROF_MAX(13, __popcll(wmask))
     lds_sync();
     // ---- 6b. velocity integrate: damping^dt == 0, no gravity/forces -> dynamic bodies' v, w := +0 ---------------
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {

@@ -68,6 +68,15 @@ def test_parity_30pct_with_contacts_and_autoreset():
     assert _run_parity(E=8, conc=0.3, T=3, steps=40, seed=0) > 1000
 
 
+@pytest.mark.parametrize("pack,E", [("4", 7), ("4", 8), ("2", 5)])
+def test_parity_packed_step_kernel(monkeypatch, pack, E):
+    """k_physics_step_pack<K> (K envs per wavefront, bp_physics_pack.hpp; opt-in with BP_PACK) is bit-identical to the oracle too:
+    full waves, a ragged last wave, auto-resets, 30 % and 50 % fields."""
+    monkeypatch.setenv("BP_PACK", pack)
+    assert _run_parity(E=E, conc=0.3, T=3, steps=30, seed=5) > 500
+    assert _run_parity(E=E, conc=0.5, T=2, steps=10, seed=21) > 100
+
+
 def test_parity_50pct_dense_field():
     assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
 
