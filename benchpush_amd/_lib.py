@@ -22,7 +22,8 @@ ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_E
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_load_maze", "bp_get_goal_map", "bp_reset", "bp_step", "bp_step_physics",
            "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_costmap_update", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_last_error",
-           "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state"]
+           "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
+           "bp_get_episode_metrics", "bp_start_uniform", "bp_debug_round2"]
 
 
 class BpCostmapConfig(C.Structure):
@@ -43,7 +44,9 @@ class BpConfig(C.Structure):
                 ("ship_tail", C.c_double * 2),
                 ("env_kind", C.c_int32), ("num_wheels", C.c_int32), ("wheel_verts", ((C.c_double * 2) * 4) * MAX_WHEELS),
                 ("goal_x", C.c_double), ("goal_reach", C.c_double), ("k_increment", C.c_double), ("wall_radius", C.c_double),
-                ("obstacle_size", C.c_double)]
+                ("obstacle_size", C.c_double),
+                ("random_start", C.c_int32), ("_pad2", C.c_int32), ("start_x_range", C.c_double), ("start_seed", C.c_uint64),
+                ("ship_mass", C.c_double)]
 
 
 class BpBdConfig(C.Structure):
@@ -107,6 +110,10 @@ def load():
     L.bp_get_world_polys.argtypes = [vp, vp, vp, vp]
     L.bp_get_body_state.argtypes = [vp, vp, vp]
     L.bp_get_low_dim_obs.argtypes = [vp, vp, vp]
+    L.bp_get_episode_metrics.argtypes = [vp, vp, vp, vp]
+    L.bp_start_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64]
+    L.bp_start_uniform.restype = C.c_double
+    L.bp_debug_round2.argtypes = [vp, vp, C.c_int32, vp]
     L.bp_costmap_update.argtypes = [vp, C.POINTER(BpCostmapConfig), vp, C.c_double, vp, vp]
     for n in ("bp_nb_cap", "bp_obs_height", "bp_obs_width"):
         getattr(L, n).argtypes = [vp]

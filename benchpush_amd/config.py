@@ -97,6 +97,10 @@ def ship_ice_physics_params(cfg):
         local_h=6.0,                             # ship_ice_env.py:91
         vshift=2.0,                              # ship_ice_env.py:58
         obs_range=12.0,                          # ship_ice_env.py:383
+        random_start=int(bool(cfg.get("random_start", False))),     # ship_ice_env.py:201-203
+        start_x_range=float(cfg.get("start_x_range", 11.0) or 11.0),
+        start_seed=int(cfg.get("start_seed", 0) or 0),              # key of the counter RNG that replaces python's global `random`
+        ship_mass=float(cfg.ship.mass),                             # ShipIceMetric(ship_mass=env.cfg.ship.mass)
     )
 
 

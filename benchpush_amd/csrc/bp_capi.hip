@@ -56,6 +56,19 @@ static int fail(bp_handle *h, int code, const std::string &msg)
         if (_e != hipSuccess) return fail((h), BP_EHIP, std::string(#call) + ": " + hipGetErrorString(_e));    \
     } while (0)
 
+// Entry points run on the handle's device and leave the calling thread's current device as they found it.
+struct DevGuard {
+    int prev = -1;
+    bool changed = false, ok = true;
+    explicit DevGuard(int d)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != d) { ok = hipSetDevice(d) == hipSuccess; changed = ok; }
+    }
+    ~DevGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+#define BP_DEVICE(h) DevGuard _dg((h)->device); if (!_dg.ok) return fail((h), BP_EHIP, "hipSetDevice failed")
+
 template <typename T>
 static int dalloc(bp_handle *h, T **p, size_t n, int fill_byte = 0)
 {
@@ -95,12 +108,15 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     if (cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
     if (cfg->env_kind != BP_ENV_SHIP_ICE && cfg->env_kind != BP_ENV_MAZE) return BP_EINVAL;
     if (cfg->env_kind == BP_ENV_MAZE && (cfg->num_wheels < 0 || cfg->num_wheels > BP_MAX_WHEELS)) return BP_EINVAL;
+    if (cfg->random_start && cfg->env_kind != BP_ENV_SHIP_ICE) return BP_EINVAL; // per-episode start poses: ship-ice only
     bp_handle *h = new bp_handle();
     h->cfg = *cfg;
     h->num_envs = num_envs;
     h->env_offset = env_id_offset;
     h->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete h; return BP_ENODEVICE; }
+    h->resettle = (cfg->env_kind == BP_ENV_SHIP_ICE && cfg->random_start != 0); // the settled field depends on the start pose
+    DevGuard _dg(device);
+    if (!_dg.ok) { delete h; return BP_ENODEVICE; }
     memset(&h->D, 0, sizeof(h->D));
     DevParams &P = h->P;
     memset(&P, 0, sizeof(P));
@@ -116,6 +132,8 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     P.nkin = (cfg->env_kind == BP_ENV_MAZE) ? 1 + cfg->num_wheels : 1;
     P.goal_x = cfg->goal_x; P.goal_reach = cfg->goal_reach; P.k_increment = cfg->k_increment;
     P.num_envs = num_envs; P.env_offset = env_id_offset;
+    P.random_start = (cfg->env_kind == BP_ENV_SHIP_ICE) ? cfg->random_start : 0;
+    P.start_x_range = cfg->start_x_range; P.start_seed = cfg->start_seed; P.ship_mass = cfg->ship_mass;
     P.num_ship_verts = cfg->num_ship_verts;
     memcpy(P.ship_verts, cfg->ship_verts, sizeof(P.ship_verts));
     memcpy(P.ship_head, cfg->ship_head, sizeof(P.ship_head));
@@ -143,7 +161,7 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
 int bp_destroy(bp_handle *h)
 {
     if (!h) return BP_EINVAL;
-    hipSetDevice(h->device);
+    DevGuard _dg(h->device);
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     delete h;
@@ -252,6 +270,12 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     if ((rc = dalloc(h, &D.a_h0, E * BP_ACAP))) return rc;
     if ((rc = dalloc(h, &D.a_h1, E * BP_ACAP))) return rc;
     if ((rc = dalloc(h, &D.a_d, E * BP_ACAP * 14))) return rc;
+    if ((rc = dalloc(h, &D.e_lastrew, E))) return rc;
+    if ((rc = dalloc(h, &D.e_lastflag, E))) return rc;
+    if ((rc = dalloc(h, &D.m_acc, E * 8))) return rc;
+    if ((rc = dalloc(h, &D.m_rows, E * BP_EPM_COUNT))) return rc;
+    if ((rc = dalloc(h, &D.m_count, E))) return rc;
+    if ((rc = dalloc(h, &D.m_open, E))) return rc;
     D.dbg = nullptr; D.dbg_env = -1; D.prof = nullptr;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -304,7 +328,7 @@ int bp_load_scenarios(bp_handle *h, int32_t T, int32_t F, int32_t V, const doubl
     if (!h || T <= 0 || F < 0 || V <= 0 || !starts || !nfloes) return BP_EINVAL;
     if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
     if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_ESTATE, "handle was created for another environment");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     using namespace bpgeom;
     std::vector<std::vector<Shape>> trials(T);
     for (int t = 0; t < T; t++) {
@@ -336,7 +360,7 @@ int bp_load_maze(bp_handle *h, int32_t T, int32_t nbox, const double *centres, i
     if (!h || T <= 0 || nbox < 0 || nwalls < 0 || nwalls > 16 || !walls || !start || (nbox > 0 && !centres)) return BP_EINVAL;
     if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
     if (h->P.env_kind != BP_ENV_MAZE) return fail(h, BP_ESTATE, "handle was created for another environment");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     using namespace bpgeom;
     const bp_config &cf = h->cfg;
     std::vector<std::vector<Shape>> trials(T);
@@ -391,6 +415,59 @@ int bp_get_goal_map(bp_handle *h, double *out_host, int32_t *grid_h, int32_t *gr
     if (grid_h) *grid_h = h->P.grid_h;
     if (grid_w) *grid_w = h->P.grid_w;
     return BP_OK;
+}
+
+// python's round(x, 2) (ship_ice_env.py:337-339 rounds info['state']): the double nearest to x rounded to two decimals, ties of the
+// exact value to even.  x * 100 is taken exactly (product + fma residual), so a product that only *rounds* onto a tie is not one.
+__device__ __forceinline__ double bp_round2(double x)
+{
+    const double y = x * 100.0;
+    const double e = __builtin_fma(x, 100.0, -y);
+    double k = __builtin_rint(y);
+    if (__builtin_fabs(y - k) == 0.5 && e != 0.0) { const double lo = __builtin_floor(y); k = (e > 0.0) ? lo + 1.0 : lo; }
+    return k / 100.0;
+}
+__global__ __launch_bounds__(256) void k_debug_round2(const double *__restrict__ in, double *__restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bp_round2(in[i]);
+}
+
+// ShipIceMetric.reset / update (ship_ice_metric.py:26-69; shared arithmetic in benchpush_amd/metrics/interactive_nav.py) for every env,
+// one thread per env, after the physics kernel of bp_step (mode 0) or the reset kernel of bp_reset (mode 1).
+__global__ __launch_bounds__(256) void k_episode_metrics(const DevParams P, const DevPtrs D, const int mode, const unsigned char *__restrict__ mask)
+{
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= P.num_envs) return;
+    double *a = D.m_acc + (size_t)env * 8;
+    const d2 p = D.pxy[(size_t)env * P.nbcap];
+    const double x = bp_round2(p.x), y = bp_round2(p.y);
+    auto emit = [&](double success) {
+        const double l0 = a[1], L = a[4], work = a[6];
+        const double own = P.ship_mass * l0;
+        double *r = D.m_rows + (size_t)env * BP_EPM_COUNT;
+        r[BP_EPM_EFFICIENCY] = (success != 0.0) ? L / l0 : 0.0;   // compute_efficiency_score
+        r[BP_EPM_EFFORT] = own / (own + work);                    // compute_effort_score
+        r[BP_EPM_REWARD] = a[0]; r[BP_EPM_SUCCESS] = success; r[BP_EPM_LENGTH] = a[5]; r[BP_EPM_TOTAL_WORK] = work;
+        D.m_count[env] += 1u;
+    };
+    if (mode == 1) {
+        if (mask != nullptr && mask[env] == 0) return;
+        if (D.m_open[env] && a[5] > 0.0) emit(0.0);   // reset of a running episode: eps_complete by truncation
+        a[0] = 0.0; a[1] = 0.0; a[2] = x; a[3] = y; a[4] = P.goal_y - y; a[5] = 0.0; a[6] = 0.0; a[7] = 0.0;
+        D.m_open[env] = 1;
+        return;
+    }
+    if (!D.m_open[env]) return; // stepped past its end without a reset: nothing to account
+    const int fl = D.e_lastflag[env];
+    const double dx = a[2] - x, dy = a[3] - y;
+    a[0] += D.e_lastrew[env];
+    a[1] += __builtin_sqrt(dx * dx + dy * dy);
+    a[2] = x; a[3] = y;
+    a[5] += 1.0;
+    a[6] = D.e_total_work[env];
+    a[7] = (double)((fl >> 1) & 1);
+    if (fl & 1) { emit(a[7]); D.m_open[env] = 0; }
 }
 
 static int launch(bp_handle *h, int mode, const double *actions, const unsigned char *mask, unsigned char *obs, double *reward,
@@ -461,6 +538,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         else
             hipLaunchKernelGGL(k_reset_copy, dim3(h->num_envs), dim3(256), 0, st, h->P, h->D, mask, info);
         HIPCHK(h, hipGetLastError());
+        if (h->P.env_kind == BP_ENV_SHIP_ICE) {
+            hipLaunchKernelGGL(k_episode_metrics, dim3((h->num_envs + 255) / 256), dim3(256), 0, st, h->P, h->D, mode == MODE_STEP ? 0 : 1, mask);
+            HIPCHK(h, hipGetLastError());
+        }
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e1, st));
     if (raster && obs) {
@@ -478,7 +559,7 @@ int bp_reset(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, double *info, 
 {
     if (!h) return BP_EINVAL;
     if (!h->loaded) return fail(h, BP_ESTATE, "bp_load_scenarios has not been called");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     const bool save = h->timing;
     h->timing = false; // resets are not part of the per-step kernel timing
     const int rc = launch(h, MODE_RESET, nullptr, env_mask, obs, nullptr, nullptr, nullptr, info, (hipStream_t)stream, true, true);
@@ -492,7 +573,7 @@ int bp_step(bp_handle *h, const double *actions, uint8_t *obs, double *reward, u
 {
     if (!h || !actions) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_step before bp_load_scenarios/bp_reset");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     return launch(h, MODE_STEP, actions, nullptr, obs, reward, terminated, truncated, info, (hipStream_t)stream, true, true);
 }
 
@@ -501,7 +582,7 @@ int bp_step_physics(bp_handle *h, const double *actions, double *reward, uint8_t
 {
     if (!h || !actions) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_step_physics before bp_load_scenarios/bp_reset");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     return launch(h, MODE_STEP, actions, nullptr, nullptr, reward, terminated, truncated, info, (hipStream_t)stream, true, false);
 }
 
@@ -509,7 +590,7 @@ int bp_observe(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void *stream
 {
     if (!h || !obs) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_observe before bp_load_scenarios/bp_reset");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     return launch(h, MODE_STEP, nullptr, env_mask, obs, nullptr, nullptr, nullptr, nullptr, (hipStream_t)stream, false, true);
 }
 
@@ -518,7 +599,7 @@ int bp_observe_global(bp_handle *h, const uint8_t *env_mask, uint8_t *obs, void 
     if (!h || !obs) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "bp_observe_global before bp_load_scenarios/bp_reset");
     if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_ESTATE, "global observation exists for ship-ice only");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     const int cell_px = (int)(0.2 * h->cfg.m_to_pix); // grid_width 0.2 m (ship_ice_env.py:97), block = int(0.2 * 25) = 5 px
     if (cell_px <= 0 || h->P.grid_h % cell_px || h->P.grid_w % cell_px) return fail(h, BP_EINVAL, "raster is not a multiple of the cell");
     const size_t lds = (size_t)4 * ((h->P.grid_h * h->P.grid_w + 31) / 32);
@@ -580,16 +661,36 @@ int bp_get_world_polys(bp_handle *h, double *out, int32_t *counts, void *stream)
 {
     if (!h || !out || !counts) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     hipLaunchKernelGGL(k_export_polys, dim3(h->num_envs), dim3(256), 0, (hipStream_t)stream, h->P, h->D, out, counts);
     HIPCHK(h, hipGetLastError());
     return BP_OK;
 }
+double bp_start_uniform(uint64_t seed, int64_t global_env_id, int64_t episode) { return bp_start_u01(seed, global_env_id, episode); }
+
+int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *stream)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_EINVAL, "episode metrics are kept for ship-ice handles only");
+    BP_DEVICE(h);
+    if (rows) HIPCHK(h, hipMemcpyAsync(rows, h->D.m_rows, sizeof(double) * BP_EPM_COUNT * h->num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->D.m_count, sizeof(unsigned) * h->num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BP_OK;
+}
+
+int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream)
+{
+    if (!in_dev || !out_dev || n < 0) return BP_EINVAL;
+    hipLaunchKernelGGL(k_debug_round2, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, n);
+    return hipGetLastError() == hipSuccess ? BP_OK : BP_EHIP;
+}
+
 int bp_get_body_state(bp_handle *h, double *out, void *stream)
 {
     if (!h || !out) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     hipLaunchKernelGGL(k_export_bodies, dim3(h->num_envs), dim3(256), 0, (hipStream_t)stream, h->P, h->D, out);
     HIPCHK(h, hipGetLastError());
     return BP_OK;
@@ -601,7 +702,7 @@ int bp_costmap_update(bp_handle *h, const bp_costmap_config *cfg, const double *
     if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_EINVAL, "bp_costmap_update: ship-ice handles only");
     const int H = (int)(cfg->m * cfg->scale), W = (int)(cfg->n * cfg->scale);
     if (!(cfg->scale > 0) || H <= 0 || W <= 0 || cfg->margin < 0 || 2 * cfg->margin > W) return fail(h, BP_EINVAL, "bp_costmap_update: bad grid");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     hipStream_t st = (hipStream_t)stream;
     const size_t total = (size_t)h->num_envs * H * W;
     const int nblk = (int)std::min<size_t>((total + 255) / 256, 65535);
@@ -617,7 +718,7 @@ int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream)
 {
     if (!h || !out) return BP_EINVAL;
     if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     hipLaunchKernelGGL(k_export_lowdim, dim3(h->num_envs), dim3(256), 0, (hipStream_t)stream, h->P, h->D, out);
     HIPCHK(h, hipGetLastError());
     return BP_OK;
@@ -643,7 +744,8 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     memset(&h->cfg, 0, sizeof(h->cfg));
     h->bdcfg = *cfg;
     h->num_envs = num_envs; h->env_offset = env_id_offset; h->device = device;
-    if (hipSetDevice(device) != hipSuccess) { delete h; return BP_ENODEVICE; }
+    DevGuard _dg(device);
+    if (!_dg.ok) { delete h; return BP_ENODEVICE; }
     memset(&h->D, 0, sizeof(h->D));
     memset(&h->Q, 0, sizeof(h->Q));
     DevParams &P = h->P;
@@ -693,7 +795,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if (!h || T <= 0 || nbox <= 0 || nbox > BD_MAXBOX || ns <= 0 || !starts || !boxes || !sverts || !scount || !spose || !srad || !stype) return BP_EINVAL;
     if (h->loaded) return fail(h, BP_ESTATE, "scenarios already loaded");
     if (h->P.env_kind != BP_ENV_BOX) return fail(h, BP_ESTATE, "handle was created for another environment");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     using namespace bpgeom;
     const bp_bd_config &cf = h->bdcfg;
     std::vector<std::vector<Shape>> trials(T);
@@ -891,7 +993,7 @@ int bp_bd_get_state(bp_handle *h, uint8_t *alive, double *waypoints, int32_t *nw
 {
     if (!h) return BP_EINVAL;
     if (!h->loaded || h->P.env_kind != BP_ENV_BOX) return fail(h, BP_ESTATE, "not a loaded box-delivery handle");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     const size_t E = h->num_envs;
     if (alive) HIPCHK(h, hipMemcpy(alive, h->Q.alive, E * BD_MAXBOX, hipMemcpyDeviceToHost));
@@ -904,7 +1006,7 @@ int bp_get_num_bodies(bp_handle *h, int32_t *out_host)
 {
     if (!h || !out_host) return BP_EINVAL;
     if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out_host, h->D.e_nb, sizeof(int) * h->num_envs, hipMemcpyDeviceToHost));
     return BP_OK;
@@ -914,7 +1016,7 @@ int bp_check_errors(bp_handle *h, int32_t *out_host)
 {
     if (!h) return BP_EINVAL;
     if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     std::vector<int> e(h->num_envs);
     HIPCHK(h, hipMemcpy(e.data(), h->D.e_err, sizeof(int) * h->num_envs, hipMemcpyDeviceToHost));
@@ -929,7 +1031,7 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 {
     if (!h || !out_host) return BP_EINVAL;
     if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out_host, h->D.e_cost, sizeof(unsigned) * h->num_envs, hipMemcpyDeviceToHost));
     return BP_OK;
@@ -946,7 +1048,7 @@ int bp_enable_timing(bp_handle *h, int32_t on)
 int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32_t *launches)
 {
     if (!h) return BP_EINVAL;
-    HIPCHK(h, hipSetDevice(h->device));
+    BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     double p = 0, r = 0;
     const int n = (int)(h->ev_used / 3);
@@ -968,7 +1070,7 @@ int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32
 int bp_set_resettle(bp_handle *h, int32_t on)
 {
     if (!h) return BP_EINVAL;
-    h->resettle = on != 0;
+    h->resettle = (on != 0) || (h->P.random_start != 0); // per-episode start poses always settle in place
     return BP_OK;
 }
 

@@ -32,6 +32,9 @@ struct DevParams {
     double ship_verts[BP_MAX_SHIP_VERTS][2];
     double ship_head[2], ship_tail[2];
     int obs_h, obs_w, grid_h, grid_w;
+    int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
+    double start_x_range, ship_mass;
+    unsigned long long start_seed;
 };
 
 // All device arrays of one handle.  "sc_" = scenario (per trial, read-only), others = per-env state.
@@ -68,6 +71,13 @@ struct DevPtrs {
     // persisted arbiter slots [E][ACAP]
     unsigned *a_key, *a_stamp, *a_sc, *a_h0, *a_h1;
     double *a_d;             // [E][ACAP][14] jn0 jt0 jn1 jt1 nx ny r1x0 r1y0 r2x0 r2y0 r1x1 r1y1 r2x1 r2y1
+    // result of the last step per env (read by k_episode_metrics) and the on-device episode metrics
+    double *e_lastrew;       // [E]
+    int *e_lastflag;         // [E] bit0 terminated, bit1 trial_success
+    double *m_acc;           // [E][8] episode reward, path length l0, previous rounded x, y, L, steps, total_work, success
+    double *m_rows;          // [E][BP_EPM_COUNT] most recently finished episode
+    unsigned *m_count;       // [E] finished episodes
+    unsigned char *m_open;   // [E] an episode is running (reset seen, not yet terminated)
     // debug
     double *dbg;             // optional [substeps][nbcap][3] pose trace of env dbg_env
     int dbg_env;
@@ -126,6 +136,20 @@ __device__ __forceinline__ void bp_sincos(double x, double &sn, double &cs)
     else if (q == 1) { sn = kc; cs = -ks; }
     else if (q == 2) { sn = -ks; cs = -kc; }
     else { sn = -kc; cs = ks; }
+}
+
+// counter RNG of the per-episode start pose (include/benchpush_amd.h: bp_start_uniform)
+__host__ __device__ inline unsigned long long bp_splitmix64(unsigned long long x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__host__ __device__ inline double bp_start_u01(unsigned long long seed, long long gid, long long episode)
+{
+    const unsigned long long k = bp_splitmix64(seed ^ bp_splitmix64(((unsigned long long)gid << 32) + (unsigned long long)episode));
+    return (double)(k >> 11) * (1.0 / 9007199254740992.0);
 }
 
 // wave-wide helpers (64 lanes) ---------------------------------------------------------------------------

@@ -261,7 +261,11 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
                 L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255;
                 if (i < P.nkin) { L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, 0.0); L.sb[i] = mk2(0.0, 0.0); }
                 if (i < E.nb) {
-                    const double4 ps = D.sc_pose[tb + i];
+                    double4 ps = D.sc_pose[tb + i];
+                    if (P.random_start && i == 0 && !tmpl) { // ship_ice_env.py:201-203 with a counter RNG keyed (env, episode)
+                        const double u = bp_start_u01(P.start_seed, P.env_offset + env, episode);
+                        ps.x = 1 + u * (P.start_x_range - 1); ps.y = 1.0; ps.z = BP_PI / 2;
+                    }
                     double sn, cs;
                     bp_sincos(ps.z, sn, cs);
                     E.pxy[i] = mk2(ps.x, ps.y); E.ang[i] = ps.z; E.rot[i] = mk2(cs, sn);
@@ -458,6 +462,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             if (reward) reward[env] = rwd;
             if (terminated) terminated[env] = (unsigned char)term;
             if (truncated) truncated[env] = 0;
+            D.e_lastrew[env] = rwd; D.e_lastflag[env] = term | (success << 1);
             if (info) {
                 double *o = info + (size_t)env * BP_INFO_COUNT;
                 o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa; o[BP_I_TOTAL_WORK] = total_work; o[BP_I_WORK] = work;
@@ -489,6 +494,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             if (reward) reward[env] = rwd;
             if (terminated) terminated[env] = (unsigned char)term;
             if (truncated) truncated[env] = 0;
+            D.e_lastrew[env] = rwd; D.e_lastflag[env] = term | (success << 1);
             if (info) {
                 double *o = info + (size_t)env * BP_INFO_COUNT;
                 o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa; o[BP_I_TOTAL_WORK] = total_work; o[BP_I_WORK] = work;

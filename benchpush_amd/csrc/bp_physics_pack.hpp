@@ -1346,6 +1346,7 @@ __device__ __forceinline__ void pk_body(const DevParams &P, const DevPtrs &D, co
             if (reward) reward[env] = rwd;
             if (terminated) terminated[env] = (unsigned char)term;
             if (truncated) truncated[env] = 0;
+            D.e_lastrew[env] = rwd; D.e_lastflag[env] = term | (success << 1);
             if (info) {
                 double *o = info + (size_t)env * BP_INFO_COUNT;
                 o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa; o[BP_I_TOTAL_WORK] = total_work; o[BP_I_WORK] = work[e];

@@ -53,7 +53,12 @@ class BatchedMazeEnv(BatchedShipIceEnv):
             raise _lib.BpError("BatchedMazeEnv needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.L = _lib.load()
         self.cfg = _maze_cfg(cfg)
+        if self.cfg.get("random_start", False):
+            # maze_NAMO_env.py:229-238 re-draws the robot start per episode (rejection-sampled against walls and boxes); the batched
+            # layouts carry one start pose -- refuse instead of silently running fixed starts
+            raise NotImplementedError("maze-NAMO-v0: cfg.random_start is not supported by the batched GPU environment")
         self.num_envs = int(num_envs)
+        self.env_id_offset = int(env_id_offset)
         self.device = torch.device(device)
         self.params = maze_physics_params(self.cfg)
         self.goal = (self.cfg.env.goal_x, self.cfg.env.goal_y)

@@ -83,6 +83,7 @@ class BatchedShipIceEnv(_BatchedBase):
         self.cfg = merge_user_cfg(default_cfg("ship_ice"), cfg)
         assert self.cfg.concentration in [0.1, 0.2, 0.3, 0.4, 0.5]  # ship_ice_env.py:75
         self.num_envs = int(num_envs)
+        self.env_id_offset = int(env_id_offset)
         self.device = torch.device(device)
         self.params = ship_ice_physics_params(self.cfg)
         self.goal = (0, self.cfg.goal_y)
@@ -190,6 +191,19 @@ class BatchedShipIceEnv(_BatchedBase):
                                                             _ptr(out), self._stream()), "bp_costmap_update")
         return out
 
+    def episode_metrics(self):
+        """On-device ShipIceMetric: (rows [E, 6] float64 = efficiency, effort, episode reward, success, episode length, total_work of
+        each env's most recently finished episode; counts [E] int32 = episodes finished so far).  Device tensors; rows of envs with
+        count 0 are zero.  This is the block benchpush_amd.parallel.allgather_episode_metrics carries between GPUs."""
+        rows = torch.zeros((self.num_envs, 6), dtype=torch.float64, device=self.device)
+        cnt = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self.L, self.h, self.L.bp_get_episode_metrics(self.h, _ptr(rows), _ptr(cnt), self._stream()), "bp_get_episode_metrics")
+        return rows, cnt
+
+    def start_uniform(self, env, episode):
+        """The uniform of the counter RNG that places env's ship in `episode` when cfg.random_start is set (bp_start_uniform)."""
+        return float(self.L.bp_start_uniform(int(self.params["start_seed"]), int(self.env_id_offset) + int(env), int(episode)))
+
     def num_bodies(self):
         out = np.zeros(self.num_envs, np.int32)
         _lib.check(self.L, self.h, self.L.bp_get_num_bodies(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_num_bodies")
@@ -230,8 +244,9 @@ class ShipIceEnv(Env):
 
     Same surface as the reference ShipIceEnv (ship_ice_env.py:33-355): ``reset(seed, options) -> (obs, info)``,
     ``step(action) -> (obs, reward, terminated, False, info)`` with numpy observations and the reference's info keys.
-    ``random_start`` draws from python's ``random`` like the reference (:201-203) -- that needs a per-episode start
-    pose, which the trial tables do not carry, so it is applied by re-creating the single trial on reset.
+    ``cfg.random_start`` (:201-203) re-draws the start x of every episode -- from a counter RNG keyed (start_seed, env, episode)
+    instead of python's global ``random`` (``BatchedShipIceEnv.start_uniform`` reproduces the draw) -- and every reset then runs
+    the 1000 settle sub-steps with the ship at that pose, like the reference.
     """
 
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
@@ -293,7 +308,8 @@ class ShipIceEnv(Env):
 
     def step(self, action):
         self.t += 1
-        a = torch.tensor([float(np.asarray(action, dtype=np.float32).reshape(-1)[0])], dtype=torch.float64)
+        # the action keeps the caller's precision, like `action * self.max_yaw_rate_step` in the reference (ship_ice_env.py:265)
+        a = torch.tensor([float(np.asarray(action, dtype=np.float64).reshape(-1)[0])], dtype=torch.float64)
         self._b.step(a)
         it = self._b.info[0].cpu().numpy()
         reward = float(self._b.reward[0].item())

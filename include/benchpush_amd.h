@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 5
+#define BP_ABI_VERSION 6
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -92,7 +92,20 @@ typedef struct bp_config {
     double k_increment;      /* 150, maze_NAMO_env.py:82 */
     double wall_radius;      /* 0.5, sim_utils.py:177 */
     double obstacle_size;    /* cfg.obstacle_size */
+    /* ---- ship-ice: per-episode start pose and metric constants ---- */
+    int32_t random_start;    /* cfg.random_start (ship_ice_env.py:201-203): start = (1 + u * (start_x_range - 1), 1.0, pi/2) with u drawn per
+                                (env, episode) from a counter RNG instead of python's global `random` (bp_start_uniform below); every reset
+                                then re-runs the settle sub-steps, because the settled field depends on where the ship sits */
+    int32_t _pad2;
+    double start_x_range;    /* cfg.start_x_range */
+    uint64_t start_seed;     /* key of the counter RNG */
+    double ship_mass;        /* cfg.ship.mass: m0 of ShipIceMetric.compute_effort_score (ship_ice_metric.py:62-69) */
 } bp_config;
+
+/* The uniform in [0, 1) that bp_reset draws for (global env id, episode index) when random_start is set: the top 53 bits of
+ * splitmix64(seed ^ splitmix64(global_env_id * 2^32 + episode)) / 2^53.  Exposed so that callers (and the parity tests) can
+ * reproduce start poses on the host. */
+double bp_start_uniform(uint64_t seed, int64_t global_env_id, int64_t episode);
 
 typedef struct bp_handle bp_handle;
 
@@ -166,6 +179,20 @@ int bp_get_world_polys(bp_handle *h, double *out, int32_t *counts, void *stream)
 int bp_get_body_state(bp_handle *h, double *out, void *stream);
 /* low-dimensional observation (ship_ice_env.py:358-370): |centroid| of every floe, device double [E][nb_cap-1][2] */
 int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream);
+
+/* Per-episode metrics accumulated on the device (ship-ice handles): what ShipIceMetric.update / reset keep per episode
+ * (benchpush/common/metrics/ship_ice_metric.py:26-69, base_metric.py:12-16) -- summed reward, path length of the ship integrated from
+ * the state rounded to 2 decimals like info['state'] (ship_ice_env.py:337-339), total_work, success, steps -- updated by every bp_step /
+ * bp_reset.  When an env terminates (or is reset while its episode is still running: eps_complete by truncation) its row is written:
+ *   rows   device double [E][BP_EPM_COUNT] = efficiency, effort, episode reward, success, episode length (steps), total_work
+ *          of the env's most recently finished episode,
+ *   counts device uint32 [E] episodes finished so far.
+ * [E][6] is the block that crosses GPUs (one all-gather per evaluation batch). */
+#define BP_EPM_COUNT 6
+enum { BP_EPM_EFFICIENCY = 0, BP_EPM_EFFORT, BP_EPM_REWARD, BP_EPM_SUCCESS, BP_EPM_LENGTH, BP_EPM_TOTAL_WORK };
+int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *stream);
+/* test hook: out[i] = the device's restatement of python's round(in[i], 2) (device doubles [n]) */
+int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream);
 
 int32_t bp_nb_cap(const bp_handle *h);       /* body slots per env (ship + max floes, padded) */
 int32_t bp_obs_height(const bp_handle *h);

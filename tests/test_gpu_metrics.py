@@ -1,0 +1,226 @@
+"""-m gpu: on-device episode metrics (bp_get_episode_metrics) against the host ShipIceMetric fed step by step, the device's
+round(x, 2), per-episode random starts against the oracle, and the whole-episode soak (capacity flags deep in episodes)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(E, conc, trials, **kw):
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
+    return BatchedShipIceEnv(E, cfg=dict({"concentration": conc}, **kw), trials=trials, device="cuda:0")
+
+
+def test_device_round2_equals_python_round():
+    """info['state'] is rounded with python's round(x, 2) (ship_ice_env.py:337-339); the metric path length is integrated from it."""
+    from benchpush_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-3, 45, 200000), np.arange(-200, 4200) / 100.0, (np.arange(-2000, 42000) + 0.5) / 1000.0,
+                         np.array([0.125, 0.375, 2.675, 1.005, 0.285, -0.125, 0.0, -0.0, 1e-9, 12.345, 39.995, 8.994999999999999])])
+    t = torch.from_numpy(xs).to("cuda:0")
+    out = torch.empty_like(t)
+    assert L.bp_debug_round2(t.data_ptr(), out.data_ptr(), t.numel(), None) == 0
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    want = np.array([round(float(v), 2) for v in xs])
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:5]
+
+
+def test_episode_metrics_equal_host_ship_ice_metric():
+    """Device accumulators == ShipIceMetric.reset / update (ship_ice_metric.py:26-69) driven with the same info dicts; rows appear when
+    an env terminates, and a reset of a running episode closes it as truncated (eps_complete = truncated)."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    from benchpush_amd.metrics import ShipIceMetric
+    E, T = 6, 3
+    trials = default_trials(0.3, T, base_seed=11, goal_y=2.6)
+    env = _mk(E, 0.3, trials, goal_y=2.6)
+    mass = float(env.cfg.ship.mass)
+    host = [ShipIceMetric("x", ship_mass=mass, goal=env.goal) for _ in range(E)]
+
+    def info_dict(row):
+        return {"state": (round(float(row[0]), 2), round(float(row[1]), 2), round(float(row[2]), 2)), "total_work": float(row[3]),
+                "trial_success": bool(row[8])}
+
+    _, info = env.reset()
+    inf = info.cpu().numpy()
+    for e in range(E):
+        host[e].reset(info_dict(inf[e]))
+    rng = np.random.default_rng(3)
+    finished = np.zeros(E, int)
+    lengths = np.zeros(E, int)
+    nrows = 0
+    for t in range(40):
+        a = rng.uniform(-0.4, 0.4, E)
+        _, rew, term, _, info = env.step(torch.from_numpy(a))
+        inf, rw, tm = info.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy().astype(bool)
+        rows, cnt = env.episode_metrics()
+        rows, cnt = rows.cpu().numpy(), cnt.cpu().numpy()
+        lengths += 1
+        for e in range(E):
+            host[e].update(info_dict(inf[e]), float(rw[e]), eps_complete=bool(tm[e]))
+            if tm[e]:
+                finished[e] += 1
+                assert cnt[e] == finished[e]
+                assert rows[e, 2] == host[e].rewards[-1] and rows[e, 3] == float(inf[e, 8])
+                assert rows[e, 4] == lengths[e] and rows[e, 5] == inf[e, 3]
+                assert math.isclose(rows[e, 0], host[e].efficiency_scores[-1], rel_tol=1e-12, abs_tol=0.0)
+                assert math.isclose(rows[e, 1], host[e].effort_scores[-1], rel_tol=1e-12, abs_tol=0.0)
+                nrows += 1
+            else:
+                assert cnt[e] == finished[e]
+        mask = torch.from_numpy(tm.astype(np.uint8))
+        if t == 20:  # truncate env 0 mid-episode: the reset closes its episode with success 0
+            if not tm[0]:
+                host[0].update(info_dict(inf[0]), 0.0, eps_complete=False)  # no-op on the scores; the lists below are made by hand
+                eff, effort, r = 0.0, host[0].compute_effort_score(), host[0].eps_reward
+                mask[0] = 1
+                _, info2 = env.reset(mask)
+                rows2, cnt2 = env.episode_metrics()
+                rows2, cnt2 = rows2.cpu().numpy(), cnt2.cpu().numpy()
+                finished[0] += 1
+                assert cnt2[0] == finished[0] and rows2[0, 0] == eff and rows2[0, 3] == 0.0 and rows2[0, 2] == r
+                assert math.isclose(rows2[0, 1], effort, rel_tol=1e-12) and rows2[0, 4] == lengths[0]
+                inf2 = info2.cpu().numpy()
+                for e in range(E):
+                    if mask[e]:
+                        host[e].reset(info_dict(inf2[e]))
+                        lengths[e] = 0
+                continue
+        if tm.any():
+            _, info2 = env.reset(mask)
+            inf2 = info2.cpu().numpy()
+            for e in range(E):
+                if tm[e]:
+                    host[e].reset(info_dict(inf2[e]))
+                    lengths[e] = 0
+    assert nrows >= 6
+    env.check_errors()
+    env.close()
+
+
+def test_random_start_matches_oracle_and_redraws_every_episode():
+    """cfg.random_start (ship_ice_env.py:201-203): start = (1 + u * (start_x_range - 1), 1, pi/2) drawn per (env, episode) from the counter
+    RNG, then the 1000 settle sub-steps with the ship there; bit-identical to the oracle reset with that start."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    from oracle.oracle import OracleShipIce
+    E, T = 3, 2
+    trials = default_trials(0.3, T, base_seed=5, goal_y=2.4)
+    env = _mk(E, 0.3, trials, goal_y=2.4, random_start=True, start_x_range=7, start_seed=99)
+    c = env.cfg
+    orcs = [OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail) for _ in range(E)]
+    eps = [0] * E
+
+    def start_of(e):
+        u = env.start_uniform(e, eps[e])
+        assert 0.0 <= u < 1.0
+        return (1 + u * (7 - 1), 1.0, np.pi / 2)
+
+    obs, info = env.reset()
+    starts = set()
+    for e in range(E):
+        oo, _ = orcs[e].reset(trials[(e + eps[e]) % T], start=start_of(e))
+        assert np.array_equal(obs[e].cpu().numpy(), oo)
+        starts.add(round(start_of(e)[0], 9))
+    rng = np.random.default_rng(1)
+    nreset = 0
+    for t in range(24):
+        a = rng.uniform(-0.3, 0.3, E)
+        obs, rew, term, _, info = env.step(torch.from_numpy(a))
+        bs = env.body_state().cpu().numpy()
+        tm = term.cpu().numpy().astype(bool)
+        for e in range(E):
+            oo, orr, ot, _ = orcs[e].step(float(a[e]))
+            nb = len(orcs[e].bodies())
+            assert np.array_equal(bs[e, :nb], orcs[e].bodies()) and float(rew[e]) == orr and bool(tm[e]) == ot
+            assert np.array_equal(obs[e].cpu().numpy(), oo)
+        if tm.any():
+            obs, _ = env.reset(term)
+            for e in range(E):
+                if tm[e]:
+                    eps[e] += 1
+                    nreset += 1
+                    oo, _ = orcs[e].reset(trials[(e + eps[e]) % T], start=start_of(e))
+                    assert np.array_equal(obs[e].cpu().numpy(), oo)
+                    starts.add(round(start_of(e)[0], 9))
+    assert nreset >= 2 and len(starts) >= 4
+    env.check_errors()
+    env.close()
+
+
+@pytest.mark.parametrize("E,conc,steps", [(4096, 0.3, 300), (2048, 0.5, 150)])
+def test_whole_episode_soak_no_capacity_flags(E, conc, steps):
+    """Episodes run to their 300-step limit (environments/__init__.py:6) with auto-reset; the in-kernel capacities (arbiter slots,
+    velocity slots, neighbour lists, colours) must never be hit deep in an episode -- check_errors() every 25 steps."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    trials = default_trials(conc, 50, base_seed=0)
+    env = _mk(E, conc, trials)
+    env.reset()
+    g = torch.Generator(device=env.device)
+    g.manual_seed(2024)
+    age = torch.zeros(E, dtype=torch.int64, device=env.device)
+    done = 0
+    for t in range(steps):
+        a = (torch.rand(E, generator=g, device=env.device, dtype=torch.float64) * 2 - 1) * 0.5  # gentler turns: longer episodes
+        _, rew, term, _, info = env.step(a)
+        age += 1
+        m = term.bool() | (age >= 300)
+        done += int(m.sum().item())
+        age[m] = 0
+        env.reset(m)
+        if t % 25 == 24:
+            env.check_errors()
+            assert bool(torch.isfinite(rew).all()) and bool(torch.isfinite(info).all())
+    env.check_errors()
+    rows, cnt = env.episode_metrics()
+    assert int(cnt.sum().item()) == done and done > 0
+    fin = rows[cnt > 0]
+    assert bool(((fin[:, 0] >= 0) & (fin[:, 0] <= 1.0 + 1e-9)).all()) and bool(((fin[:, 1] > 0) & (fin[:, 1] <= 1.0)).all())
+    env.close()
+
+
+def test_sampled_envs_bit_exact_over_300_steps():
+    """8 envs x 300 steps against the oracle (the parity suite's other cases stop at 40 steps): body state, rewards, termination and
+    observations stay identical through whole episodes, resets included."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    from oracle.oracle import OracleShipIce
+    E, T = 8, 4
+    trials = default_trials(0.3, T, base_seed=40)
+    env = _mk(E, 0.3, trials)
+    c = env.cfg
+    orcs = [OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail) for _ in range(E)]
+    obs, _ = env.reset()
+    eps = [0] * E
+    for e in range(E):
+        oo, _ = orcs[e].reset(trials[e % T])
+        assert np.array_equal(obs[e].cpu().numpy(), oo)
+    rng = np.random.default_rng(8)
+    age = np.zeros(E, int)
+    for t in range(300):
+        a = rng.uniform(-1, 1, E) * 0.35
+        obs, rew, term, _, info = env.step(torch.from_numpy(a))
+        bs = env.body_state().cpu().numpy()
+        tm = term.cpu().numpy().astype(bool)
+        ob = obs.cpu().numpy() if t % 10 == 0 else None
+        for e in range(E):
+            oo, orr, ot, _ = orcs[e].step(float(a[e]), observe=ob is not None)
+            nb = len(orcs[e].bodies())
+            assert np.array_equal(bs[e, :nb], orcs[e].bodies()), (t, e)
+            assert float(rew[e]) == orr and bool(tm[e]) == ot, (t, e)
+            if ob is not None:
+                assert np.array_equal(ob[e], oo), (t, e)
+        age += 1
+        m = tm | (age >= 300)
+        if m.any():
+            obs, _ = env.reset(torch.from_numpy(m.astype(np.uint8)))
+            for e in range(E):
+                if m[e]:
+                    eps[e] += 1
+                    age[e] = 0
+                    oo, _ = orcs[e].reset(trials[(e + eps[e]) % T])
+                    assert np.array_equal(obs[e].cpu().numpy(), oo)
+    env.check_errors()
+    env.close()
