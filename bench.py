@@ -5,11 +5,17 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one batched env.step() over all envs of a rank: 400 physics sub-steps + work/reward + the 4x150x150 u8
-observation raster, followed by the auto-reset (new trial + 1000 settle sub-steps) of the envs that terminated --
-everything an RL collector needs per step.  Inputs (scenarios, actions) are resident in HBM before the timed region.
-Multi-GPU: environments shard over ranks (4096 per GPU, weak scaling, no data-path collective); the only collective
-is the all-gather of per-rank episode counters after the timed region.
+One "step" = one batched env.step() over all envs of a rank: 400 physics sub-steps + work/reward + the on-device episode
+metrics + the 4x150x150 u8 observation raster, followed by the auto-reset of the envs that terminated.  What is timed for a
+reset is a copy of the trial's settled template (each trial's 1000 settle sub-steps run once, at load: reset() is a pure
+function of the trial when cfg.random_start is off -- tested identical to settling in place) plus its first observation.
+Inputs (scenarios, actions) are resident in HBM before the timed region.  `value` is measured from freshly reset episodes
+(steps W..W+K); `steady_state` repeats the measurement with the envs spread uniformly over the phases of an episode.
+Multi-GPU: environments shard over ranks (4096 per GPU, weak scaling, no data-path collective); the only collective is the
+all-gather of the [E/R, 6] episode-metric rows after the timed region (RCCL over xGMI).
+
+    --config c2 (default)  BASELINE.json configs[1]: 4096 envs per GPU, 30 % concentration
+    --config c5            BASELINE.json configs[4]: 4096 envs per GPU, 50 % concentration (32 768 envs on 8 GPUs)
 """
 import argparse
 import json
@@ -77,6 +83,37 @@ def cpu_baseline(env, trials):
                       "threads, step loop only (resets untimed), %.2f s wall = %.0f core-seconds" % (nenv, steps, cores, sec, sec * cores)}
 
 
+def cpu_baseline_single_thread(env):
+    """SURVEY 8d / BASELINE.md 3 (config C1): ONE env, 10 % concentration, action 0, one host thread -- the latency leg of the CPU
+    baseline (the reference's own loop is one env in one python process)."""
+    from benchpush_amd.config import default_cfg, merge_user_cfg, ship_ice_physics_params
+    from benchpush_amd.envs.ship_ice import default_trials
+    from oracle.oracle import OracleShipIce
+
+    cfg = merge_user_cfg(default_cfg("ship_ice"), {"concentration": 0.1})
+    trial = default_trials(0.1, 1, base_seed=0)[0]
+    o = OracleShipIce(ship_ice_physics_params(cfg), cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+    o.reset(trial)
+    n, t0 = 0, time.perf_counter()
+    while n < 300 and time.perf_counter() - t0 < 6.0:
+        _, _, term, _ = o.step(0.0)
+        n += 1
+        if term:
+            o.reset(trial)
+    sec = time.perf_counter() - t0
+    return {"value": n / sec, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "1 env, 10%% concentration (%d floes), action 0, %d env.step() incl. raster, one thread, %.2f s" % (len(trial["obstacles"]), n, sec)}
+
+
+def profile_sourced(name):
+    """Numbers that need hardware counters come from the committed rocprofv3 passes of the same kernels, tagged with their source."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
 def cpu_baseline_box(env, trials):
     """box-delivery oracle (oracle/bp_oracle_bd.c) on one host core: a bounded sample of the same trials and action stream."""
     from benchpush_amd import box_delivery_scenario as S
@@ -107,12 +144,17 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--concentration", type=float, default=0.3)
     ap.add_argument("--trials", type=int, default=100)
+    ap.add_argument("--config", default="c2", choices=["c2", "c5"], help="c2 = BASELINE.json configs[1] (30 %%), c5 = configs[4] (50 %%, 4096 envs per GPU)")
+    ap.add_argument("--no-steady-state", action="store_true", help="skip the staggered-phase (steady-state) measurement")
+    ap.add_argument("--steady-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-auto-reset", action="store_true")
     ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze", "box", "area"],
                     help="ship-ice = BASELINE.json configs[1] (the headline); maze = configs[2], box = configs[3] (box-delivery-v0, "
                          "12 boxes), both informational")
     args = ap.parse_args()
+    if args.config == "c5":
+        args.concentration = 0.5
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -137,7 +179,7 @@ def main():
     torch.cuda.set_device(device)
 
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
-    from benchpush_amd.parallel import allgather_episode_metrics
+    from benchpush_amd.parallel import allgather_episode_metrics, gather_episode_block, summarize_episode_block
 
     E = args.envs_per_gpu
     if args.env == "maze":
@@ -165,7 +207,10 @@ def main():
     # actions ~ U(-1,1), counter-style: a generator keyed by (seed, rank); resident in HBM before timing
     g = torch.Generator(device=device)
     g.manual_seed(1234 + rank)
-    actions = (torch.rand((K + W, E), generator=g, device=device, dtype=torch.float64) * 2 - 1).float().double()
+    PH = 40                                                       # phases of the staggered (steady-state) measurement
+    KS = 0 if (args.no_steady_state or args.env != "ship-ice") else args.steady_steps
+    extra = (PH + KS) if KS > 0 else 0
+    actions = (torch.rand((K + W + extra, E), generator=g, device=device, dtype=torch.float64) * 2 - 1).float().double()
 
     env.reset()
     ep_done = torch.zeros(E, dtype=torch.int64, device=device)
@@ -206,34 +251,92 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
-    # episode metrics cross GPUs once, after the timed region (RCCL all-gather over xGMI)
+    # episode metrics cross GPUs once, after the timed region (RCCL all-gather over xGMI): per-rank counters and, for ship-ice, the
+    # [E/R, 6] rows of the on-device ShipIceMetric (efficiency, effort, reward, success, length, total_work per finished episode)
     local = torch.stack([ep_done.sum(), ep_success.sum()]).to(torch.float64).reshape(1, 2).to(coll_device)
     allm = allgather_episode_metrics(local, dist)
+    episode_summary = None
+    if args.env == "ship-ice":
+        rows, cnt = env.episode_metrics()
+        torch.cuda.synchronize()
+        allr, allc = gather_episode_block(rows.to(coll_device), cnt.to(coll_device), dist)
+        episode_summary = summarize_episode_block(allr, allc)
+        episode_summary["gathered_shape"] = [int(allr.shape[0]), int(allr.shape[1])]
     total_envs = E * world
     value = total_envs * K / tmax
+
+    # ---- steady state: spread the envs uniformly over the phases of an episode (forced resets of E/PH envs per step, untimed), then
+    #      time KS more steps; episodes run ~36 steps under U(-1,1) actions, so freshly reset batches are lighter than the mix ----
+    steady = None
+    if KS > 0:
+        ids = torch.arange(E, device=device)
+        for s_ in range(PH):
+            one_step(W + K + s_)
+            env.reset((ids % PH) == s_)
+        torch.cuda.synchronize()
+        env.kernel_time_ms()
+        env.enable_timing(True)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(W + K + PH, W + K + PH + KS):
+            one_step(t)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - t1
+        sp_ms, sr_ms, sn = env.kernel_time_ms()
+        env.enable_timing(False)
+        env.check_errors()
+        tm2 = torch.tensor([dts], dtype=torch.float64, device=coll_device)
+        if dist is not None:
+            dist.all_reduce(tm2, op=dist.ReduceOp.MAX)
+        dts = float(tm2.item())
+        steady = {"value": total_envs * KS / dts, "unit": "env-steps/s", "steps": KS, "ms_per_step": dts / KS * 1e3, "physics_ms": sp_ms,
+                  "raster_ms": sr_ms, "phases": PH,
+                  "how": "envs pre-advanced to uniformly spread episode steps (E/%d envs force-reset per step over %d untimed steps), "
+                         "then %d timed steps with auto-reset" % (PH, PH, KS)}
 
     if rank == 0:
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
+        # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
+        # (profiles/r02_final/pmc.json, written by tools/profile_gpu.sh for the build named inside), never measured in this run
+        pmc = profile_sourced(os.path.join("r02_final", "pmc.json")) if args.env == "ship-ice" else None
+        clock_hz = 2.4e9
         roof = {
             "bound": "hbm",
             "kernel": "k_physics_step",
             "achieved": a_phys * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
-            "achieved_stream": (a_stream - 4 * 150 * 150) * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
+            "binds": "wave issue slots and dependent-instruction latency of one wavefront per env, not HBM and not MFMA: the state stays "
+                     "on-chip for the 400 sub-steps (DESIGN.md section 4)",
             "raster_kernel": {"kernel": "k_observe", "achieved": 4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 if rast_ms > 0 else None,
-                              "ms": rast_ms},
+                              "ms": rast_ms, "frac": (4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rast_ms > 0 else None},
             "physics_ms": phys_ms, "launches": nlaunch,
             "bytes_per_env_step": {"A_min": a_min, "A_stream": a_stream, "k_physics_min": a_phys},
-            "note": "k_physics keeps state on-chip for 400 sub-steps; it is latency/VALU-bound, not HBM-bound (DESIGN.md)",
+            "hypothetical_stream_design": {"GB/s": (a_stream - 4 * 150 * 150) * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
+                                           "note": "bytes a design that streams the body state from HBM every sub-step would move, divided by "
+                                                   "THIS kernel's time; nothing achieves it (SURVEY 8d asks for both accountings)"},
         }
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
-        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                roof["traffic"] = json.load(open(tpath)).get("k_physics_step_hbm_bytes_per_launch")
-            except Exception:
-                pass
+        if pmc and phys_ms > 0:
+            per = pmc.get("per_launch", {})
+            insts = sum(per.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+            scale = E / float(pmc.get("envs", E))
+            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/r02_final/pmc.json (rocprofv3 --pmc passes of build %s, %s envs; not measured in this run)" % (
+                pmc.get("build", "?"), pmc.get("envs", "?"))
+            roof["issue"] = {
+                "wave_instructions_per_launch": insts * scale,
+                "frac": insts * scale / (1024 * clock_hz * phys_ms * 1e-3),
+                "unit": "wave-instructions per SIMD-cycle (1024 SIMDs x 2.4 GHz x kernel time; VALU+SALU+LDS+VMEM)",
+                "valu_frac": per.get("SQ_INSTS_VALU", 0.0) * scale * 4 / (1024 * clock_hz * phys_ms * 1e-3),
+                "lanes_active": pmc.get("lanes_active"),
+                "source": roof["traffic_source"],
+            }
         out = {
             "metric": "env-steps/sec at N=4096 envs (ship-ice-v0), 1/2/4/8 MI355X" if args.env == "ship-ice"
                       else "env-steps/sec at N=4096 envs (maze-NAMO-v0), informational" if args.env == "maze"
@@ -254,16 +357,22 @@ def main():
                                     "per env.step (about 950), robot spfa map, 224x224x4 u8 obs, auto-reset" % E),
                        "envs_per_gpu": E, "total_envs": total_envs, "concentration": args.concentration,
                        "substeps_per_step": env.params["steps"], "auto_reset": not args.no_auto_reset,
-                       "episodes_finished": int(allm[:, 0].sum().item()), "episodes_success": int(allm[:, 1].sum().item())},
+                       "episodes_finished": int(allm[:, 0].sum().item()), "episodes_success": int(allm[:, 1].sum().item()),
+                       "config": args.config if args.env == "ship-ice" else None},
             "substeps_per_s": value * env.params["steps"],
             "roofline": roof,
         }
+        if steady is not None:
+            out["steady_state"] = steady
+        if episode_summary is not None:
+            out["episode_metrics"] = episode_summary
         if args.env in ("box", "area"):
             out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish in physics_ms)"
             out["roofline"]["note"] = "persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c)"
             out["substeps_per_s"] = None
         if world == 1 and not args.no_cpu_baseline and args.env == "ship-ice":
             out["cpu_baseline"] = cpu_baseline(env, trials)
+            out["cpu_baseline"]["single_thread"] = cpu_baseline_single_thread(env)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if world == 1 and not args.no_cpu_baseline and args.env == "box":
             out["cpu_baseline"] = cpu_baseline_box(env, trials)

@@ -162,6 +162,21 @@ local = torch.arange(lo, hi, dtype=torch.float64).reshape(-1, 1) * torch.tensor(
 out = allgather_episode_metrics(local, dist)
 exp = torch.arange(0, 10, dtype=torch.float64).reshape(-1, 1) * torch.tensor([[1.0, 10.0, 100.0]], dtype=torch.float64)
 assert torch.equal(out, exp), (rank, out)
+# the real payload: [E/R, 6] episode rows + counts of this rank's env shard -> the job's block in global env order
+from benchpush_amd.parallel import gather_episode_block, summarize_episode_block
+E = 12
+def rows_of(lo, hi):
+    g = torch.arange(lo, hi, dtype=torch.float64)
+    rows = torch.stack([0.5 + g / 100, 0.9 - g / 100, -3.0 * g, (g %% 2), 30 + g, 0.25 * g], dim=1)
+    cnt = (g %% 3).to(torch.int32)           # every third env has not finished an episode yet
+    return rows, cnt
+lo, hi = shard_range(E, rank, 2)
+rows, cnt = rows_of(lo, hi)
+assert rows.shape == (E // 2, 6)
+allr, allc = gather_episode_block(rows, cnt, dist)
+wr, wc = rows_of(0, E)
+assert allr.shape == (E, 6) and torch.equal(allr, wr) and torch.equal(allc, wc.to(torch.int64))
+assert summarize_episode_block(allr, allc) == summarize_episode_block(wr, wc.to(torch.int64))
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 '''
