@@ -185,6 +185,9 @@ typedef struct orc_env {
     arb_t *arbs; int narb, caparb;
     int *active; int nactive, capactive;
     int *solve, *color; int capsolve; uint32_t *used; long stat_ncol_max;
+    /* order-sensitivity study (orc_set_solve_order): 0 = the documented (colour, key) order, 1 = ascending key, 2 = the order in
+     * which the y-sweep met the pairs this sub-step, 3 = a seeded random permutation per sub-step, 4 = descending key */
+    int solve_order; uint64_t order_seed; int *disc; int capdisc;
     long stamp;
     double curr_dt;
     /* sweep order */
@@ -727,6 +730,10 @@ static void space_step(orc_env *E, double dt)
                 collide_pair(E, sa, sb);
             }
         }
+        if (E->solve_order == 2) {
+            if (E->nactive > E->capdisc) { E->capdisc = E->nactive * 2; E->disc = (int *)realloc(E->disc, (size_t)E->capdisc * sizeof(int)); }
+            memcpy(E->disc, E->active, (size_t)E->nactive * sizeof(int));
+        }
         qsort(E->active, (size_t)E->nactive, sizeof(int), cmp_u32);
     }
     if (E->kind == 2 && E->nevents) bd_run_presolve(E);
@@ -776,6 +783,21 @@ static void space_step(orc_env *E, double dt)
         for (int c = 0; c < ncol; c++)
             for (int k = 0; k < E->nactive; k++) if (E->color[k] == c) E->solve[w++] = E->active[k];
         if (ncol > E->stat_ncol_max) E->stat_ncol_max = ncol;
+        /* Alternative Gauss-Seidel sweeps for the order-sensitivity envelope (tests/test_order_envelope.py): what
+         * Chipmunk's own order -- a by-product of its BB-tree and hash set, not recoverable here -- could do to the results. */
+        if (E->solve_order == 1) memcpy(E->solve, E->active, (size_t)E->nactive * sizeof(int));
+        else if (E->solve_order == 2 && !E->P.brute_force) memcpy(E->solve, E->disc, (size_t)E->nactive * sizeof(int));
+        else if (E->solve_order == 4) { for (int k = 0; k < E->nactive; k++) E->solve[k] = E->active[E->nactive - 1 - k]; }
+        else if (E->solve_order == 3) {
+            memcpy(E->solve, E->active, (size_t)E->nactive * sizeof(int));
+            uint64_t st = E->order_seed ^ ((uint64_t)E->stamp * 0x9E3779B97F4A7C15ull);
+            for (int k = E->nactive - 1; k > 0; k--) {
+                st += 0x9E3779B97F4A7C15ull;
+                uint64_t z = st; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+                int j = (int)(z % (uint64_t)(k + 1));
+                int t = E->solve[k]; E->solve[k] = E->solve[j]; E->solve[j] = t;
+            }
+        }
     }
     /* prestep */
     for (int k = 0; k < E->nactive; k++) {
@@ -868,7 +890,7 @@ void orc_destroy(orc_env *E)
 {
     if (!E) return;
     free(E->bodies); free(E->shapes); free(E->arbs); free(E->active); free(E->order); free(E->prev_wv);
-    free(E->solve); free(E->color); free(E->used); free(E->dist_map); free(E->wall_map); free(E->dist_raw);
+    free(E->solve); free(E->color); free(E->used); free(E->disc); free(E->dist_map); free(E->wall_map); free(E->dist_raw);
     free(E->ras_occ); free(E->ras_foot); free(E->ras_orient); free(E->removed); free(E->events);
     free(E);
 }
@@ -1033,6 +1055,7 @@ void orc_step(orc_env *E, double action, uint8_t *obs, double *reward, int *term
 }
 
 int orc_num_shapes(const orc_env *E) { return E->ns; }
+void orc_set_solve_order(orc_env *E, int mode, uint64_t seed) { E->solve_order = mode; E->order_seed = seed; }
 /* body state: [nb][9] = x, y, a, vx, vy, w, vbx, vby, wb */
 void orc_get_bodies(const orc_env *E, double *out)
 {

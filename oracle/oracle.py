@@ -118,6 +118,12 @@ class OracleShipIce:
         except Exception:
             pass
 
+    def set_solve_order(self, mode, seed=0):
+        """Arbiter sweep order of the solver: 0 = (colour, key) [what the GPU path and every parity test use], 1 = ascending key,
+        2 = order in which the broadphase sweep met the pairs, 3 = seeded random permutation per sub-step, 4 = descending key."""
+        self.L.orc_set_solve_order.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
+        self.L.orc_set_solve_order(self.h, int(mode), int(seed))
+
     def reset(self, trial, start=None, observe=True):
         obs_list = trial["obstacles"]
         counts = np.array([len(o["vertices"]) for o in obs_list], np.int32)

@@ -43,16 +43,20 @@ def _compare_step(env, oracles, actions, tag):
     return res
 
 
-@pytest.mark.parametrize("oc", ["small_empty", "small_columns"])
+@pytest.mark.parametrize("oc", ["small_empty", "small_columns", "large_columns", "large_divider"])
 def test_maps_reset_and_steps_match_oracle(oc):
+    """All four shipped obstacle configs (box_delivery/config.yaml:49,117-120): the 10 x 5 m rooms with 10 boxes and the 10 x 10 m rooms
+    with 20 boxes, columns / divider included."""
     from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
     cfg = default_cfg("box_delivery")
     cfg.env.obstacle_config = oc
-    trials = S.generate_trials(cfg, 5)
-    E = 5
+    large = oc.startswith("large")
+    E = 3 if large else 5
+    trials = S.generate_trials(cfg, E)
+    assert len(trials[0]["boxes"]) == (20 if large else 10)
     env = BatchedBoxDeliveryEnv(E, cfg={"env": {"obstacle_config": oc}}, trials=trials)
     oracles = [_oracle(cfg, trials[e % len(trials)]) for e in range(E)]
-    for t in (0, 3):
+    for t in (0, E - 2):
         m, om = env.maps(t), oracles[t].maps()
         d = m["dims"]
         si, sj, SH, SW = int(d[4]), int(d[5]), int(d[2]), int(d[3])
@@ -66,7 +70,7 @@ def test_maps_reset_and_steps_match_oracle(oc):
     assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
     assert obs.shape == (E, 224, 224, 4)
     rng = np.random.RandomState(7)
-    for t in range(5):
+    for t in range(4 if large else 5):
         _compare_step(env, oracles, rng.uniform(-1, 1, E), "step %d" % t)
     env.check_errors()
     env.close()

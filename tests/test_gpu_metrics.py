@@ -224,3 +224,46 @@ def test_sampled_envs_bit_exact_over_300_steps():
                     assert np.array_equal(obs[e].cpu().numpy(), oo)
     env.check_errors()
     env.close()
+
+
+def test_reference_schema_pickle_through_the_hip_env(tmp_path, monkeypatch):
+    """an experiment file with the reference's name and pickle schema ({'meta_data', 'exp': {conc: {trial: {'goal',
+    'ship_state', 'obstacles'}}}}, ship_ice_env.py:76-80,188-198), written by the restated generate_rand_exp pipeline, is picked up through
+    $BENCHPUSH_ICE_DIR by the gym-shaped ShipIceEnv and by the batched env, and steps bit-identically to the oracle on its trials."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, ShipIceEnv, experiment_file, resolve_trials
+    from benchpush_amd.config import default_cfg, merge_user_cfg
+    from benchpush_amd.ice_field_generator import generate_rand_exp
+    from benchpush_amd.scenario import load_experiment
+    from oracle.oracle import OracleShipIce
+    path = experiment_file(0.2, str(tmp_path))
+    generate_rand_exp(0.2, max_trials=3, filename=path, seed=5, goal=(0, 2.5))
+    monkeypatch.setenv("BENCHPUSH_ICE_DIR", str(tmp_path))
+    cfg = merge_user_cfg(default_cfg("ship_ice"), {"concentration": 0.2, "goal_y": 2.5})
+    trials = resolve_trials(cfg)
+    exp = load_experiment(path, 0.2)
+    assert len(trials) == 3 and all(np.array_equal(trials[k]["obstacles"][0]["vertices"], exp[k]["obstacles"][0]["vertices"]) for k in range(3))
+    env = BatchedShipIceEnv(3, cfg={"concentration": 0.2, "goal_y": 2.5}, device="cuda:0")        # trials come from the file
+    assert len(env.trials) == 3
+    c = env.cfg
+    orcs = [OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail) for _ in range(3)]
+    obs, _ = env.reset()
+    for e in range(3):
+        oo, _ = orcs[e].reset(trials[e])
+        assert np.array_equal(obs[e].cpu().numpy(), oo)
+    rng = np.random.default_rng(2)
+    for t in range(10):
+        a = rng.uniform(-0.5, 0.5, 3)
+        obs, rew, term, _, info = env.step(torch.from_numpy(a))
+        bs = env.body_state().cpu().numpy()
+        for e in range(3):
+            oo, orr, ot, _ = orcs[e].step(float(a[e]))
+            nb = len(orcs[e].bodies())
+            assert np.array_equal(bs[e, :nb], orcs[e].bodies()) and float(rew[e]) == orr and bool(term[e]) == ot
+            assert np.array_equal(obs[e].cpu().numpy(), oo)
+    env.check_errors()
+    env.close()
+    g = ShipIceEnv(cfg={"concentration": 0.2, "goal_y": 2.5}, device="cuda:0")
+    o0, info0 = g.reset()
+    oo, _ = OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail).reset(trials[0])
+    assert np.array_equal(o0, oo) and len(info0["obs"]) == len(trials[0]["obstacles"])
+    g.close()

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Order-sensitivity envelope of the restated Chipmunk step.
+
+pymunk is absent, so the reference's own arbiter sweep order (a by-product of Chipmunk's BB-tree and hash set) cannot be observed.
+What can be measured is how much ANY Gauss-Seidel sweep order moves the results: the oracle runs the same trials and actions with
+its documented (colour, key) order and with four alternatives (ascending key, broadphase discovery order, seeded random permutation
+per sub-step, descending key).  The spread between them is the stated tolerance against the real reference for every quantity the
+solver order can touch; quantities it cannot touch (the kinematic ship's pose, hence termination and the directional reward) are exact.
+
+    python tools/order_envelope.py [trials=100] [steps=300] [threads=8] > tests/golden/order_envelope.json
+"""
+import json
+import os
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+from benchpush_amd.config import default_cfg, merge_user_cfg, ship_ice_physics_params
+from benchpush_amd.envs.ship_ice import default_trials
+from oracle.oracle import OracleShipIce
+
+MODES = {0: "colour_key (documented order)", 1: "ascending_key", 2: "broadphase_discovery", 3: "random_permutation", 4: "descending_key"}
+
+
+def run_trial(args):
+    conc, tidx, steps, mode = args
+    cfg = merge_user_cfg(default_cfg("ship_ice"), {"concentration": conc})
+    P = ship_ice_physics_params(cfg)
+    trial = default_trials(conc, tidx + 1, base_seed=0)[tidx] if False else TRIALS[(conc, tidx)]
+    o = OracleShipIce(P, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+    o.set_solve_order(mode, 1234 + tidx)
+    o.reset(trial, observe=False)
+    rng = np.random.default_rng(1000 + tidx)
+    rows, episodes = [], []
+    ep_reward, ep_len = 0.0, 0
+    for t in range(steps):
+        a = float(rng.uniform(-1, 1))
+        ob, r, term, info = o.step(a, observe=(t % 10 == 0))
+        rows.append((info["x"], info["y"], info["theta"], info["total_work"], r, info["n_contact_pts"], info["n_post_solve"],
+                     info["n_first_contact"], float(term)))
+        ep_reward += r
+        ep_len += 1
+        occ = int(ob[3].astype(np.int64).sum()) if ob is not None else -1
+        rows[-1] = rows[-1] + (occ,)
+        if term:
+            b = o.bodies()
+            episodes.append((ep_len, ep_reward, info["total_work"], float(info["trial_success"]), b[1:, :3].copy()))
+            ep_reward, ep_len = 0.0, 0
+            o.reset(trial, observe=False)
+    return np.array(rows), episodes
+
+
+TRIALS = {}
+
+
+def main():
+    ntr = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    steps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    nth = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    conc = float(sys.argv[4]) if len(sys.argv) > 4 else 0.3
+    for i, tr in enumerate(default_trials(conc, ntr, base_seed=0)):
+        TRIALS[(conc, i)] = tr
+    res = {}
+    with ThreadPoolExecutor(nth) as ex:
+        for mode in MODES:
+            res[mode] = list(ex.map(run_trial, [(conc, i, steps, mode) for i in range(ntr)]))
+    env = {"trials": ntr, "steps_per_trial": steps, "concentration": conc, "orders": MODES, "vs_documented_order": {}}
+    for mode in (1, 2, 3, 4):
+        d = {"ship_pose_max_abs": 0.0, "termination_step_mismatches": 0, "episodes": 0, "step_reward_max_abs": 0.0,
+             "episode_reward_max_abs": 0.0, "episode_reward_max_rel": 0.0, "total_work_episode_max_rel": 0.0, "total_work_episode_mean_rel": 0.0,
+             "success_mismatches": 0, "contact_pts_episode_max_rel": 0.0, "first_contacts_episode_max_abs": 0.0,
+             "floe_position_episode_end_max_abs_m": 0.0, "floe_angle_episode_end_max_abs_rad": 0.0, "occupancy_channel_sum_max_rel": 0.0}
+        rels = []
+        for (r0, e0), (r1, e1) in zip(res[0], res[mode]):
+            d["ship_pose_max_abs"] = max(d["ship_pose_max_abs"], float(np.abs(r0[:, :3] - r1[:, :3]).max()))
+            d["termination_step_mismatches"] += int((r0[:, 8] != r1[:, 8]).sum())
+            d["step_reward_max_abs"] = max(d["step_reward_max_abs"], float(np.abs(r0[:, 4] - r1[:, 4]).max()))
+            m = r0[:, 9] >= 0
+            if m.any():
+                d["occupancy_channel_sum_max_rel"] = max(d["occupancy_channel_sum_max_rel"],
+                                                         float((np.abs(r0[m, 9] - r1[m, 9]) / np.maximum(r0[m, 9], 1)).max()))
+            # contact counters are cumulative over the space's life (reset at every episode): compare at the last step of each episode
+            ends = np.nonzero(r0[:, 8] > 0)[0]
+            for k in ends:
+                if r0[k, 5] > 0:
+                    d["contact_pts_episode_max_rel"] = max(d["contact_pts_episode_max_rel"], abs(r0[k, 5] - r1[k, 5]) / r0[k, 5])
+                d["first_contacts_episode_max_abs"] = max(d["first_contacts_episode_max_abs"], abs(r0[k, 7] - r1[k, 7]))
+            assert len(e0) == len(e1)
+            for (l0, w0, tw0, s0, b0), (l1, w1, tw1, s1, b1) in zip(e0, e1):
+                d["episodes"] += 1
+                d["termination_step_mismatches"] += int(l0 != l1)
+                d["success_mismatches"] += int(s0 != s1)
+                d["episode_reward_max_abs"] = max(d["episode_reward_max_abs"], abs(w0 - w1))
+                d["episode_reward_max_rel"] = max(d["episode_reward_max_rel"], abs(w0 - w1) / max(abs(w0), 1e-9))
+                if tw0 > 0:
+                    rel = abs(tw0 - tw1) / tw0
+                    rels.append(rel)
+                    d["total_work_episode_max_rel"] = max(d["total_work_episode_max_rel"], rel)
+                d["floe_position_episode_end_max_abs_m"] = max(d["floe_position_episode_end_max_abs_m"], float(np.abs(b0[:, :2] - b1[:, :2]).max()))
+                d["floe_angle_episode_end_max_abs_rad"] = max(d["floe_angle_episode_end_max_abs_rad"], float(np.abs(b0[:, 2] - b1[:, 2]).max()))
+        d["total_work_episode_mean_rel"] = float(np.mean(rels)) if rels else 0.0
+        env["vs_documented_order"][MODES[mode]] = d
+    worst = {}
+    for d in env["vs_documented_order"].values():
+        for k, v in d.items():
+            if k != "episodes":
+                worst[k] = max(worst.get(k, 0), v)
+    env["envelope"] = worst
+    print(json.dumps(env, indent=1))
+
+
+if __name__ == "__main__":
+    main()
