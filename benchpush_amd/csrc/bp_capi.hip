@@ -151,7 +151,7 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
         h->obs_lds_bytes = (size_t)4 * (nwords + ((nwords + 1) & ~1)) + sizeof(double) * 2 * MZ_MAXBOX * 4;
         if (hipFuncSetAttribute((const void *)k_observe_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
     } else {
-        h->obs_lds_bytes = (size_t)((P.obs_h * P.obs_w + 15) & ~15) + (size_t)((P.obs_h + 15) & ~15) + sizeof(double) * 2 * OBS_MAXCAND * BP_MAXV;
+        h->obs_lds_bytes = (size_t)((P.obs_h * P.obs_w + 15) & ~15) + (size_t)((P.obs_h + 15) & ~15) + sizeof(double) * 2 * OBS_CHUNK * BP_MAXV;
         if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
     }
     *out = h;
@@ -548,7 +548,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         if (h->P.env_kind == BP_ENV_MAZE)
             hipLaunchKernelGGL(k_observe_maze, dim3(h->num_envs), dim3(OBS_THREADS), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
         else
-            hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
+            hipLaunchKernelGGL(k_observe, dim3(h->num_envs), dim3(OBS_THREADS_SHIP), h->obs_lds_bytes, st, h->P, h->D, mask, obs);
         HIPCHK(h, hipGetLastError());
     }
     if (h->timing) HIPCHK(h, hipEventRecord(e2, st));

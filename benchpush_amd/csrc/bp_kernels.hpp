@@ -639,7 +639,11 @@ __global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const Dev
 //   ch3 occupancy   skimage.draw.polygon of floes within 12 m, 25 px/m   occupancy_map.py:37-65,112-140
 // ------------------------------------------------------------------------------------------------------------
 #define OBS_THREADS 256
+#ifndef OBS_THREADS_SHIP
+#define OBS_THREADS_SHIP 512   // k_observe (ship-ice): 8 waves per workgroup, 4 workgroups per CU = the 32 wave slots of a CU
+#endif
 #define OBS_MAXCAND 96      // floes whose pixel AABB meets the 150x150 window (6 m x 6 m; typically 15-40)
+#define OBS_CHUNK 32        // candidates rasterised per pass: 10 KB of vertex staging instead of 30 KB -> 4 workgroups per CU instead of 2
 #ifndef OBS_SNAP_Y
 #define OBS_SNAP_Y 1e-6     // a vertex this close to a raster row sends the row to the per-pixel test
 #define OBS_SNAP_X 1e-6     // a crossing this close to a pixel centre is decided by the exact test on that pixel
@@ -749,14 +753,14 @@ __device__ __forceinline__ d2 poly_centroid_xy(const double *x, const double *y,
 {
     double d1 = 0.0, d2_ = 0.0;
     for (int i = 0; i < n; i++) {
-        const int p = (i - 1 + n) % n;
+        const int p = (i == 0) ? n - 1 : i - 1;
         d1 += x[i] * y[p];
         d2_ += y[i] * x[p];
     }
     const double A = 0.5 * __builtin_fabs(d1 - d2_);
     double sx = 0.0, sy = 0.0;
     for (int i = 0; i < n; i++) {
-        const int p = (i - 1 + n) % n;
+        const int p = (i == 0) ? n - 1 : i - 1;
         const double u = x[i] * y[p] - x[p] * y[i];
         sx += (x[i] + x[p]) * u;
         sy += (y[i] + y[p]) * u;
@@ -765,13 +769,77 @@ __device__ __forceinline__ d2 poly_centroid_xy(const double *x, const double *y,
     return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
 }
 
+// One raster row of skimage.draw.polygon for a CONVEX polygon (xp = columns, yp = rows, raster coordinates), columns [c0, c1]:
+// the inside pixels of the row form one span between the two edges that straddle it.  With every vertex at least OBS_SNAP_Y away
+// from the row, point_in_polygon's crossing tests have the sign of (X - x) * dy for the crossing abscissa X of an edge (error
+// ~1e-13 px), so pixels strictly between the two crossings are inside and the others outside; a crossing within OBS_SNAP_X of a
+// pixel centre is decided by the exact test on that pixel.  Rows with a vertex within OBS_SNAP_Y (vertex / edge rules of
+// point_in_polygon) or not exactly two crossings fall back to the exact test on every pixel.  Identical to testing every pixel.
+template <bool OR_BITS>
+__device__ __forceinline__ void raster_row_convex(const double *xp, const double *yp, int n, int gi, int c0, int c1, unsigned char *row,
+                                                  unsigned char flag)
+{
+    const double y = (double)gi;
+    bool slow = false;
+    int ncross = 0, ia = 0, ib = 0;   // the (at most two) edges i-1 -> i that straddle the row; their abscissae are computed after the
+    double y1 = yp[n - 1] - y;        // loop, so that the lanes of a wave do not serialise one division per vertex
+    for (int i = 0; i < n; i++) {
+        const double y0 = yp[i] - y;
+        if (__builtin_fabs(y0) < OBS_SNAP_Y) slow = true;
+        if ((y0 > 0) != (y1 > 0)) {
+            if (ncross == 0) ia = i; else ib = i;
+            ncross++;
+        }
+        y1 = y0;
+    }
+    double xa = 0.0, xb = 0.0;
+    if (ncross == 2) {
+        const int pa = (ia == 0) ? n - 1 : ia - 1, pb = (ib == 0) ? n - 1 : ib - 1;
+        { const double x0 = xp[ia], y0 = yp[ia] - y, x1 = xp[pa], y1_ = yp[pa] - y; xa = x0 - y0 * ((x1 - x0) / (y1_ - y0)); }
+        { const double x0 = xp[ib], y0 = yp[ib] - y, x1 = xp[pb], y1_ = yp[pb] - y; xb = x0 - y0 * ((x1 - x0) / (y1_ - y0)); }
+    }
+    if (slow || (ncross != 0 && ncross != 2)) {
+        for (int gj = c0; gj <= c1; gj++)
+            if (pip_arrays(xp, yp, n, (double)gj, y)) { if (OR_BITS) row[gj] |= flag; else row[gj] = flag; }
+        return;
+    }
+    if (ncross == 0) return;
+    const double xl = fmin(xa, xb), xr = fmax(xa, xb);
+    int first, last;
+    {
+        const double rl = __builtin_rint(xl);
+        if (__builtin_fabs(xl - rl) < OBS_SNAP_X) first = pip_arrays(xp, yp, n, rl, y) ? (int)rl : (int)rl + 1;
+        else first = (int)__builtin_ceil(xl);
+        const double rr = __builtin_rint(xr);
+        if (__builtin_fabs(xr - rr) < OBS_SNAP_X) last = pip_arrays(xp, yp, n, rr, y) ? (int)rr : (int)rr - 1;
+        else last = (int)__builtin_floor(xr);
+    }
+    first = max(first, c0); last = min(last, c1);
+    if (OR_BITS) { for (int gj = first; gj <= last; gj++) row[gj] |= flag; return; }
+    // plain stores: whole 32-bit words where the span covers them (every byte of such a word belongs to this span, and any other
+    // writer of this phase stores the same flag), single bytes at the two ends
+    unsigned char *p = row + first, *const pe = row + last + 1;
+    while (p < pe && ((uintptr_t)p & 3u)) *p++ = flag;
+    const unsigned w4 = (unsigned)flag * 0x01010101u;
+    for (; p + 4 <= pe; p += 4) *(unsigned *)p = w4;
+    while (p < pe) *p++ = flag;
+}
+
+// byte mask of the first k bytes of a little-endian word (k <= 0: none, k >= 4: all)
+__device__ __forceinline__ unsigned obs_upto(int k) { return k <= 0 ? 0u : (k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u)); }
+
 // Flag bits of the LDS window image
+#ifdef BP_PROF
+#define OPROF(k) { if (tid == 0 && D.prof != nullptr) D.prof[(size_t)env * 24 + (k)] = __builtin_amdgcn_s_memtime(); }
+#else
+#define OPROF(k)
+#endif
 #define OBS_F_OCC 1u
 #define OBS_F_SHIP 2u
 #define OBS_F_LINE 4u
 #define OBS_F_HEAD 8u
 
-__global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+__global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                          unsigned char *__restrict__ obs)
 {
     const int env = blockIdx.x;
@@ -789,18 +857,19 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
     // LDS: window image of flag bits [npix] u8 | goal-distance row table [LH] u8 | candidate polygons (world, then raster coordinates)
     unsigned char *s_img = (unsigned char *)obs_smem;
     unsigned char *s_edt = s_img + ((npix + 15) & ~15);
-    double *s_px = (double *)(s_edt + ((LH + 15) & ~15));   // [OBS_MAXCAND][BP_MAXV]
-    double *s_py = s_px + OBS_MAXCAND * BP_MAXV;
+    double *s_px = (double *)(s_edt + ((LH + 15) & ~15));   // [OBS_CHUNK][BP_MAXV]: the candidates are processed OBS_CHUNK at a time
+    double *s_py = s_px + OBS_CHUNK * BP_MAXV;
     __shared__ int s_npass;
     __shared__ unsigned short s_list[OBS_MAXCAND];
-    __shared__ int s_bbx[OBS_MAXCAND][4]; // window-clipped pixel box: r0, r1, c0, c1 (global raster coordinates); r1 < r0: not a candidate
-    __shared__ unsigned char s_cn[OBS_MAXCAND];
-    __shared__ int s_roff[OBS_MAXCAND + 1]; // first (candidate, row) item of each candidate
+    __shared__ int s_bbx[OBS_CHUNK][4]; // window-clipped pixel box: r0, r1, c0, c1 (global raster coordinates); r1 < r0: not a candidate
+    __shared__ unsigned char s_cn[OBS_CHUNK];
     __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
     __shared__ int s_fcnt, s_fbb[4];
+    OPROF(0)
     if (tid == 0) s_npass = 0;
-    for (int w = tid; w < (npix + 3) / 4; w += OBS_THREADS) ((unsigned *)s_img)[w] = 0u;
+    for (int w = tid; w < (npix + 3) / 4; w += OBS_THREADS_SHIP) ((unsigned *)s_img)[w] = 0u;
     __syncthreads();
+    OPROF(1)
 
     const d2 sp = D.pxy[eb];
     const d2 srot = D.rot[eb]; // (cos, sin) == bp_sincos(angle)
@@ -813,7 +882,7 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
     const int bh = (int)(P.map_h * P.m_to_pix), bw = (int)(P.map_w * P.m_to_pix);
     // ---- 1. conservative pre-test on the body AABBs (min/max of the same world vertices, grown by the shape radius): a floe whose
     //         AABB, grown by a pixel, misses the window cannot pass the exact pixel-box test of step 3 -> its vertices are not read
-    for (int s = 1 + tid; s < nb; s += OBS_THREADS) {
+    for (int s = 1 + tid; s < nb; s += OBS_THREADS_SHIP) {
         const double4 b = D.bb[eb + s];
         if (__builtin_floor(b.y * P.m_to_pix) - 1.0 > (double)gi1 || __builtin_ceil(b.w * P.m_to_pix) + 1.0 < (double)gi0 ||
             __builtin_floor(b.x * P.m_to_pix) - 1.0 > (double)gj1 || __builtin_ceil(b.z * P.m_to_pix) + 1.0 < (double)gj0) continue;
@@ -852,7 +921,7 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
     }
     // goal-distance value per window row (occupancy_map.py:413-433): max(0, goal - i*g2m)/goal, out of map -> 1
     const double g2m = P.map_h / (double)Hg;
-    for (int li = tid; li < LH; li += OBS_THREADS) {
+    for (int li = tid; li < LH; li += OBS_THREADS_SHIP) {
         const int gi = gi0 + li;
         unsigned char e = 255;
         if (gi >= 0 && gi < Hg) {
@@ -863,17 +932,21 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
         s_edt[li] = e;
     }
     __syncthreads();
-    const int ncand = min(s_npass, OBS_MAXCAND);
+    OPROF(2)
+    const int ncand_all = min(s_npass, OBS_MAXCAND);
     if (tid == 0 && s_npass > OBS_MAXCAND) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+    for (int cbase = 0; cbase < ncand_all; cbase += OBS_CHUNK) {
+    const int ncand = min(OBS_CHUNK, ncand_all - cbase);
     // ---- 2. world vertices of the pre-test survivors -> LDS, one (floe, vertex) item per thread ----
-    for (int idx = tid; idx < ncand * BP_MAXV; idx += OBS_THREADS) {
+    for (int idx = tid; idx < ncand * BP_MAXV; idx += OBS_THREADS_SHIP) {
         const int k = idx / BP_MAXV, q = idx - k * BP_MAXV;
-        const int s = s_list[k];
+        const int s = s_list[cbase + k];
         const int n = nv[s];
         if (q == 0) s_cn[k] = (unsigned char)n;
         if (q < n) { const d2 v = wv[(size_t)s * BP_MAXV + q]; s_px[idx] = v.x; s_py[idx] = v.y; }
     }
     __syncthreads();
+    OPROF(3)
     // ---- 3. exact candidate test, one floe per thread: |centroid| range culling (occupancy_map.py:44-49) + pixel box vs window;
     //         the vertices are converted to raster coordinates in place ----
     if (tid < ncand) {
@@ -901,115 +974,89 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe(const DevParams P, cons
         } else { s_bbx[k][0] = 0; s_bbx[k][1] = -1; s_bbx[k][2] = 0; s_bbx[k][3] = -1; }
     }
     __syncthreads();
-    // ---- 4. occupancy: skimage.draw.polygon of each candidate, one (candidate, raster row) item per thread.
-    // The hulls are convex, so a row's inside pixels form one span between the two edges that straddle the row.  With every
-    // vertex at least OBS_SNAP_Y away from the row, point_in_polygon's crossing tests have the sign of (X - x) * dy for the
-    // crossing abscissa X of an edge (error ~1e-13 px), so pixels strictly between the two crossings are inside and the others
-    // outside; a crossing within OBS_SNAP_X of a pixel centre is decided by the exact test on that pixel.  Rows that have a
-    // vertex within OBS_SNAP_Y (vertex / edge rules of point_in_polygon) or not exactly two crossings fall back to the exact
-    // test on every pixel of the row.  Result: identical to testing every pixel of the box (the oracle does that).
-    if (tid == 0) {
-        int acc = 0;
-        for (int k = 0; k < ncand; k++) { s_roff[k] = acc; acc += max(0, s_bbx[k][1] - s_bbx[k][0] + 1); }
-        s_roff[ncand] = acc;
-    }
-    __syncthreads();
-    const int nitems = s_roff[ncand];
-    for (int it = tid; it < nitems; it += OBS_THREADS) {
-        int k = 0;
-        {   // last k with s_roff[k] <= it (candidates without rows repeat their successor's offset and are skipped by "last")
-            int lo = 0, hi = ncand - 1;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (s_roff[mid] <= it) lo = mid; else hi = mid - 1; }
-            k = lo;
-        }
-        const int gi = s_bbx[k][0] + (it - s_roff[k]);
-        if (gi < 0 || gi >= Hg || gi > s_bbx[k][1]) continue;
-        const int c0 = max(s_bbx[k][2], 0), c1 = min(s_bbx[k][3], Wg - 1);
-        const int n = s_cn[k];
-        const double *xp = s_px + k * BP_MAXV, *yp = s_py + k * BP_MAXV;
-        const double y = (double)gi;
-        bool slow = false;
-        int ncross = 0;
-        double xa = 0.0, xb = 0.0;
-        double x1 = xp[n - 1], y1 = yp[n - 1] - y;
-        for (int i = 0; i < n; i++) {
-            const double x0 = xp[i], y0 = yp[i] - y;
-            if (__builtin_fabs(y0) < OBS_SNAP_Y) slow = true;
-            if ((y0 > 0) != (y1 > 0)) {
-                const double X = x0 - y0 * ((x1 - x0) / (y1 - y0));
-                if (ncross == 0) xa = X; else xb = X;
-                ncross++;
+    OPROF(4)
+    // ---- 4. occupancy: skimage.draw.polygon of each candidate as exact scanline spans (raster_row_convex): OBS_THREADS_SHIP / OBS_CHUNK
+    //         threads per candidate walk its raster rows ----
+    {
+        int TPC = OBS_THREADS_SHIP / OBS_CHUNK;                 // threads per candidate: all 256 threads share the chunk's candidates
+        while (TPC * ncand * 2 <= OBS_THREADS_SHIP) TPC *= 2;
+        const int k = tid / TPC, sub = tid - k * TPC;
+        if (k < ncand && s_bbx[k][1] >= s_bbx[k][0]) {
+            const int c0 = max(s_bbx[k][2], 0), c1 = min(s_bbx[k][3], Wg - 1);
+            const int n = s_cn[k];
+            const double *xp = s_px + k * BP_MAXV, *yp = s_py + k * BP_MAXV;
+            for (int gi = s_bbx[k][0] + sub; gi <= s_bbx[k][1]; gi += TPC) {
+                if (gi < 0 || gi >= Hg) continue;
+                raster_row_convex<false>(xp, yp, n, gi, c0, c1, s_img + (gi - gi0) * LW - gj0, (unsigned char)OBS_F_OCC);
             }
-            x1 = x0; y1 = y0;
         }
-        unsigned char *row = s_img + (gi - gi0) * LW - gj0;
-        if (slow || (ncross != 0 && ncross != 2)) {
-            for (int gj = c0; gj <= c1; gj++) if (pip_arrays(xp, yp, n, (double)gj, y)) row[gj] = OBS_F_OCC;
-            continue;
-        }
-        if (ncross == 0) continue;
-        const double xl = fmin(xa, xb), xr = fmax(xa, xb);
-        int first, last;
-        {
-            const double rl = __builtin_rint(xl);
-            if (__builtin_fabs(xl - rl) < OBS_SNAP_X) first = pip_arrays(xp, yp, n, rl, y) ? (int)rl : (int)rl + 1;
-            else first = (int)__builtin_ceil(xl);
-            const double rr = __builtin_rint(xr);
-            if (__builtin_fabs(xr - rr) < OBS_SNAP_X) last = pip_arrays(xp, yp, n, rr, y) ? (int)rr : (int)rr - 1;
-            else last = (int)__builtin_floor(xr);
-        }
-        first = max(first, c0); last = min(last, c1);
-        for (int gj = first; gj <= last; gj++) row[gj] = OBS_F_OCC;
     }
     __syncthreads();
+    }
+    OPROF(5)
     // ---- 5. footprint (skimage.draw.polygon of the hull outline, exact test over its pixel box) and heading line -> flag bits.
     //         Writers of one phase all store "previous bits | own bit" to a byte, so concurrent stores agree. ----
-    if (s_fcnt > 0) {
-        const int r0 = max(s_fbb[0], max(gi0, 0)), r1 = min(s_fbb[1], min(gi1, Hg - 1));
-        const int c0 = max(s_fbb[2], max(gj0, 0)), c1 = min(s_fbb[3], min(gj1, Wg - 1));
-        const int wbox = c1 - c0 + 1, npx = (r1 >= r0 && c1 >= c0) ? (r1 - r0 + 1) * wbox : 0;
-        for (int q = tid; q < npx; q += OBS_THREADS) {
-            const int rr = q / wbox, cc = q - rr * wbox;
-            const int gi = r0 + rr, gj = c0 + cc;
-            if (pip_arrays(s_fc, s_fr, s_fcnt, (double)gj, (double)gi)) s_img[(gi - gi0) * LW + (gj - gj0)] |= OBS_F_SHIP;
+    // One wavefront does the three in turn: the LDS operations of a wave execute in issue order, so its later read-modify-writes see
+    // its earlier ones without a workgroup barrier (the occupancy stores of all waves are behind the barrier above).
+    if (tid < 64) {
+        if (s_fcnt > 0) {   // the hull outline (vertices outside the grid dropped) stays convex: same exact scanline spans as the floes
+            const int r0 = max(s_fbb[0], max(gi0, 0)), r1 = min(s_fbb[1], min(gi1, Hg - 1));
+            const int c0 = max(s_fbb[2], max(gj0, 0)), c1 = min(s_fbb[3], min(gj1, Wg - 1));
+            if (c1 >= c0)
+                for (int gi = r0 + tid; gi <= r1; gi += 64)
+                    raster_row_convex<true>(s_fc, s_fr, s_fcnt, gi, c0, c1, s_img + (gi - gi0) * LW - gj0, (unsigned char)OBS_F_SHIP);
         }
+        asm volatile("" ::: "memory");
+        if (line.valid) {   // cv2.line: pixel t of the 8-connected walk, t = 0 .. dmaj (closed form of on_line)
+            const long long dmaj = line.vert ? line.dy : line.dx, dmin = line.vert ? line.dx : line.dy;
+            for (long long t = tid; t <= dmaj; t += 64) {
+                // coordinates are u16 (cast by the reference); inside the 1000 x 300 map 2 * dmin * t + dmaj fits u32
+                const long long mt = (dmaj == 0) ? 0 : ((dmaj < 32768 && dmin < 32768)
+                                         ? (long long)(((unsigned)(2 * dmin * t) + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj))
+                                         : (2 * dmin * t + dmaj - 1) / (2 * dmaj));
+                const long long ax = line.vert ? mt : t, ay = line.vert ? t : mt;
+                const long long gj = line.x0 + ax * line.sx, gi = line.y0 + ay * line.sy;
+                if (gi >= gi0 && gi <= gi1 && gj >= gj0 && gj <= gj1 && gi >= 0 && gi < Hg && gj >= 0 && gj < Wg)
+                    s_img[((int)gi - gi0) * LW + ((int)gj - gj0)] |= OBS_F_LINE;
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (tid == 0 && hpy >= gi0 && hpy <= gi1 && hpx >= gj0 && hpx <= gj1) s_img[((int)hpy - gi0) * LW + ((int)hpx - gj0)] |= OBS_F_HEAD;
     }
     __syncthreads();
-    if (line.valid) {   // cv2.line: pixel t of the 8-connected walk, t = 0 .. dmaj (closed form of on_line)
-        const long long dmaj = line.vert ? line.dy : line.dx, dmin = line.vert ? line.dx : line.dy;
-        for (long long t = tid; t <= dmaj; t += OBS_THREADS) {
-            const long long mt = (dmaj == 0) ? 0 : (2 * dmin * t + dmaj - 1) / (2 * dmaj);
-            const long long ax = line.vert ? mt : t, ay = line.vert ? t : mt;
-            const long long gj = line.x0 + ax * line.sx, gi = line.y0 + ay * line.sy;
-            if (gi >= gi0 && gi <= gi1 && gj >= gj0 && gj <= gj1 && gi >= 0 && gi < Hg && gj >= 0 && gj < Wg)
-                s_img[((int)gi - gi0) * LW + ((int)gj - gj0)] |= OBS_F_LINE;
-        }
-    }
-    __syncthreads();
-    if (tid == 0 && hpy >= gi0 && hpy <= gi1 && hpx >= gj0 && hpx <= gj1) s_img[((int)hpy - gi0) * LW + ((int)hpx - gj0)] |= OBS_F_HEAD;
-    __syncthreads();
+    OPROF(6)
     // ---- 6. compose the four channels from the flag image, 4 pixels per 32-bit store ----
     //   ch0: in map 127, ship 255, out of map 0; ch1: row value, out of map 255; ch2: line 127, head 255; ch3: occupied 255
     const size_t plane = (size_t)npix;
     unsigned *o32 = (unsigned *)(obs + (size_t)env * BP_OBS_C * plane);
     const int nwords = npix / 4; // 150*150 is a multiple of 4 (checked on the host)
-    for (int w = tid; w < nwords; w += OBS_THREADS) {
+    // pixel 4*w = (li, lj) advances by 4*OBS_THREADS_SHIP pixels per trip: carried incrementally instead of dividing by the row length
+    const int adv = 4 * OBS_THREADS_SHIP, adv_r = adv / LW, adv_c = adv - adv_r * LW;
+    int li0 = (4 * tid) / LW, lj0 = 4 * tid - li0 * LW;
+    const int ljlo = max(0, -gj0), ljhi = min(LW - 1, Wg - 1 - gj0);
+    for (int w = tid; w < nwords; w += OBS_THREADS_SHIP) {
         const unsigned f = ((const unsigned *)s_img)[w];
-        unsigned inb = 0, e = 0;
-        for (int b = 0; b < 4; b++) {   // a word may straddle two window rows
-            const int px = 4 * w + b;
-            const int li = px / LW, lj = px - li * LW;
-            const int gi = gi0 + li, gj = gj0 + lj;
-            if (!(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg)) { inb |= 0xFFu << (8 * b); e |= (unsigned)s_edt[li] << (8 * b); }
-        }
+        // in-map byte mask and goal-distance bytes of the word, branch-free: bytes [0, bs) lie in window row li0, the rest (a word may
+        // straddle two rows) in row li0 + 1; columns inside the map are the window columns [ljlo, ljhi]
+        const int bs = LW - lj0;
+        const unsigned mlo = obs_upto(bs);
+        const int giA = gi0 + li0, giB = giA + 1;
+        const unsigned rowA = (giA >= 0 && giA < Hg) ? 0xFFFFFFFFu : 0u, rowB = (giB >= 0 && giB < Hg && li0 + 1 < LH) ? 0xFFFFFFFFu : 0u;
+        const unsigned colA = obs_upto(ljhi - lj0 + 1) & ~obs_upto(ljlo - lj0);
+        const unsigned colB = obs_upto(bs + ljhi + 1) & ~obs_upto(bs + ljlo);
+        const unsigned inb = (rowA & mlo & colA) | (rowB & ~mlo & colB);
+        const unsigned eA = (unsigned)s_edt[li0] * 0x01010101u, eB = (unsigned)s_edt[min(li0 + 1, LH - 1)] * 0x01010101u;
+        const unsigned e = ((eA & mlo) | (eB & ~mlo)) & inb;
         const unsigned ship = (f >> 1) & 0x01010101u, ln = (f >> 2) & 0x01010101u, hd = (f >> 3) & 0x01010101u;
         o32[w] = inb & (0x7F7F7F7Fu + ship * 0x80u);
         o32[nwords + w] = e | ~inb;
         o32[2 * nwords + w] = inb & ((ln & ~hd) * 127u + hd * 255u);
         o32[3 * nwords + w] = (f & 0x01010101u) * 255u;
+        li0 += adv_r; lj0 += adv_c;
+        if (lj0 >= LW) { lj0 -= LW; li0++; }
     }
+    OPROF(7)
 }
-
 
 // ------------------------------------------------------------------------------------------------------------
 // k_observe_maze: maze-NAMO-v0 observation, uint8 [4][192][192] per env (maze_NAMO_env.py:514-525 ->

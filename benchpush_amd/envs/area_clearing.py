@@ -139,6 +139,8 @@ class AreaClearingEnv(Env):
 
     def reset(self, seed=None, options=None):
         self.episode_idx = 0 if self.episode_idx is None else self.episode_idx + 1
+        if self.episode_idx:
+            self._b.check_errors()   # capacity flags of the episode that just ended (raises BpError)
         self._b.reset()
         it = self._b.info[0].cpu().numpy()
         boxes = self._boxes()

@@ -149,6 +149,8 @@ class MazeNAMO(Env):
 
     def reset(self, seed=None, options=None):
         self.episode_idx = 0 if self.episode_idx is None else self.episode_idx + 1
+        if self.episode_idx:
+            self._b.check_errors()   # capacity flags of the episode that just ended (raises BpError)
         self._b.reset()
         self.t = 0
         self.total_work = [0, []]

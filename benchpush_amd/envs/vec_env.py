@@ -65,6 +65,9 @@ class BatchedVecEnv(_Base):
             for k, e in enumerate(np.nonzero(done_h)[0]):
                 infos[e]["terminal_observation"] = term_obs[k]
                 infos[e]["TimeLimit.truncated"] = bool(trunc_h[e])
+            # an in-kernel capacity overflow (neighbour list, arbiter / velocity slots, colours) only raises a per-env flag while the
+            # step carries on with dropped items: surface it here, once per batch of finished episodes, instead of never
+            self.env.check_errors()
             obs, _ = self.env.reset(done)
             self._steps[done] = 0
         return self._out(obs), rew_out, (done_h if self.to_numpy else done), infos
