@@ -34,6 +34,7 @@ def run_trial(args):
     o.reset(trial, observe=False)
     rng = np.random.default_rng(1000 + tidx)
     rows, episodes = [], []
+    snaps = {}
     ep_reward, ep_len = 0.0, 0
     for t in range(steps):
         a = float(rng.uniform(-1, 1))
@@ -44,12 +45,14 @@ def run_trial(args):
         ep_len += 1
         occ = int(ob[3].astype(np.int64).sum()) if ob is not None else -1
         rows[-1] = rows[-1] + (occ,)
+        if len(episodes) == 0 and ep_len in (1, 2, 5, 10, 20):
+            snaps[ep_len] = o.bodies()[1:, :3].copy()      # floe poses k steps into the first episode: growth of the deviation
         if term:
             b = o.bodies()
             episodes.append((ep_len, ep_reward, info["total_work"], float(info["trial_success"]), b[1:, :3].copy()))
             ep_reward, ep_len = 0.0, 0
             o.reset(trial, observe=False)
-    return np.array(rows), episodes
+    return np.array(rows), episodes, snaps
 
 
 TRIALS = {}
@@ -73,7 +76,15 @@ def main():
              "success_mismatches": 0, "contact_pts_episode_max_rel": 0.0, "first_contacts_episode_max_abs": 0.0,
              "floe_position_episode_end_max_abs_m": 0.0, "floe_angle_episode_end_max_abs_rad": 0.0, "occupancy_channel_sum_max_rel": 0.0}
         rels = []
-        for (r0, e0), (r1, e1) in zip(res[0], res[mode]):
+        growth = {}
+        tw_sum = [0.0, 0.0]
+        rw_sum = [0.0, 0.0]
+        for (r0, e0, s0_), (r1, e1, s1_) in zip(res[0], res[mode]):
+            for kk in s0_:
+                if kk in s1_:
+                    growth[kk] = max(growth.get(kk, 0.0), float(np.abs(s0_[kk][:, :2] - s1_[kk][:, :2]).max()))
+            for (l0, w0, tw0, sc0, b0), (l1, w1, tw1, sc1, b1) in zip(e0, e1):
+                tw_sum[0] += tw0; tw_sum[1] += tw1; rw_sum[0] += w0; rw_sum[1] += w1
             d["ship_pose_max_abs"] = max(d["ship_pose_max_abs"], float(np.abs(r0[:, :3] - r1[:, :3]).max()))
             d["termination_step_mismatches"] += int((r0[:, 8] != r1[:, 8]).sum())
             d["step_reward_max_abs"] = max(d["step_reward_max_abs"], float(np.abs(r0[:, 4] - r1[:, 4]).max()))
@@ -101,11 +112,21 @@ def main():
                 d["floe_position_episode_end_max_abs_m"] = max(d["floe_position_episode_end_max_abs_m"], float(np.abs(b0[:, :2] - b1[:, :2]).max()))
                 d["floe_angle_episode_end_max_abs_rad"] = max(d["floe_angle_episode_end_max_abs_rad"], float(np.abs(b0[:, 2] - b1[:, 2]).max()))
         d["total_work_episode_mean_rel"] = float(np.mean(rels)) if rels else 0.0
+        if rels:
+            q = np.percentile(rels, [50, 90, 99])
+            d["total_work_episode_rel_p50"], d["total_work_episode_rel_p90"], d["total_work_episode_rel_p99"] = map(float, q)
+        d["floe_position_max_abs_m_after_k_steps"] = {str(k): growth[k] for k in sorted(growth)}
+        d["batch_mean_total_work_rel"] = abs(tw_sum[0] - tw_sum[1]) / max(tw_sum[0], 1e-300)
+        d["batch_mean_episode_reward_rel"] = abs(rw_sum[0] - rw_sum[1]) / max(abs(rw_sum[0]), 1e-300)
         env["vs_documented_order"][MODES[mode]] = d
     worst = {}
     for d in env["vs_documented_order"].values():
         for k, v in d.items():
-            if k != "episodes":
+            if k == "floe_position_max_abs_m_after_k_steps":
+                w = worst.setdefault(k, {})
+                for kk, vv in v.items():
+                    w[kk] = max(w.get(kk, 0.0), vv)
+            elif k != "episodes":
                 worst[k] = max(worst.get(k, 0), v)
     env["envelope"] = worst
     print(json.dumps(env, indent=1))
