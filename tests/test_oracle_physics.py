@@ -188,3 +188,33 @@ def test_work_nonnegative_and_determinism(ship_cfg):
             seq.append((r, info["total_work"], info["n_contact_pts"]))
         outs.append((seq, e.bodies().copy()))
     assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_contact_points_known_answers_worked_by_hand():
+    """cpCollide / ContactPoints (Chipmunk2D 7.0.3 cpCollision.c) on two configurations worked out by hand from the published algorithm
+    (support edges, d_e* cross products, clamped lerps, radii along the normal), radius 0.02 per shape as in the reference
+    (sim_utils.py:144, ship.py:90).
+      parallel edges: unit square A, unit square B shifted by (1.03, 0.25): n = (1, 0); the overlapping stretch y in [0.25, 1] of the two
+        facing edges gives two contacts, each 0.01 deep (gap 0.03 - radii 0.04).
+      vertex-vertex: B is a diamond whose left vertex sits 0.03 from A's corner (1, 1) in the direction 30 degrees: n = (cos 30, sin 30);
+        A's support edge is its right edge (n.x > n.y), B's the lower-left one; only the pair of end points (1,1) / B's vertex is within reach."""
+    r = 0.02
+    A = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], float)
+    B = A + np.array([1.03, 0.25])
+    cnt, n, p1, p2, h = orc.collide(A, r, B, r)
+    assert cnt == 2 and np.allclose(n, [1.0, 0.0], atol=0, rtol=0)
+    assert np.allclose(p1, [[1.02, 0.25], [1.02, 1.0]], atol=1e-12) and np.allclose(p2, [[1.01, 0.25], [1.01, 1.0]], atol=1e-12)
+    assert np.allclose((p2 - p1) @ n, [-0.01, -0.01], atol=1e-12) and h[0] != h[1]
+    c30, s30 = np.cos(np.pi / 6), np.sin(np.pi / 6)
+    L = np.array([1.0, 1.0]) + 0.03 * np.array([c30, s30])
+    D = np.array([L + [0.5, -0.5], L + [1.0, 0.0], L + [0.5, 0.5], L])       # CCW: bottom, right, top, left
+    cnt, n, p1, p2, h = orc.collide(A, r, D, r)
+    assert cnt == 1 and np.allclose(n, [c30, s30], atol=1e-12)
+    assert np.allclose(p1[0], [1.0 + r * c30, 1.0 + r * s30], atol=1e-9) and np.allclose(p2[0], L - r * np.array([c30, s30]), atol=1e-9)
+    assert abs(float((p2[0] - p1[0]) @ n) - (0.03 - 2 * r)) < 1e-9
+    # just out of reach: 0.0401 between the two vertices -> no contact; the same shapes swapped give the mirrored normal
+    L2 = np.array([1.0, 1.0]) + 0.0401 * np.array([c30, s30])
+    D2 = np.array([L2 + [0.5, -0.5], L2 + [1.0, 0.0], L2 + [0.5, 0.5], L2])
+    assert orc.collide(A, r, D2, r)[0] == 0
+    cnt, n2, q1, q2, _ = orc.collide(D, r, A, r)
+    assert cnt == 1 and np.allclose(n2, [-c30, -s30], atol=1e-12) and np.allclose(q1[0], p2[0], atol=1e-9) and np.allclose(q2[0], p1[0], atol=1e-9)
