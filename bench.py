@@ -73,7 +73,7 @@ def cpu_baseline(env, trials):
     from oracle import oracle as orc
 
     cores = effective_cores()
-    nenv, steps = 8 * cores, 10
+    nenv, steps = 8 * cores, 30   # 30 steps from a fresh reset: the same episode phases as the GPU's timed region (steps 5..35)
     pk = pack_trials(trials[: min(len(trials), nenv)], max_verts=24)
     cfg = env.cfg
     orc.bench(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail, pk, min(nenv, 4), 1, cores)  # warm the library
