@@ -26,6 +26,11 @@ struct bp_handle {
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
     int pack = 0;          // ship-ice step kernel: K envs per wavefront (4 / 2), 0 = one env per wavefront (k_physics_step)
     size_t pack_lds = 0;
+    // mixed launch (BP_MIX=<heavy envs>): the heaviest envs one per SIMD (k_physics_step_solo, high-priority stream), the rest two to a
+    // wavefront (k_physics_step_pack2) on the caller's stream
+    int mix_heavy = 0;
+    hipStream_t st_solo = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -162,6 +167,9 @@ int bp_destroy(bp_handle *h)
 {
     if (!h) return BP_EINVAL;
     DevGuard _dg(h->device);
+    if (h->st_solo) { hipStreamSynchronize(h->st_solo); hipStreamDestroy(h->st_solo); }
+    if (h->ev_fork) hipEventDestroy(h->ev_fork);
+    if (h->ev_join) hipEventDestroy(h->ev_join);
     for (void *p : h->allocs) hipFree(p);
     for (hipEvent_t e : h->ev) hipEventDestroy(e);
     delete h;
@@ -293,7 +301,22 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             }
         int want = 0;
         if (const char *ev = getenv("BP_PACK")) want = atoi(ev);
-        if (plain && (want == 2 || want == 4) && pk_lds_bytes(want, nbcap) <= 40 * 1024) {
+        int mix = 0;
+        if (const char *ev = getenv("BP_MIX")) mix = atoi(ev);
+        if (plain && mix > 0 && pk_lds_bytes(2, nbcap) <= 40 * 1024 && h->num_envs >= 4 * mix) {
+            h->mix_heavy = mix;
+            h->P.cost_proxy = 1;
+            h->pack_lds = pk_lds_bytes(2, nbcap);
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(2, nbcap)));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            if (!h->st_solo) {
+                int lo = 0, hi = 0;
+                HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(h, hipStreamCreateWithPriority(&h->st_solo, hipStreamNonBlocking, hi));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+            }
+        } else if (plain && (want == 2 || want == 4) && pk_lds_bytes(want, nbcap) <= 40 * 1024) {
             h->pack = want;
             h->pack_lds = pk_lds_bytes(want, nbcap);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(4, nbcap)));
@@ -525,10 +548,21 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         if (mode == MODE_STEP) h->steps_done = true;
         if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (mode == MODE_STEP && h->mix_heavy > 0 && h->D.order != nullptr && h->D.dbg == nullptr) {
+            const int NH = h->mix_heavy, NL = h->num_envs - NH;
+            HIPCHK(h, hipEventRecord(h->ev_fork, st));
+            HIPCHK(h, hipStreamWaitEvent(h->st_solo, h->ev_fork, 0));
+            hipLaunchKernelGGL(k_physics_step_solo, dim3(NH), dim3(64), h->lds_bytes, h->st_solo, h->P, h->D, actions, reward, term, trunc, info);
+            HIPCHK(h, hipGetLastError());
+            HIPCHK(h, hipEventRecord(h->ev_join, h->st_solo));
+            hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 3000u);
+            hipLaunchKernelGGL(k_physics_step_pack2, dim3((NL + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, NH, NL);
+            HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+        }
         else if (mode == MODE_STEP && h->pack == 4 && h->D.dbg == nullptr)
-            hipLaunchKernelGGL(k_physics_step_pack4, dim3((h->num_envs + 3) / 4), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info);
+            hipLaunchKernelGGL(k_physics_step_pack4, dim3((h->num_envs + 3) / 4), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, 0, h->num_envs);
         else if (mode == MODE_STEP && h->pack == 2 && h->D.dbg == nullptr)
-            hipLaunchKernelGGL(k_physics_step_pack2, dim3((h->num_envs + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info);
+            hipLaunchKernelGGL(k_physics_step_pack2, dim3((h->num_envs + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, 0, h->num_envs);
         else if (mode == MODE_STEP)
             hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (h->resettle && h->maze8)

@@ -87,6 +87,7 @@ struct SubState {
     double total_ke, total_imp;
     unsigned n_post, n_contact, n_first;
     int err;
+    unsigned costp;            // work proxy of the env step: sum over sub-steps of 16 + 2 * active arbiters + 4 * warm arbiters * colours
     int yaw_violated, boundary_violated;
     int wall_flag;             // maze: robot body touched a wall (pre_solve of the (1,3) handler)
     int quiescent;             // set by substep(): nothing moves and no arbiter is warm -> later sub-steps are no-ops
@@ -783,6 +784,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     }
     PROF_CNT(21, __popcll(wmask))
     PROF_MAX(13, __popcll(wmask))
+    S.costp += 16u + 2u * (unsigned)__popcll(amask) + 4u * (unsigned)(__popcll(wmask) * S.nlevels);
     lds_sync();
     // ---- 6b. velocity integrate: damping^dt == 0, no gravity/forces -> dynamic bodies' v, w := +0 ---------------
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {

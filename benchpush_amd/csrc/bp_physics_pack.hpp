@@ -1059,7 +1059,7 @@ __device__ __forceinline__ void pk_substep(const DevParams &P, const DevPtrs &D,
 template <int K, int R>
 __device__ __forceinline__ void pk_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                         double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                        unsigned char *__restrict__ truncated, double *__restrict__ info)
+                                        unsigned char *__restrict__ truncated, double *__restrict__ info, const int pos0, const int npos)
 {
     const int lane = lane_id();
     const int W = (int)gridDim.x;
@@ -1078,8 +1078,9 @@ __device__ __forceinline__ void pk_body(const DevParams &P, const DevPtrs &D, co
     // that the per-wave sums of the previous step's costs are about equal
 #pragma unroll
     for (int e = 0; e < K; e++) {
-        const int pos = (e & 1) ? ((e + 1) * W - 1 - (int)blockIdx.x) : (e * W + (int)blockIdx.x);
-        const bool valid = pos < P.num_envs;
+        const int rel = (e & 1) ? ((e + 1) * W - 1 - (int)blockIdx.x) : (e * W + (int)blockIdx.x);
+        const bool valid = rel < npos;   // the launch covers positions [pos0, pos0 + npos) of the dispatch order
+        const int pos = pos0 + rel;
         const int env = valid ? (D.order != nullptr ? D.order[pos] : pos) : 0;
         C.valid[e] = valid; C.env[e] = env;
         const int trial = valid ? D.e_trial[env] : 0;
@@ -1361,13 +1362,15 @@ __device__ __forceinline__ void pk_body(const DevParams &P, const DevPtrs &D, co
 
 __global__ __launch_bounds__(64) void k_physics_step_pack4(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
+                                                           unsigned char *__restrict__ truncated, double *__restrict__ info,
+                                                           const int pos0, const int npos)
 {
-    pk_body<4, 2>(P, D, actions, reward, terminated, truncated, info);
+    pk_body<4, 2>(P, D, actions, reward, terminated, truncated, info, pos0, npos);
 }
 __global__ __launch_bounds__(64, 2) void k_physics_step_pack2(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
+                                                           unsigned char *__restrict__ truncated, double *__restrict__ info,
+                                                           const int pos0, const int npos)
 {
-    pk_body<2, 1>(P, D, actions, reward, terminated, truncated, info);
+    pk_body<2, 1>(P, D, actions, reward, terminated, truncated, info, pos0, npos);
 }

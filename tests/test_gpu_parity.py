@@ -77,6 +77,12 @@ def test_parity_packed_step_kernel(monkeypatch, pack, E):
     assert _run_parity(E=E, conc=0.5, T=2, steps=10, seed=21) > 100
 
 
+def test_parity_mixed_launch(monkeypatch):
+    """BP_MIX: the heaviest envs in the one-SIMD-per-wave kernel on a second stream, the rest two to a wavefront -- same results."""
+    monkeypatch.setenv("BP_MIX", "2")
+    assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
+
+
 def test_parity_50pct_dense_field():
     assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
 
