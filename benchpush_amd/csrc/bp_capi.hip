@@ -29,6 +29,7 @@ struct bp_handle {
     // mixed launch (BP_MIX=<heavy envs>): the heaviest envs one per SIMD (k_physics_step_solo, high-priority stream), the rest two to a
     // wavefront (k_physics_step_pack2) on the caller's stream
     int mix_heavy = 0;
+    bool mix_light_packed = true;   // BP_MIX_LIGHT=old: the light envs on one env per wave (k_physics_step_from) instead of the packed kernel
     hipStream_t st_solo = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevParams P;
@@ -306,6 +307,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         if (plain && mix > 0 && pk_lds_bytes(2, nbcap) <= 40 * 1024 && h->num_envs >= 4 * mix) {
             h->mix_heavy = mix;
             h->P.cost_proxy = 1;
+            if (const char *ev2 = getenv("BP_MIX_LIGHT")) h->mix_light_packed = std::string(ev2) != "old";
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_from, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             h->pack_lds = pk_lds_bytes(2, nbcap);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(2, nbcap)));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -556,7 +559,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(h->ev_join, h->st_solo));
             hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 3000u);
-            hipLaunchKernelGGL(k_physics_step_pack2, dim3((NL + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, NH, NL);
+            if (h->mix_light_packed)
+                hipLaunchKernelGGL(k_physics_step_pack2, dim3((NL + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, NH, NL);
+            else
+                hipLaunchKernelGGL(k_physics_step_from, dim3(NL), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info, NH);
             HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
         }
         else if (mode == MODE_STEP && h->pack == 4 && h->D.dbg == nullptr)

@@ -516,6 +516,13 @@ __global__ __launch_bounds__(64) void k_physics_step(const DevParams P, const De
 {
     physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
 }
+// the same for the envs at positions [boff, boff + gridDim.x) of the dispatch order (mixed launch, light part on one env per wave)
+__global__ __launch_bounds__(64) void k_physics_step_from(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                          double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                          unsigned char *__restrict__ truncated, double *__restrict__ info, const int boff)
+{
+    physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, boff);
+}
 // Mixed launch (BP_MIX, bp_capi.hip): the same step for the heaviest envs in a kernel whose waves claim a SIMD each -- an accumulation
 // register is touched so that the wave's register allocation exceeds what leaves room for any other wave -- so that the envs that set
 // the launch time run without a SIMD mate; the light majority runs two to a wavefront (k_physics_step_pack2) beside them.
