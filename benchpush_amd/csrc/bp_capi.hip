@@ -396,8 +396,9 @@ int bp_load_maze(bp_handle *h, int32_t T, int32_t nbox, const double *centres, i
         // default 0 (Robot.sim sets mass and elasticity only, robot.py:90-105)
         for (int k = 0; k <= cf.num_wheels; k++) {
             Shape s;
-            if (k == 0) build_kinematic_part(cf.ship_verts, cf.num_ship_verts, start[0], start[1], start[2], s);
-            else build_kinematic_part(cf.wheel_verts[k - 1], 4, start[0], start[1], start[2], s);
+            const double *st3 = start + 3 * (size_t)t;   // start pose of this layout (maze_NAMO_env.py:229-245)
+            if (k == 0) build_kinematic_part(cf.ship_verts, cf.num_ship_verts, st3[0], st3[1], st3[2], s);
+            else build_kinematic_part(cf.wheel_verts[k - 1], 4, st3[0], st3[1], st3[2], s);
             s.radius = cf.poly_radius; s.e = cf.elasticity; s.u = 0.0;
             s.kind = kind_of(k == 0 ? 1 : 0, 1, BODY_KINEMATIC);
             bodies.push_back(s);

@@ -53,10 +53,6 @@ class BatchedMazeEnv(BatchedShipIceEnv):
             raise _lib.BpError("BatchedMazeEnv needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.L = _lib.load()
         self.cfg = _maze_cfg(cfg)
-        if self.cfg.get("random_start", False):
-            # maze_NAMO_env.py:229-238 re-draws the robot start per episode (rejection-sampled against walls and boxes); the batched
-            # layouts carry one start pose -- refuse instead of silently running fixed starts
-            raise NotImplementedError("maze-NAMO-v0: cfg.random_start is not supported by the batched GPU environment")
         self.num_envs = int(num_envs)
         self.env_id_offset = int(env_id_offset)
         self.device = torch.device(device)
@@ -81,7 +77,9 @@ class BatchedMazeEnv(BatchedShipIceEnv):
             raise ValueError("all layouts must hold the same number of boxes")
         centres = np.ascontiguousarray(np.stack([np.asarray(l["centres"], np.float64).reshape(nbox, 2) for l in layouts]))
         walls = np.ascontiguousarray(self.walls, np.float64)
-        start = np.ascontiguousarray(layouts[0]["start"], np.float64)
+        # one start pose per layout: the fixed pose, or the layout's draw of cfg.random_start (the reference re-draws per episode from
+        # python's unseeded global generator; here episode k plays layout (env + k) % T, whose start was drawn from Random(base_seed + t))
+        start = np.ascontiguousarray(np.stack([np.asarray(l["start"], np.float64).reshape(3) for l in layouts]))
         _lib.check(self.L, self.h, self.L.bp_load_maze(self.h, len(layouts), nbox, centres.ctypes.data_as(C.c_void_p), len(walls),
                                                        walls.ctypes.data_as(C.c_void_p), start.ctypes.data_as(C.c_void_p)), "bp_load_maze")
         self._alloc_io()

@@ -52,6 +52,19 @@ def maze_start(cfg):
     return (16.66, 16.66, 3 * math.pi / 2)
 
 
+def random_start(cfg, walls, rng):
+    """cfg.random_start (maze_NAMO_env.py:229-238): rejection-sample (x, y) in [1, start_range] until the point keeps
+    robot.min_obstacle_dist from every wall (point_query against the walls only: the boxes are drawn afterwards and are not tested
+    against the robot); heading 3 pi / 2.  Drawn before the boxes, like the reference, from the layout's generator."""
+    while True:
+        x = 1 + rng.random() * (cfg.start_x_range - 1)
+        y = 1 + rng.random() * (cfg.start_y_range - 1)
+        if not point_query_hits_wall(walls, x, y, cfg.robot.min_obstacle_dist):
+            return (x, y, np.pi * 3 / 2)
+
+
 def generate_layout(cfg, walls, seed):
+    """One episode's layout on ``random.Random(seed)`` in the reference's draw order: start pose (if cfg.random_start), then boxes."""
     rng = _random.Random(seed)
-    return {"centres": generate_boxes(cfg, walls, rng), "walls": np.array(walls, np.float64), "start": maze_start(cfg)}
+    start = random_start(cfg, walls, rng) if cfg.get("random_start", False) else maze_start(cfg)
+    return {"centres": generate_boxes(cfg, walls, rng), "walls": np.array(walls, np.float64), "start": start}

@@ -124,7 +124,8 @@ int bp_load_scenarios(bp_handle *h, int32_t num_trials, int32_t F, int32_t V, co
                       const int32_t *counts, const double *centres, const double *starts, const int32_t *nfloes);
 
 /* maze-NAMO-v0 counterpart of bp_load_scenarios: `num_layouts` box layouts (host pointers), centres[T][nbox][2], the wall
- * segments walls[nwalls][4] = ax, ay, bx, by (construct_maze_walls, maze_NAMO_env.py:357-375) and the start pose.  Builds the
+ * segments walls[nwalls][4] = ax, ay, bx, by (construct_maze_walls, maze_NAMO_env.py:357-375) and the start poses start[num_layouts][3]
+ * (the fixed pose of :241-245, or one draw of cfg.random_start per layout, :229-238).  Builds the
  * KINEMATIC robot (body + wheels, robot.py:77-118), the boxes (sim_utils.py:136-163), the static Segment(radius 0.5) walls
  * (sim_utils.py:174-181) and the BFS goal map (occupancy_map.py:435-485) on the host.  Replaces init_maze_NAMO_env (:221-269). */
 int bp_load_maze(bp_handle *h, int32_t num_layouts, int32_t nbox, const double *centres, int32_t nwalls, const double *walls,

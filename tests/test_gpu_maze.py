@@ -59,6 +59,21 @@ def test_parity_default_5_boxes_and_maze_v2():
     _run(E=2, nbox=8, T=2, steps=15, seed=9, maze_version=2)
 
 
+def test_parity_random_start_per_layout():
+    """cfg.random_start (maze_NAMO_env.py:229-238): every layout carries its own rejection-sampled start (heading 3 pi / 2), drawn before
+    the boxes from the layout's generator; the envs start there and match the oracle through resets."""
+    from benchpush_amd.envs.maze_namo import BatchedMazeEnv
+    from benchpush_amd.maze_scenario import point_query_hits_wall
+    env = BatchedMazeEnv(2, cfg={"num_obstacles": 6, "random_start": True, "maze_version": 2}, num_layouts=3, base_seed=3, device="cuda:0")
+    starts = [tuple(l["start"]) for l in env.layouts]
+    assert len(set(starts)) == 3 and all(abs(s[2] - 1.5 * math.pi) < 1e-15 and 1 <= s[0] <= 20 and 1 <= s[1] <= 20 for s in starts)
+    assert not any(point_query_hits_wall(env.walls, s[0], s[1], env.cfg.robot.min_obstacle_dist) for s in starts)
+    _, info = env.reset()
+    assert np.allclose(info[:, :3].cpu().numpy(), np.array(starts[:2]), atol=1e-9)   # the settle leaves the kinematic robot in place
+    env.close()
+    _run(E=3, nbox=6, T=3, steps=12, seed=3, random_start=True, maze_version=2)
+
+
 def test_parity_straight_drive_pushes_boxes():
     _run(E=2, nbox=20, T=2, steps=30, seed=2, action_fn=lambda e, t: 0.0)
 
