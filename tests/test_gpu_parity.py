@@ -252,6 +252,45 @@ def test_full_size_properties_4096_envs():
     assert x0.min() >= 1.0 and x0.max() <= 11.0
 
 
+def test_step_kernel_variants_agree_at_full_size(monkeypatch):
+    """4096 envs x 40 steps with auto-reset (deep enough for the cost-sorted dispatch order, the snake seating of the packed waves and
+    the heavy / light split of the mixed launch to matter): the packed kernels (BP_PACK=4, 2) and the mixed launch (BP_MIX) leave every
+    env in exactly the state of the one-env-per-wavefront kernel -- body state, rewards, termination, observations, episode metrics."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    trials = default_trials(0.3, 24, base_seed=3)
+    E, steps = 4096, 40
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(5)
+    acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
+
+    def run(env_vars):
+        for k in ("BP_PACK", "BP_MIX", "BP_MIX_LIGHT"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env_vars.items():
+            monkeypatch.setenv(k, v)
+        env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+        env.reset()
+        rsum = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+        nterm = 0
+        for t in range(steps):
+            obs, rew, term, _, info = env.step(acts[t])
+            rsum += rew
+            nterm += int(term.sum().item())
+            env.reset(term)
+        env.check_errors()
+        out = (env.body_state().clone(), rsum, env.obs.clone(), env.info.clone(), env.episode_metrics()[0].clone(), nterm)
+        env.close()
+        return out
+
+    ref = run({})
+    assert ref[5] > 1000                                       # episodes did end and restart inside the window
+    for variant in ({"BP_PACK": "4"}, {"BP_PACK": "2"}, {"BP_MIX": "512"}):
+        got = run(variant)
+        for a, b in zip(ref[:5], got[:5]):
+            assert torch.equal(a, b), variant
+        assert got[5] == ref[5]
+
+
 def test_gym_adapter_surface_and_metric_plumbing():
     import benchpush_amd
     from benchpush_amd.envs.ship_ice import default_trials
