@@ -36,9 +36,9 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
 {
     const int nbcap = P.nbcap;
     char *p = (char *)bp_smem;
-    L.sv = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
-    L.sw = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
-    L.sb = (d2 *)p; p += sizeof(d2) * BP_NSLOT;
+    L.sv = (d2 *)p; p += sizeof(d2) * (BP_NSLOT + 1);   // + 1: scratch slot BP_NSLOT
+    L.sw = (d2 *)p; p += sizeof(d2) * (BP_NSLOT + 1);
+    L.sb = (d2 *)p; p += sizeof(d2) * (BP_NSLOT + 1);
     L.tf = (d2 *)p; p += sizeof(d2) * 128;
     // scratch region shared by the plane search (res_*, pl_*) and, afterwards, the manifold mailbox
     char *scr = p;

@@ -802,8 +802,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     const int nlevels = wmask ? S.nlevels : 0;
     unsigned lvlmask = 0; // colours that hold at least one warm arbiter
     for (int lvl = 1; lvl <= nlevels; lvl++) if (ballot(warm && A.level == lvl)) lvlmask |= 1u << lvl;
-    for (int lvl = 1; lvl <= nlevels; lvl++) {
-        if (!(lvlmask & (1u << lvl))) continue;
+    for (unsigned lm = lvlmask; lm; lm &= lm - 1u) {
+        const int lvl = __ffs((int)lm) - 1;
         if (warm && A.level == lvl && A.state != ARB_FIRST) {
             d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
             d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
@@ -823,12 +823,17 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     PROF_ACC(7)
     // ---- 6d. sequential impulses (cpArbiterApplyImpulse) ------------------------------------------------------
     // two copies of the loop: with and without bias terms (wave-uniform, fixed for the sub-step) -> no per-contact uniform branches
+    // Write-back slots of a solver pass: the (unchanged) velocity of an infinite-mass body goes to the scratch slot BP_NSLOT instead of
+    // being predicated away -- two EXEC-mask branches less per pass (+2.8 % env-steps/s, same-box A/B).  Not for box-delivery, whose
+    // kernel sits at the 256-VGPR limit of two waves per SIMD.
+    constexpr bool SCRATCH_WB = (KIND != BP_ENV_BOX);
+    const int wA = (!SCRATCH_WB || A.ma != 0.0) ? A.slotA : BP_NSLOT, wB = (!SCRATCH_WB || A.mb != 0.0) ? A.slotB : BP_NSLOT;
     auto iterate = [&](auto bias_tag) {
     constexpr bool AB = decltype(bias_tag)::value;
     for (int it = 0; it < P.iterations; it++) {
         bool changed = false;
-        for (int lvl = 1; lvl <= nlevels; lvl++) {
-            if (!(lvlmask & (1u << lvl))) continue;
+        for (unsigned lm = lvlmask; lm; lm &= lm - 1u) { // colours that hold a warm arbiter, ascending
+            const int lvl = __ffs((int)lm) - 1;
             if (warm && A.level == lvl) {
                 d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
                 d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
@@ -877,8 +882,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
                     }
                 }
-                if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; if (AB) L.sb[A.slotA] = vba; }
-                if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; if (AB) L.sb[A.slotB] = vbb; }
+                if (SCRATCH_WB) {
+                    L.sv[wA] = va; L.sw[wA] = wa2; if (AB) L.sb[wA] = vba;
+                    L.sv[wB] = vb; L.sw[wB] = wb2; if (AB) L.sb[wB] = vbb;
+                } else {
+                    if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; if (AB) L.sb[A.slotA] = vba; }
+                    if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; if (AB) L.sb[A.slotB] = vbb; }
+                }
             }
             lds_sync();
         }
