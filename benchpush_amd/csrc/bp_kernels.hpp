@@ -342,7 +342,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     for (int it = 0; it < nsub; it++) {
         substep<KIND>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
-        if (S.quiescent && D.dbg == nullptr) {
+        if (BP_UNLIKELY2(S.quiescent && D.dbg == nullptr)) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active
             // arbiters are re-stamped (FIRST -> NORMAL), cached ones age out after `persistence` sub-steps, and the
@@ -360,7 +360,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             }
             break;
         }
-        if (D.dbg != nullptr && env == D.dbg_env) {
+        if (BP_UNLIKELY2(D.dbg != nullptr && env == D.dbg_env)) {
             for (int base = 0; base < E.nb; base += 64) {
                 const int i = base + lane;
                 if (i < E.nb) {

@@ -28,6 +28,12 @@
 #define PROF_MAX(slot, v)
 #endif
 
+
+// Wave-level branches that are rarely taken (neighbour-list refresh, first use of a velocity slot, new arbiter, recolouring, fixed-point exit,
+// debug / quiescent paths): telling the compiler keeps them out of line.  Block placement matters here: marking the second contact of the solver
+// pass *likely* costs 8 %, marking these unlikely gains 1.5 % (same-box A/B, tools/experiments/README.md).
+#define BP_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#define BP_UNLIKELY2(x) __builtin_expect(!!(x), 0)
 struct ArbReg {
     unsigned key, stamp, h0, h1;
     int state, count, level, rank;
@@ -104,7 +110,7 @@ struct SubState {
 __device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, int body)
 {
     int s = L.slot_of[body];
-    if (s == 255) {
+    if (BP_UNLIKELY(s == 255)) {
         s = S.nslots;
         if (s >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; s = BP_NSLOT - 1; }
         else S.nslots = s + 1;
@@ -300,8 +306,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         PROF_ACC(0)
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
         unsigned long long rm = ballot((lane < cnt) && L.rf[lane < cnt ? lane : 0]);
-        if (rm) __syncthreads(); // refresh_body reads the AABBs other lanes have just stored
-        while (rm) {
+        if (BP_UNLIKELY(rm != 0)) __syncthreads(); // refresh_body reads the AABBs other lanes have just stored
+        while (BP_UNLIKELY(rm != 0)) {
             const int kk = __ffsll((long long)rm) - 1;
             rm &= rm - 1;
             refresh_body(P, E, L.mv[k0 + kk], S.err);
@@ -589,12 +595,12 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     const unsigned key = ((unsigned)__builtin_amdgcn_readlane(sa, l) << 16) | (unsigned)__builtin_amdgcn_readlane(sb, l);
                     unsigned long long om = ballot(A.key == key);
                     bool fr = false;
-                    if (!om) { om = ballot(A.key == ARB_FREE_KEY); fr = true; }
-                    if (!om) { S.err |= BP_ERR_ARB_OVERFLOW; }
+                    if (BP_UNLIKELY2(!om)) { om = ballot(A.key == ARB_FREE_KEY); fr = true; }
+                    if (BP_UNLIKELY2(!om)) { S.err |= BP_ERR_ARB_OVERFLOW; }
                     else {
                         const int owner = __ffsll((long long)om) - 1;
                         int s1 = 0, s2 = 0;
-                        if (fr) { s1 = slot_get(L, S, (int)(key >> 16)); s2 = slot_get(L, S, (int)(key & 0xFFFFu)); }
+                        if (BP_UNLIKELY2(fr)) { s1 = slot_get(L, S, (int)(key >> 16)); s2 = slot_get(L, S, (int)(key & 0xFFFFu)); }
                         if (lane == owner) {
                             my_mb = dr - dbase; fresh = fr; A.key = key;
                             if (fr) { A.slotA = s1; A.slotB = s2; }
@@ -748,7 +754,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     const bool any_bias = ballot(warm && ((A.bias0 != 0.0) || (A.count > 1 && A.bias1 != 0.0))) != 0;
     // ---- solve order: greedy colouring of the active set in ascending key order (cached while the set is unchanged);
     //      arbiters of one colour share no dynamic body, so a colour runs in parallel; order = (colour, key) ----------
-    if (amask != S.prev_amask) {
+    if (BP_UNLIKELY(amask != S.prev_amask)) {
         int rank = 0;
         unsigned long long m = amask;
         while (m) {
@@ -894,7 +900,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         // an iteration that changed no accumulated impulse applied only zero impulses: the state is a fixed point and
         // the remaining iterations would repeat it exactly
-        if (!ballot(changed)) break;
+        if (BP_UNLIKELY2(!ballot(changed))) break;
     }
     };
     if (any_bias) iterate(std::true_type{}); else iterate(std::false_type{});
