@@ -44,6 +44,12 @@ def test_published_envelope_is_what_the_tool_measures():
     assert 0.0 < e["floe_position_max_abs_m_after_k_steps"]["1"] < e["floe_position_max_abs_m_after_k_steps"]["20"]
 
 
+def test_50pct_envelope_has_the_same_exact_quantities():
+    e50 = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "order_envelope_50pct.json")))["envelope"]
+    assert e50["ship_pose_max_abs"] == 0 and e50["termination_step_mismatches"] == 0 and e50["success_mismatches"] == 0
+    assert e50["total_work_episode_mean_rel"] < 0.01 and e50["batch_mean_total_work_rel"] < 0.01
+
+
 def test_sample_stays_inside_the_envelope():
     trials = default_trials(0.3, 6, base_seed=0)
     jobs = [(trials[i], i, 24, mode) for mode in (0, 1, 3) for i in range(6)]
