@@ -182,14 +182,15 @@ def test_whole_episode_soak_no_capacity_flags(E, conc, steps):
     env.close()
 
 
-def test_sampled_envs_bit_exact_over_300_steps():
-    """8 envs x 300 steps against the oracle (the parity suite's other cases stop at 40 steps): body state, rewards, termination and
-    observations stay identical through whole episodes, resets included."""
+@pytest.mark.parametrize("E,conc,steps", [(8, 0.3, 300), (4, 0.5, 120)])
+def test_sampled_envs_bit_exact_over_300_steps(E, conc, steps):
+    """8 envs x 300 steps at 30 % (and 4 x 120 at 50 %, the concentration of config C5) against the oracle -- the parity suite's other
+    cases stop at 40 steps: body state, rewards, termination and observations stay identical through whole episodes, resets included."""
     from benchpush_amd.envs.ship_ice import default_trials
     from oracle.oracle import OracleShipIce
-    E, T = 8, 4
-    trials = default_trials(0.3, T, base_seed=40)
-    env = _mk(E, 0.3, trials)
+    T = 4
+    trials = default_trials(conc, T, base_seed=40)
+    env = _mk(E, conc, trials)
     c = env.cfg
     orcs = [OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail) for _ in range(E)]
     obs, _ = env.reset()
@@ -199,7 +200,7 @@ def test_sampled_envs_bit_exact_over_300_steps():
         assert np.array_equal(obs[e].cpu().numpy(), oo)
     rng = np.random.default_rng(8)
     age = np.zeros(E, int)
-    for t in range(300):
+    for t in range(steps):
         a = rng.uniform(-1, 1, E) * 0.35
         obs, rew, term, _, info = env.step(torch.from_numpy(a))
         bs = env.body_state().cpu().numpy()
