@@ -122,6 +122,7 @@ def maze_physics_params(cfg):
         boundary_penalty=-50.0, terminal_reward=200.0,
         local_w=float(cfg.occ.local_width), local_h=float(cfg.occ.local_height), vshift=0.0, obs_range=0.0,
         wall_radius=0.5,                          # sim_utils.py:177
+        ship_mass=float(cfg.robot.mass),          # m0 of MazeNamoMetric.compute_effort_score (maze_namo_metric.py:36-42)
     )
 
 

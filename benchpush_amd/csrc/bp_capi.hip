@@ -431,6 +431,10 @@ int bp_load_maze(bp_handle *h, int32_t T, int32_t nbox, const double *centres, i
     HIPCHK(h, hipMemcpy(d_norm, norm.data(), sizeof(double) * norm.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_wall, wall.data(), wall.size(), hipMemcpyHostToDevice));
     h->D.dist_map = d_norm; h->D.wall_map = d_wall;
+    double *d_raw;
+    if ((rc = dalloc(h, &d_raw, h->goal_raw.size()))) return rc;
+    HIPCHK(h, hipMemcpy(d_raw, h->goal_raw.data(), sizeof(double) * h->goal_raw.size(), hipMemcpyHostToDevice));
+    h->D.goal_raw = d_raw;
     return upload_trials(h, trials);
 }
 
@@ -481,7 +485,12 @@ __global__ __launch_bounds__(256) void k_episode_metrics(const DevParams P, cons
     if (mode == 1) {
         if (mask != nullptr && mask[env] == 0) return;
         if (D.m_open[env] && a[5] > 0.0) emit(0.0);   // reset of a running episode: eps_complete by truncation
-        a[0] = 0.0; a[1] = 0.0; a[2] = x; a[3] = y; a[4] = P.goal_y - y; a[5] = 0.0; a[6] = 0.0; a[7] = 0.0;
+        double L = P.goal_y - y;                      // ShipIceMetric: goal line - start y (ship_ice_metric.py:52)
+        if (P.env_kind == BP_ENV_MAZE) {              // MazeNamoMetric: wavefront length at the start pixel (maze_namo_metric.py:68-75)
+            const int px = (int)(x * P.m_to_pix), py = (int)(y * P.m_to_pix);
+            L = (px >= 0 && px < P.grid_w && py >= 0 && py < P.grid_h) ? D.goal_raw[(size_t)py * P.grid_w + px] / P.m_to_pix : 0.0;
+        }
+        a[0] = 0.0; a[1] = 0.0; a[2] = x; a[3] = y; a[4] = L; a[5] = 0.0; a[6] = 0.0; a[7] = 0.0;
         D.m_open[env] = 1;
         return;
     }
@@ -579,7 +588,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         else
             hipLaunchKernelGGL(k_reset_copy, dim3(h->num_envs), dim3(256), 0, st, h->P, h->D, mask, info);
         HIPCHK(h, hipGetLastError());
-        if (h->P.env_kind == BP_ENV_SHIP_ICE) {
+        if (h->P.env_kind == BP_ENV_SHIP_ICE || h->P.env_kind == BP_ENV_MAZE) {
             hipLaunchKernelGGL(k_episode_metrics, dim3((h->num_envs + 255) / 256), dim3(256), 0, st, h->P, h->D, mode == MODE_STEP ? 0 : 1, mask);
             HIPCHK(h, hipGetLastError());
         }
@@ -713,7 +722,8 @@ int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *s
 {
     if (!h) return BP_EINVAL;
     if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
-    if (h->P.env_kind != BP_ENV_SHIP_ICE) return fail(h, BP_EINVAL, "episode metrics are kept for ship-ice handles only");
+    if (h->P.env_kind != BP_ENV_SHIP_ICE && h->P.env_kind != BP_ENV_MAZE)
+        return fail(h, BP_EINVAL, "episode metrics are kept for ship-ice and maze handles only");
     BP_DEVICE(h);
     if (rows) HIPCHK(h, hipMemcpyAsync(rows, h->D.m_rows, sizeof(double) * BP_EPM_COUNT * h->num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->D.m_count, sizeof(unsigned) * h->num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));

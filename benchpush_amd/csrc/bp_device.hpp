@@ -51,6 +51,7 @@ struct DevPtrs {
     const int *sc_kind;      // [T][nbcap] collision_type | group << 8 | body_type << 16 (group != 0: parts of one body)
     const double *dist_map;  // maze: normalised BFS goal map [grid_h][grid_w]
     const unsigned char *wall_map; // maze: wall raster [grid_h][grid_w]
+    const double *goal_raw;  // maze: un-normalised wavefront map (info['goal_dt']) [grid_h][grid_w]
     // env state
     int *e_trial, *e_episode, *e_nb, *e_err;
     int *e_flags;            // [E] maze: bit0 wall_collision (sticky), bit1 prev_dist valid

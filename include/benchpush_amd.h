@@ -181,7 +181,8 @@ int bp_get_body_state(bp_handle *h, double *out, void *stream);
 /* low-dimensional observation (ship_ice_env.py:358-370): |centroid| of every floe, device double [E][nb_cap-1][2] */
 int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream);
 
-/* Per-episode metrics accumulated on the device (ship-ice handles): what ShipIceMetric.update / reset keep per episode
+/* Per-episode metrics accumulated on the device (ship-ice and maze handles; the maze uses MazeNamoMetric's L = wavefront length at the
+ * start pixel, maze_namo_metric.py:68-75, and bp_config.ship_mass = cfg.robot.mass): what ShipIceMetric.update / reset keep per episode
  * (benchpush/common/metrics/ship_ice_metric.py:26-69, base_metric.py:12-16) -- summed reward, path length of the ship integrated from
  * the state rounded to 2 decimals like info['state'] (ship_ice_env.py:337-339), total_work, success, steps -- updated by every bp_step /
  * bp_reset.  When an env terminates (or is reset while its episode is still running: eps_complete by truncation) its row is written:

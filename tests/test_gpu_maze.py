@@ -123,3 +123,52 @@ def test_full_size_properties_4096_envs():
         assert (obs[:, 0].view(E, -1).max(dim=1).values == 255).all()              # the robot is always in its own view
         env.reset(term)
     env.check_errors()
+
+
+def test_episode_metrics_equal_host_maze_namo_metric():
+    """On-device episode rows (bp_get_episode_metrics) == MazeNamoMetric.reset / update (maze_namo_metric.py:25-75) fed step by step:
+    L from the wavefront map at the rounded start pixel, path length from the rounded state, effort with the robot's mass."""
+    from benchpush_amd.envs.maze_namo import BatchedMazeEnv
+    from benchpush_amd.metrics import MazeNamoMetric
+    E = 4
+    env = BatchedMazeEnv(E, cfg={"num_obstacles": 8}, num_layouts=3, base_seed=1, device="cuda:0")
+    gdt, s = env.goal_map(), float(env.cfg.occ.m_to_pix_scale)
+    host = [MazeNamoMetric("x", robot_mass=float(env.cfg.robot.mass)) for _ in range(E)]
+
+    def info_dict(row, reset=False):
+        d = {"state": (round(float(row[0]), 2), round(float(row[1]), 2), round(float(row[2]), 2)), "total_work": float(row[3]),
+             "trial_success": bool(row[8])}
+        if reset:
+            d.update(goal_dt=gdt, m_to_pix_scale=s)
+        return d
+
+    _, info = env.reset()
+    for e in range(E):
+        host[e].reset(info_dict(info[e].cpu().numpy(), reset=True))
+    rng = np.random.default_rng(2)
+    lengths, finished, nrows = np.zeros(E, int), np.zeros(E, int), 0
+    for t in range(60):
+        a = rng.uniform(-1, 1, E)
+        a[0], a[1] = 1.0, -1.0                                  # hard-over: these end on a wall and restart
+        _, rew, term, _, info = env.step(torch.from_numpy(a))
+        inf, rw, tm = info.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy().astype(bool)
+        rows, cnt = env.episode_metrics()
+        rows, cnt = rows.cpu().numpy(), cnt.cpu().numpy()
+        lengths += 1
+        for e in range(E):
+            host[e].update(info_dict(inf[e]), float(rw[e]), eps_complete=bool(tm[e]))
+            if tm[e]:
+                finished[e] += 1
+                nrows += 1
+                assert cnt[e] == finished[e] and rows[e, 2] == host[e].rewards[-1] and rows[e, 3] == float(inf[e, 8])
+                assert rows[e, 4] == lengths[e] and rows[e, 5] == inf[e, 3]
+                assert math.isclose(rows[e, 0], host[e].efficiency_scores[-1], rel_tol=1e-12, abs_tol=0.0)
+                assert math.isclose(rows[e, 1], host[e].effort_scores[-1], rel_tol=1e-12, abs_tol=0.0)
+        if tm.any():
+            _, info2 = env.reset(term)
+            for e in np.nonzero(tm)[0]:
+                host[e].reset(info_dict(info2[e].cpu().numpy(), reset=True))
+                lengths[e] = 0
+    assert nrows >= 2
+    env.check_errors()
+    env.close()
