@@ -30,8 +30,9 @@ struct bp_handle {
     // wavefront (k_physics_step_pack2) on the caller's stream
     int mix_heavy = 0;
     bool mix_light_packed = true;   // BP_MIX_LIGHT=old: the light envs on one env per wave (k_physics_step_from) instead of the packed kernel
-    hipStream_t st_solo = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int mix_plain = 0;              // BP_MIX_PLAIN=<n>: the next n envs of the cost order on one env per wave beside the solo and the packed kernel
+    hipStream_t st_solo = nullptr, st_mid = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -169,6 +170,8 @@ int bp_destroy(bp_handle *h)
     if (!h) return BP_EINVAL;
     DevGuard _dg(h->device);
     if (h->st_solo) { hipStreamSynchronize(h->st_solo); hipStreamDestroy(h->st_solo); }
+    if (h->st_mid) { hipStreamSynchronize(h->st_mid); hipStreamDestroy(h->st_mid); }
+    if (h->ev_join2) hipEventDestroy(h->ev_join2);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (void *p : h->allocs) hipFree(p);
@@ -308,6 +311,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->mix_heavy = mix;
             h->P.cost_proxy = 1;
             if (const char *ev2 = getenv("BP_MIX_LIGHT")) h->mix_light_packed = std::string(ev2) != "old";
+            if (const char *ev2 = getenv("BP_MIX_PLAIN")) h->mix_plain = std::max(0, std::min(atoi(ev2), h->num_envs - mix - 2));
+            if (const char *ev2 = getenv("BP_MIX_PAIR")) h->P.pack_adjacent = std::string(ev2) == "adjacent";
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_from, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             h->pack_lds = pk_lds_bytes(2, nbcap);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(2, nbcap)));
@@ -316,6 +321,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 int lo = 0, hi = 0;
                 HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
                 HIPCHK(h, hipStreamCreateWithPriority(&h->st_solo, hipStreamNonBlocking, hi));
+                HIPCHK(h, hipStreamCreateWithPriority(&h->st_mid, hipStreamNonBlocking, hi));
+                HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
                 HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
                 HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
             }
@@ -562,18 +569,26 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (mode == MODE_STEP && h->mix_heavy > 0 && h->D.order != nullptr && h->D.dbg == nullptr) {
-            const int NH = h->mix_heavy, NL = h->num_envs - NH;
+            const int NP = h->mix_plain;
+            const int NH = h->mix_heavy + NP, NL = h->num_envs - NH;
             HIPCHK(h, hipEventRecord(h->ev_fork, st));
             HIPCHK(h, hipStreamWaitEvent(h->st_solo, h->ev_fork, 0));
-            hipLaunchKernelGGL(k_physics_step_solo, dim3(NH), dim3(64), h->lds_bytes, h->st_solo, h->P, h->D, actions, reward, term, trunc, info);
+            hipLaunchKernelGGL(k_physics_step_solo, dim3(h->mix_heavy), dim3(64), h->lds_bytes, h->st_solo, h->P, h->D, actions, reward, term, trunc, info);
             HIPCHK(h, hipGetLastError());
             HIPCHK(h, hipEventRecord(h->ev_join, h->st_solo));
+            if (NP > 0) { // the next NP envs of the cost order: one env per wave, two waves per SIMD
+                HIPCHK(h, hipStreamWaitEvent(h->st_mid, h->ev_fork, 0));
+                hipLaunchKernelGGL(k_physics_step_from, dim3(NP), dim3(64), h->lds_bytes, h->st_mid, h->P, h->D, actions, reward, term, trunc, info, h->mix_heavy);
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipEventRecord(h->ev_join2, h->st_mid));
+            }
             hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 3000u);
             if (h->mix_light_packed)
                 hipLaunchKernelGGL(k_physics_step_pack2, dim3((NL + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, NH, NL);
             else
                 hipLaunchKernelGGL(k_physics_step_from, dim3(NL), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info, NH);
             HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+            if (NP > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join2, 0));
         }
         else if (mode == MODE_STEP && h->pack == 4 && h->D.dbg == nullptr)
             hipLaunchKernelGGL(k_physics_step_pack4, dim3((h->num_envs + 3) / 4), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, 0, h->num_envs);

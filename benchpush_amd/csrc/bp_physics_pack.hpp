@@ -1078,7 +1078,7 @@ __device__ __forceinline__ void pk_body(const DevParams &P, const DevPtrs &D, co
     // that the per-wave sums of the previous step's costs are about equal
 #pragma unroll
     for (int e = 0; e < K; e++) {
-        const int rel = (e & 1) ? ((e + 1) * W - 1 - (int)blockIdx.x) : (e * W + (int)blockIdx.x);
+        const int rel = P.pack_adjacent ? (K * (int)blockIdx.x + e) : ((e & 1) ? ((e + 1) * W - 1 - (int)blockIdx.x) : (e * W + (int)blockIdx.x));
         const bool valid = rel < npos;   // the launch covers positions [pos0, pos0 + npos) of the dispatch order
         const int pos = pos0 + rel;
         const int env = valid ? (D.order != nullptr ? D.order[pos] : pos) : 0;

@@ -83,6 +83,14 @@ def test_parity_mixed_launch(monkeypatch):
     assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
 
 
+def test_parity_three_way_launch(monkeypatch):
+    """BP_MIX + BP_MIX_PLAIN + BP_MIX_PAIR=adjacent: heaviest envs solo, the next ones one per wave, the rest packed in cost order (ragged last wave)."""
+    monkeypatch.setenv("BP_MIX", "2")
+    monkeypatch.setenv("BP_MIX_PLAIN", "3")
+    monkeypatch.setenv("BP_MIX_PAIR", "adjacent")
+    assert _run_parity(E=12, conc=0.3, T=3, steps=30, seed=6) > 500
+
+
 def test_parity_50pct_dense_field():
     assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
 
