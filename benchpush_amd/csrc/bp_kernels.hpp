@@ -891,6 +891,9 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
     __shared__ double s_fr[BP_MAX_SHIP_VERTS], s_fc[BP_MAX_SHIP_VERTS];
     __shared__ int s_fcnt, s_fbb[4];
     OPROF(0)
+    // the first AABB of every thread is requested together with the env scalars and the ship pose (its address needs neither): one cold
+    // round trip at the start of the kernel instead of three dependent ones
+    const double4 bb_first = D.bb[eb + min(1 + tid, nbcap - 1)];
     if (tid == 0) s_npass = 0;
     for (int w = tid; w < (npix + 3) / 4; w += OBS_THREADS_SHIP) ((unsigned *)s_img)[w] = 0u;
     __syncthreads();
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
     // ---- 1. conservative pre-test on the body AABBs (min/max of the same world vertices, grown by the shape radius): a floe whose
     //         AABB, grown by a pixel, misses the window cannot pass the exact pixel-box test of step 3 -> its vertices are not read
     for (int s = 1 + tid; s < nb; s += OBS_THREADS_SHIP) {
-        const double4 b = D.bb[eb + s];
+        const double4 b = (s == 1 + tid) ? bb_first : D.bb[eb + s];
         if (__builtin_floor(b.y * P.m_to_pix) - 1.0 > (double)gi1 || __builtin_ceil(b.w * P.m_to_pix) + 1.0 < (double)gi0 ||
             __builtin_floor(b.x * P.m_to_pix) - 1.0 > (double)gj1 || __builtin_ceil(b.z * P.m_to_pix) + 1.0 < (double)gj0) continue;
         const int slot = atomicAdd(&s_npass, 1);
@@ -966,9 +969,10 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
     for (int idx = tid; idx < ncand * BP_MAXV; idx += OBS_THREADS_SHIP) {
         const int k = idx / BP_MAXV, q = idx - k * BP_MAXV;
         const int s = s_list[cbase + k];
+        const d2 v = wv[(size_t)s * BP_MAXV + q]; // unconditional (slots >= n hold stale vertices of the same array): travels with nv[s]
         const int n = nv[s];
         if (q == 0) s_cn[k] = (unsigned char)n;
-        if (q < n) { const d2 v = wv[(size_t)s * BP_MAXV + q]; s_px[idx] = v.x; s_py[idx] = v.y; }
+        if (q < n) { s_px[idx] = v.x; s_py[idx] = v.y; }
     }
     __syncthreads();
     OPROF(3)
@@ -979,14 +983,29 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
         const int n = s_cn[k];
         double *xp = s_px + k * BP_MAXV, *yp = s_py + k * BP_MAXV;
         bool keep = true;
-        const d2 c = poly_centroid_xy(xp, yp, n);
-        const double cx = __builtin_fabs(c.x), cy = __builtin_fabs(c.y);
-        if (__builtin_fabs(sp.x - cx) > P.obs_range || __builtin_fabs(sp.y - cy) > P.obs_range) keep = false;
+        // poly_centroid_xy's three sums (area, x and y moments) and the pixel box in ONE pass over the vertices: five independent accumulators,
+        // each in the order of the sequential forms; the previous vertex stays in registers, so the in-place conversion to raster
+        // coordinates can happen in the same pass
+        double d1 = 0.0, d2_ = 0.0, sx = 0.0, sy = 0.0;
         double rmin = BP_INF, rmax = -BP_INF, cmin = BP_INF, cmax = -BP_INF;
+        double xq = xp[n - 1], yq = yp[n - 1];
         for (int i = 0; i < n; i++) {
-            const double r = yp[i] * P.m_to_pix, cc = xp[i] * P.m_to_pix;
+            const double xi = xp[i], yi = yp[i];
+            const double a = xi * yq, b = yi * xq;
+            d1 += a; d2_ += b;
+            const double u = a - xq * yi;
+            sx += (xi + xq) * u;
+            sy += (yi + yq) * u;
+            const double r = yi * P.m_to_pix, cc = xi * P.m_to_pix;
             xp[i] = cc; yp[i] = r;
             rmin = fmin(rmin, r); rmax = fmax(rmax, r); cmin = fmin(cmin, cc); cmax = fmax(cmax, cc);
+            xq = xi; yq = yi;
+        }
+        {
+            const double A = 0.5 * __builtin_fabs(d1 - d2_);
+            const double f = 1.0 / (6.0 * A);
+            const double cx = __builtin_fabs(__builtin_fabs(f * sx)), cy = __builtin_fabs(__builtin_fabs(f * sy));
+            if (__builtin_fabs(sp.x - cx) > P.obs_range || __builtin_fabs(sp.y - cy) > P.obs_range) keep = false;
         }
         long long minr = (long long)fmax(0.0, rmin), maxr = (long long)__builtin_ceil(rmax);
         long long minc = (long long)fmax(0.0, cmin), maxc = (long long)__builtin_ceil(cmax);
