@@ -158,6 +158,8 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
         h->obs_lds_bytes = (size_t)4 * (nwords + ((nwords + 1) & ~1)) + sizeof(double) * 2 * MZ_MAXBOX * 4;
         if (hipFuncSetAttribute((const void *)k_observe_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
     } else {
+        // k_observe composes two window rows as obs_w / 2 whole words per thread group
+        if (P.obs_h % 2 != 0 || P.obs_w % 2 != 0 || P.obs_w / 2 > OBS_THREADS_SHIP) { delete h; return BP_EINVAL; }
         h->obs_lds_bytes = (size_t)((P.obs_h * P.obs_w + 15) & ~15) + (size_t)((P.obs_h + 15) & ~15) + sizeof(double) * 2 * OBS_CHUNK * BP_MAXV;
         if (hipFuncSetAttribute((const void *)k_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->obs_lds_bytes) != hipSuccess) { delete h; return BP_EHIP; }
     }

@@ -794,15 +794,27 @@ __device__ __forceinline__ d2 poly_centroid_xy(const double *x, const double *y,
     return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
 }
 
+// byte mask of the first k bytes of a little-endian word (k <= 0: none, k >= 4: all)
+__device__ __forceinline__ unsigned obs_upto(int k) { return k <= 0 ? 0u : (k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u)); }
+// flag |= on the bytes [b0, b1] of an LDS byte image through word atomics (several wavefronts may touch one word)
+__device__ __forceinline__ void obs_or_bytes(unsigned *img32, int b0, int b1, unsigned char flag)
+{
+    for (int w = b0 >> 2; w <= (b1 >> 2); w++) {
+        const int lo = max(b0, 4 * w) - 4 * w, hi = min(b1, 4 * w + 3) - 4 * w;
+        atomicOr(&img32[w], (obs_upto(hi + 1) & ~obs_upto(lo)) & ((unsigned)flag * 0x01010101u));
+    }
+}
+
 // One raster row of skimage.draw.polygon for a CONVEX polygon (xp = columns, yp = rows, raster coordinates), columns [c0, c1]:
 // the inside pixels of the row form one span between the two edges that straddle it.  With every vertex at least OBS_SNAP_Y away
 // from the row, point_in_polygon's crossing tests have the sign of (X - x) * dy for the crossing abscissa X of an edge (error
 // ~1e-13 px), so pixels strictly between the two crossings are inside and the others outside; a crossing within OBS_SNAP_X of a
 // pixel centre is decided by the exact test on that pixel.  Rows with a vertex within OBS_SNAP_Y (vertex / edge rules of
 // point_in_polygon) or not exactly two crossings fall back to the exact test on every pixel.  Identical to testing every pixel.
+// OR_BITS: the bytes keep their other flag bits; `row` is then the image base and pixel gj is byte off + gj of it (word atomics).
 template <bool OR_BITS>
 __device__ __forceinline__ void raster_row_convex(const double *xp, const double *yp, int n, int gi, int c0, int c1, unsigned char *row,
-                                                  unsigned char flag)
+                                                  unsigned char flag, const int off = 0)
 {
     const double y = (double)gi;
     bool slow = false;
@@ -825,7 +837,7 @@ __device__ __forceinline__ void raster_row_convex(const double *xp, const double
     }
     if (slow || (ncross != 0 && ncross != 2)) {
         for (int gj = c0; gj <= c1; gj++)
-            if (pip_arrays(xp, yp, n, (double)gj, y)) { if (OR_BITS) row[gj] |= flag; else row[gj] = flag; }
+            if (pip_arrays(xp, yp, n, (double)gj, y)) { if (OR_BITS) obs_or_bytes((unsigned *)row, off + gj, off + gj, flag); else row[gj] = flag; }
         return;
     }
     if (ncross == 0) return;
@@ -840,7 +852,7 @@ __device__ __forceinline__ void raster_row_convex(const double *xp, const double
         else last = (int)__builtin_floor(xr);
     }
     first = max(first, c0); last = min(last, c1);
-    if (OR_BITS) { for (int gj = first; gj <= last; gj++) row[gj] |= flag; return; }
+    if (OR_BITS) { if (last >= first) obs_or_bytes((unsigned *)row, off + first, off + last, flag); return; }
     // plain stores: whole 32-bit words where the span covers them (every byte of such a word belongs to this span, and any other
     // writer of this phase stores the same flag), single bytes at the two ends
     unsigned char *p = row + first, *const pe = row + last + 1;
@@ -850,8 +862,6 @@ __device__ __forceinline__ void raster_row_convex(const double *xp, const double
     while (p < pe) *p++ = flag;
 }
 
-// byte mask of the first k bytes of a little-endian word (k <= 0: none, k >= 4: all)
-__device__ __forceinline__ unsigned obs_upto(int k) { return k <= 0 ? 0u : (k >= 4 ? 0xFFFFFFFFu : ((1u << (8 * k)) - 1u)); }
 
 // Flag bits of the LDS window image
 #ifdef BP_PROF
@@ -939,13 +949,16 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
                 s_fbb[2] = (int)(long long)fmax(0.0, cmin); s_fbb[3] = (int)(long long)__builtin_ceil(cmax);
             }
         }
-        const double hx = P.ship_head[0] * ch + P.ship_head[1] * -sh + sp.x, hy = P.ship_head[0] * sh + P.ship_head[1] * ch + sp.y;
-        const double tx = P.ship_tail[0] * ch + P.ship_tail[1] * -sh + sp.x, ty = P.ship_tail[0] * sh + P.ship_tail[1] * ch + sp.y;
-        hpx = to_u16(hx * m2gx); hpy = to_u16(hy * m2gy);
-        const long long tpx = to_u16(tx * m2gx), tpy = to_u16(ty * m2gy);
-        line = make_line(Wg, Hg, hpx, hpy, tpx, tpy);
-        hpx = hpx < 0 ? 0 : (hpx > Wg - 1 ? Wg - 1 : hpx);
-        hpy = hpy < 0 ? 0 : (hpy > Hg - 1 ? Hg - 1 : hpy);
+        line.valid = 0; hpx = hpy = 0;
+        if (tid >= 64 && tid < 128) { // only the second wavefront draws the heading line and the head pixel (step 5)
+            const double hx = P.ship_head[0] * ch + P.ship_head[1] * -sh + sp.x, hy = P.ship_head[0] * sh + P.ship_head[1] * ch + sp.y;
+            const double tx = P.ship_tail[0] * ch + P.ship_tail[1] * -sh + sp.x, ty = P.ship_tail[0] * sh + P.ship_tail[1] * ch + sp.y;
+            hpx = to_u16(hx * m2gx); hpy = to_u16(hy * m2gy);
+            const long long tpx = to_u16(tx * m2gx), tpy = to_u16(ty * m2gy);
+            line = make_line(Wg, Hg, hpx, hpy, tpx, tpy);
+            hpx = hpx < 0 ? 0 : (hpx > Wg - 1 ? Wg - 1 : hpx);
+            hpy = hpy < 0 ? 0 : (hpy > Hg - 1 ? Hg - 1 : hpy);
+        }
     }
     // goal-distance value per window row (occupancy_map.py:413-433): max(0, goal - i*g2m)/goal, out of map -> 1
     const double g2m = P.map_h / (double)Hg;
@@ -1039,33 +1052,37 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
     }
     OPROF(5)
     // ---- 5. footprint (skimage.draw.polygon of the hull outline, exact test over its pixel box) and heading line -> flag bits.
-    //         Writers of one phase all store "previous bits | own bit" to a byte, so concurrent stores agree. ----
-    // One wavefront does the three in turn: the LDS operations of a wave execute in issue order, so its later read-modify-writes see
-    // its earlier ones without a workgroup barrier (the occupancy stores of all waves are behind the barrier above).
+    //         The first wavefront sets the ship bits, the second the heading line and the head pixel, both with word atomics (the two overlap,
+    //         and a word may straddle two rows), so they need no order between them; the occupancy stores are behind the barrier above. ----
     if (tid < 64) {
         if (s_fcnt > 0) {   // the hull outline (vertices outside the grid dropped) stays convex: same exact scanline spans as the floes
             const int r0 = max(s_fbb[0], max(gi0, 0)), r1 = min(s_fbb[1], min(gi1, Hg - 1));
             const int c0 = max(s_fbb[2], max(gj0, 0)), c1 = min(s_fbb[3], min(gj1, Wg - 1));
             if (c1 >= c0)
                 for (int gi = r0 + tid; gi <= r1; gi += 64)
-                    raster_row_convex<true>(s_fc, s_fr, s_fcnt, gi, c0, c1, s_img + (gi - gi0) * LW - gj0, (unsigned char)OBS_F_SHIP);
+                    raster_row_convex<true>(s_fc, s_fr, s_fcnt, gi, c0, c1, s_img, (unsigned char)OBS_F_SHIP, (gi - gi0) * LW - gj0);
         }
-        asm volatile("" ::: "memory");
+    } else if (tid < 128) {
+        const int l2 = tid - 64;
         if (line.valid) {   // cv2.line: pixel t of the 8-connected walk, t = 0 .. dmaj (closed form of on_line)
             const long long dmaj = line.vert ? line.dy : line.dx, dmin = line.vert ? line.dx : line.dy;
-            for (long long t = tid; t <= dmaj; t += 64) {
+            for (long long t = l2; t <= dmaj; t += 64) {
                 // coordinates are u16 (cast by the reference); inside the 1000 x 300 map 2 * dmin * t + dmaj fits u32
                 const long long mt = (dmaj == 0) ? 0 : ((dmaj < 32768 && dmin < 32768)
                                          ? (long long)(((unsigned)(2 * dmin * t) + (unsigned)dmaj - 1u) / (unsigned)(2 * dmaj))
                                          : (2 * dmin * t + dmaj - 1) / (2 * dmaj));
                 const long long ax = line.vert ? mt : t, ay = line.vert ? t : mt;
                 const long long gj = line.x0 + ax * line.sx, gi = line.y0 + ay * line.sy;
-                if (gi >= gi0 && gi <= gi1 && gj >= gj0 && gj <= gj1 && gi >= 0 && gi < Hg && gj >= 0 && gj < Wg)
-                    s_img[((int)gi - gi0) * LW + ((int)gj - gj0)] |= OBS_F_LINE;
+                if (gi >= gi0 && gi <= gi1 && gj >= gj0 && gj <= gj1 && gi >= 0 && gi < Hg && gj >= 0 && gj < Wg) {
+                    const int b = ((int)gi - gi0) * LW + ((int)gj - gj0);
+                    obs_or_bytes((unsigned *)s_img, b, b, (unsigned char)OBS_F_LINE);
+                }
             }
         }
-        asm volatile("" ::: "memory");
-        if (tid == 0 && hpy >= gi0 && hpy <= gi1 && hpx >= gj0 && hpx <= gj1) s_img[((int)hpy - gi0) * LW + ((int)hpx - gj0)] |= OBS_F_HEAD;
+        if (l2 == 0 && hpy >= gi0 && hpy <= gi1 && hpx >= gj0 && hpx <= gj1) {
+            const int b = ((int)hpy - gi0) * LW + ((int)hpx - gj0);
+            obs_or_bytes((unsigned *)s_img, b, b, (unsigned char)OBS_F_HEAD);
+        }
     }
     __syncthreads();
     OPROF(6)
@@ -1073,31 +1090,33 @@ __global__ __launch_bounds__(OBS_THREADS_SHIP, 8) void k_observe(const DevParams
     //   ch0: in map 127, ship 255, out of map 0; ch1: row value, out of map 255; ch2: line 127, head 255; ch3: occupied 255
     const size_t plane = (size_t)npix;
     unsigned *o32 = (unsigned *)(obs + (size_t)env * BP_OBS_C * plane);
-    const int nwords = npix / 4; // 150*150 is a multiple of 4 (checked on the host)
-    // pixel 4*w = (li, lj) advances by 4*OBS_THREADS_SHIP pixels per trip: carried incrementally instead of dividing by the row length
-    const int adv = 4 * OBS_THREADS_SHIP, adv_r = adv / LW, adv_c = adv - adv_r * LW;
-    int li0 = (4 * tid) / LW, lj0 = 4 * tid - li0 * LW;
+    const int nwords = npix / 4;
+    // LW and LH are even (checked on the host), so two window rows are WP = LW / 2 whole words.  Thread (g, j) composes word j of the row pairs
+    // g, g + G, ...: which of its bytes lie in the first row of the pair and which lie inside the map's columns depends on j alone, so the byte
+    // masks are computed once per thread; per word only the two rows' in-map tests and goal-distance bytes change.
+    const int WP = LW / 2, G = OBS_THREADS_SHIP / WP;
+    const int g = tid / WP, j = tid - g * WP;
     const int ljlo = max(0, -gj0), ljhi = min(LW - 1, Wg - 1 - gj0);
-    for (int w = tid; w < nwords; w += OBS_THREADS_SHIP) {
-        const unsigned f = ((const unsigned *)s_img)[w];
-        // in-map byte mask and goal-distance bytes of the word, branch-free: bytes [0, bs) lie in window row li0, the rest (a word may
-        // straddle two rows) in row li0 + 1; columns inside the map are the window columns [ljlo, ljhi]
-        const int bs = LW - lj0;
+    if (g < G) {
+        const int bs = LW - 4 * j;             // bytes [0, bs) of the word lie in the first row of the pair
         const unsigned mlo = obs_upto(bs);
-        const int giA = gi0 + li0, giB = giA + 1;
-        const unsigned rowA = (giA >= 0 && giA < Hg) ? 0xFFFFFFFFu : 0u, rowB = (giB >= 0 && giB < Hg && li0 + 1 < LH) ? 0xFFFFFFFFu : 0u;
-        const unsigned colA = obs_upto(ljhi - lj0 + 1) & ~obs_upto(ljlo - lj0);
-        const unsigned colB = obs_upto(bs + ljhi + 1) & ~obs_upto(bs + ljlo);
-        const unsigned inb = (rowA & mlo & colA) | (rowB & ~mlo & colB);
-        const unsigned eA = (unsigned)s_edt[li0] * 0x01010101u, eB = (unsigned)s_edt[min(li0 + 1, LH - 1)] * 0x01010101u;
-        const unsigned e = ((eA & mlo) | (eB & ~mlo)) & inb;
-        const unsigned ship = (f >> 1) & 0x01010101u, ln = (f >> 2) & 0x01010101u, hd = (f >> 3) & 0x01010101u;
-        o32[w] = inb & (0x7F7F7F7Fu + ship * 0x80u);
-        o32[nwords + w] = e | ~inb;
-        o32[2 * nwords + w] = inb & ((ln & ~hd) * 127u + hd * 255u);
-        o32[3 * nwords + w] = (f & 0x01010101u) * 255u;
-        li0 += adv_r; lj0 += adv_c;
-        if (lj0 >= LW) { lj0 -= LW; li0++; }
+        const unsigned mA = mlo & obs_upto(ljhi - 4 * j + 1) & ~obs_upto(ljlo - 4 * j);
+        const unsigned mB = ~mlo & obs_upto(bs + ljhi + 1) & ~obs_upto(bs + ljlo);
+        for (int rp = g; 2 * rp < LH; rp += G) {
+            const int w = rp * WP + j;
+            const unsigned f = ((const unsigned *)s_img)[w];
+            const int giA = gi0 + 2 * rp, giB = giA + 1;
+            const unsigned rowA = (giA >= 0 && giA < Hg) ? 0xFFFFFFFFu : 0u, rowB = (giB >= 0 && giB < Hg) ? 0xFFFFFFFFu : 0u;
+            const unsigned inb = (rowA & mA) | (rowB & mB);
+            const unsigned e2 = ((const unsigned short *)s_edt)[rp];
+            const unsigned eA = (e2 & 0xFFu) * 0x01010101u, eB = (e2 >> 8) * 0x01010101u;
+            const unsigned e = ((eA & mlo) | (eB & ~mlo)) & inb;
+            const unsigned ship = (f >> 1) & 0x01010101u, ln = (f >> 2) & 0x01010101u, hd = (f >> 3) & 0x01010101u;
+            o32[w] = inb & (0x7F7F7F7Fu + ship * 0x80u);
+            o32[nwords + w] = e | ~inb;
+            o32[2 * nwords + w] = inb & ((ln & ~hd) * 127u + hd * 255u);
+            o32[3 * nwords + w] = (f & 0x01010101u) * 255u;
+        }
     }
     OPROF(7)
 }
