@@ -30,6 +30,7 @@ struct bp_handle {
     // wavefront (k_physics_step_pack2) on the caller's stream
     int mix_heavy = 0;
     bool mix_light_packed = true;   // BP_MIX_LIGHT=old: the light envs on one env per wave (k_physics_step_from) instead of the packed kernel
+    int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
     int mix_plain = 0;              // BP_MIX_PLAIN=<n>: the next n envs of the cost order on one env per wave beside the solo and the packed kernel
     hipStream_t st_solo = nullptr, st_mid = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
@@ -309,6 +310,23 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         if (const char *ev = getenv("BP_PACK")) want = atoi(ev);
         int mix = 0;
         if (const char *ev = getenv("BP_MIX")) mix = atoi(ev);
+        // Preemptive scheduler (k_physics_step_sched), the default step kernel of a ship-ice handle: chunks of 40 sub-steps.  It pays while the launch
+        // is a few rounds of the wave slots (+14 % at 4096 envs; -1 % at 16 384, where the tail is amortised): BP_SCHED=<chunk> forces it, BP_SCHED=0
+        // selects the one-wave-per-env kernel.
+        int ch = (h->num_envs <= 8192) ? 40 : 0;
+        if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
+        if (plain && ch > 0 && mix <= 0 && want == 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
+            h->sched_chunk = ch;
+            h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch;
+            h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
+            int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
+            if ((rc = dalloc(h, &d_items, (size_t)8 * SQ_MAXLEV * h->P.sq_cap))) return rc;
+            if ((rc = dalloc(h, &d_ctr, (size_t)8 * (SQ_MAXLEV + 2) * 2))) return rc;
+            if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
+            if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
+            h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        }
         if (plain && mix > 0 && pk_lds_bytes(2, nbcap) <= 40 * 1024 && h->num_envs >= 4 * mix) {
             h->mix_heavy = mix;
             h->P.cost_proxy = 1;
@@ -568,7 +586,13 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             h->D.order = h->order_buf;
         }
         if (mode == MODE_STEP) h->steps_done = true;
-        if (mode == MODE_STEP && h->maze8)
+        if (mode == MODE_STEP && h->sched_chunk > 0 && h->D.dbg == nullptr) {
+            // preemptive scheduler: one workgroup per (env, chunk) task (most leave at once: only parked envs need a second workgroup)
+            hipLaunchKernelGGL(k_sched_init, dim3(16), dim3(1024), 0, st, h->P, h->D);
+            HIPCHK(h, hipGetLastError());
+            hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        }
+        else if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (mode == MODE_STEP && h->mix_heavy > 0 && h->D.order != nullptr && h->D.dbg == nullptr) {
             const int NP = h->mix_plain;
@@ -1102,6 +1126,16 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
     BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out_host, h->D.e_cost, sizeof(unsigned) * h->num_envs, hipMemcpyDeviceToHost));
+    return BP_OK;
+}
+
+int bp_set_step_cost_hint(bp_handle *h, const uint32_t *host_costs)
+{
+    if (!h || !host_costs) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    BP_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(h->D.e_cost, host_costs, sizeof(unsigned) * h->num_envs, hipMemcpyHostToDevice));
     return BP_OK;
 }
 

@@ -32,6 +32,7 @@ struct DevParams {
     double ship_verts[BP_MAX_SHIP_VERTS][2];
     double ship_head[2], ship_tail[2];
     int obs_h, obs_w, grid_h, grid_w;
+    int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
     int cost_proxy;                            // e_cost = work proxy (same unit in every step kernel) instead of wave cycles: mixed launches
     int pack_adjacent;                         // packed kernels: wave b takes positions K*b .. K*b+K-1 of the cost order instead of the snake
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
@@ -62,6 +63,11 @@ struct DevPtrs {
     unsigned *e_cnt;         // [E][4] n_post_solve, n_contact_pts, n_first_contact, -
     unsigned *e_cost;        // [E] wave cycles (>>8) the env's last step took: dispatch-order hint only
     const int *order;        // [E] env handled by workgroup b (heaviest first), or null = identity
+    // preemptive step scheduler (k_physics_step_sched): per XCD and level (= chunks of the step already done) a queue of waiting envs
+    int *sq_items;           // [8][SQ_MAXLEV][sq_cap] env ids, -1 = not yet written
+    int *sq_ctr;             // [8][SQ_MAXLEV + 2][2]: (head, tail) per level; row SQ_MAXLEV = (finished, total) of the XCD
+    unsigned *sq_carry;      // [E][4] step-local state across chunks: yaw_violated, boundary_violated, work proxy, wave cycles >> 8
+    unsigned char *sq_moved; // [E][nbcap] shape moved in an earlier chunk of this step
     d2 *pxy;                 // [E][nbcap] position of COG
     double *ang;             // [E][nbcap]
     d2 *rot;                 // [E][nbcap] cos, sin
@@ -101,6 +107,7 @@ __device__ __forceinline__ d2 vlerp(d2 a, d2 b, double t) { return vadd(vmul(a, 
 __device__ __forceinline__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
 __device__ __forceinline__ double fclampd(double f, double lo, double hi) { return fmin(fmax(f, lo), hi); }
 
+#define SQ_MAXLEV 16
 #define BP_DBL_MIN 2.2250738585072014e-308
 #define BP_PI 3.14159265358979323846
 #define BP_INF (__builtin_inf())

@@ -206,26 +206,82 @@ __device__ __forceinline__ void store_state(const DevParams &P, const DevPtrs &D
     }
 }
 
-template <int mode, int KIND>
-__device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
+// ---- queues of the preemptive step scheduler (k_physics_step_sched below) -----------------------------------------------------------------
+// D.sq_ctr: per XCD x SQ_MAXLEV + 2 rows of two ints: rows 0 .. SQ_MAXLEV-1 = (head, tail) of the queue of envs that have completed that many
+// chunks; row SQ_MAXLEV of XCD x = (envs waiting in any of x's queues, -); XCD 0 additionally keeps the launch-wide counters in row SQ_MAXLEV + 1 =
+// (envs finished, first chunks started).  D.sq_items: [8][SQ_MAXLEV][sq_cap] env | priority class << 24, -1 = claimed but not yet written.
+__device__ __forceinline__ int sq_xcc_id()
+{
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 7u);
+}
+__device__ __forceinline__ int sq_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int *sq_row(const DevPtrs &D, const int x, const int row) { return D.sq_ctr + ((size_t)x * (SQ_MAXLEV + 2) + row) * 2; }
+__device__ __forceinline__ int *sq_finished(const DevPtrs &D) { return sq_row(D, 0, SQ_MAXLEV + 1); }
+__device__ __forceinline__ int *sq_started(const DevPtrs &D) { return sq_row(D, 0, SQ_MAXLEV + 1) + 1; }
+__device__ __forceinline__ int *sq_waiting(const DevPtrs &D, const int x) { return sq_row(D, x, SQ_MAXLEV); }
+// lane 0: take the waiting env of XCD x that has completed the fewest chunks; -1 = nothing waiting
+__device__ __forceinline__ int sq_pop(const DevParams &P, const DevPtrs &D, const int x, int &lev)
+{
+    if (sq_ld(sq_waiting(D, x)) <= 0) return -1;
+    for (int l = 0; l < P.sq_levels; l++) {
+        int *ctr = sq_row(D, x, l);
+        int h = sq_ld(ctr);
+        while (h < sq_ld(ctr + 1)) {
+            const int got = atomicCAS(ctr, h, h + 1);
+            if (got == h) {
+                const int *slot = D.sq_items + ((size_t)x * SQ_MAXLEV + l) * P.sq_cap + h;
+                int e;
+                while ((e = sq_ld(slot)) < 0) __builtin_amdgcn_s_sleep(1); // the pusher has taken the index, the id is on its way
+                atomicSub(sq_waiting(D, x), 1);
+                lev = l;
+                return e;
+            }
+            h = got;
+        }
+    }
+    return -1;
+}
+__device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, const int x, const int lev, const int item)
+{
+    const int idx = atomicAdd(sq_row(D, x, lev) + 1, 1);
+    __hip_atomic_store(D.sq_items + ((size_t)x * SQ_MAXLEV + lev) * P.sq_cap + idx, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(sq_waiting(D, x), 1);
+}
+// lane 0: is some env behind one that has completed `lev` chunks?  Envs whose first chunk has not been dispatched yet are behind everybody.
+__device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevPtrs &D, const int x, const int lev)
+{
+    bool any = sq_ld(sq_started(D)) < P.num_envs;
+    if (!any && sq_ld(sq_waiting(D, x)) > 0)
+        for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
+    return any;
+}
+// CHUNKED (k_physics_step_sched): the call resumes env `c_env`'s step after `c_lev` chunks of P.sq_chunk sub-steps and runs until the step is complete
+// (returns true) or, at a chunk boundary, an env that has completed fewer chunks is waiting in XCD c_x's queues (returns false, *c_lev_out = chunks
+// completed): an env that is behind everybody else -- a heavy one -- is never parked.  Parking goes through the same store / load as a step boundary,
+// the step-local flags through D.sq_carry.
+template <int mode, int KIND, bool CHUNKED = false>
+__device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
-                                             double *__restrict__ info, const int tmpl, const int boff = 0)
+                                             double *__restrict__ info, const int tmpl, const int boff = 0, const int c_env = 0, const int c_lev = 0,
+                                             const int c_x = 0, int *c_lev_out = nullptr)
 {
     // MODE_RESET with tmpl != 0 settles the per-trial reset templates: state slot num_envs + t holds trial t
     // MODE_STEP: workgroup b steps the env at position boff + b of the dispatch order
-    const int env = (mode == MODE_RESET) ? (tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x)
+    const int env = CHUNKED ? c_env : (mode == MODE_RESET) ? (tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x)
                                          : (D.order != nullptr ? D.order[blockIdx.x + boff] : (int)blockIdx.x + boff);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = lane_id();
 #if 1
     // heaviest-first dispatch: the first workgroups carry the envs that set the launch time -> issue priority over their SIMD mates
-    if (mode == MODE_STEP && D.order != nullptr) {
+    if (!CHUNKED && mode == MODE_STEP && D.order != nullptr) {
         if (blockIdx.x < gridDim.x / 4) __builtin_amdgcn_s_setprio(3);
         else if (blockIdx.x < gridDim.x / 2) __builtin_amdgcn_s_setprio(1);
     }
 #endif
-    if (mode == MODE_RESET && !tmpl && mask != nullptr && mask[env] == 0) return;
+    if (mode == MODE_RESET && !tmpl && mask != nullptr && mask[env] == 0) return true;
     const int nbcap = P.nbcap;
 
     // ---- carve LDS ----
@@ -327,8 +383,12 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         __syncthreads();
     } else {
         load_state_a<KIND>(P, D, E, L, A, S, env);
+        if (CHUNKED && c_lev > 0) {
+            const unsigned *cy = D.sq_carry + (size_t)env * 4;
+            S.yaw_violated = (int)(cy[0] & 1u); S.boundary_violated = (int)(cy[1] & 1u); S.costp = cy[2];
+        }
         // ship control (ship_ice_env.py:265-274): set once per env step
-        if (lane < P.nkin) { // every part of the kinematic agent carries the same velocity
+        if ((!CHUNKED || c_lev == 0) && lane < P.nkin) { // every part of the kinematic agent carries the same velocity
             const double act = actions[env] * P.max_yaw_rate;
             const d2 r = E.rot[0];
             L.sv[lane] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
@@ -340,7 +400,32 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
 
     const unsigned stamp_start = S.stamp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
-    for (int it = 0; it < nsub; it++) {
+    const int it_first = CHUNKED ? c_lev * P.sq_chunk : 0;
+    bool step_done = true;
+    int to_boundary = CHUNKED ? P.sq_chunk : 0x7FFFFFFF;   // sub-steps until the next chunk boundary
+    if (CHUNKED && c_lev == 0) { // nothing has moved in this step yet
+        unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap;
+        for (int i = lane; i < nbcap; i += 64) mvd_[i] = 0;
+    }
+#ifdef BP_PRED
+    unsigned pr_c200 = 0, pr_c100 = 0, pr_c50 = 0, pr_c10 = 0;
+#endif
+    for (int it = it_first; it < nsub; it++) {
+        if (CHUNKED) {
+            if (to_boundary == 0) { // chunk boundary: yield to an env that is further behind, otherwise carry on without a context switch
+                int yield = 0;
+                if (lane == 0) yield = sq_someone_behind(P, D, c_x, it / P.sq_chunk) ? 1 : 0;
+                if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = it / P.sq_chunk; break; }
+                to_boundary = P.sq_chunk;
+            }
+            to_boundary--;
+        }
+#ifdef BP_PRED
+        if (it == nsub - 200) pr_c200 = S.costp;
+        if (it == nsub - 100) pr_c100 = S.costp;
+        if (it == nsub - 50) pr_c50 = S.costp;
+        if (it == nsub - 10) pr_c10 = S.costp;
+#endif
         substep<KIND>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
         if (BP_UNLIKELY2(S.quiescent && D.dbg == nullptr)) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
@@ -358,6 +443,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
                 S.n_post += k * S.ship_post;
                 S.n_contact += k * S.ship_contacts;
             }
+            step_done = true;
             break;
         }
         if (BP_UNLIKELY2(D.dbg != nullptr && env == D.dbg_env)) {
@@ -371,12 +457,34 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         }
     }
 
+    if (CHUNKED && !step_done) {
+        // ---- end of a chunk: park the env exactly as at a step boundary; the step-local flags and the shapes that have moved so far go along
+        unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap;
+        for (int i = lane; i < E.nb; i += 64) if (L.mvs[i] > stamp_start) mvd_[i] = 1;
+        __syncthreads();
+        store_state(P, D, L, A, env);
+        const int err_c = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |
+                          (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
+                          (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
+        if (lane == 0) {
+            D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
+            D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
+            D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
+            unsigned *cy = D.sq_carry + (size_t)env * 4;
+            cy[0] = (unsigned)S.yaw_violated; cy[1] = (unsigned)S.boundary_violated; cy[2] = S.costp;
+            cy[3] = (c_lev == 0 ? 0u : cy[3]) + (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
+            if (err_c) atomicOr(&D.e_err[env], err_c);
+        }
+        return false;
+    }
     // ---- end of step: work / reward / termination (ship_ice_env.py:291-345) or reset snapshot ----
     double work = 0.0;
     if (mode == MODE_STEP) {
         for (int base = 0; base < E.nb; base += 64) {
             const int i = base + lane;
-            const bool mvd = (i < E.nb) && (L.mvs[i] > stamp_start) && (kind_ctype(E.kind[i]) == 2); // floes / boxes only
+            // shapes that did not move contribute exactly +0, so the test only saves work; across chunks the flag comes from D.sq_moved
+            const bool mvd = (i < E.nb) && ((L.mvs[i] > stamp_start) || (CHUNKED && c_lev > 0 && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
+                             (kind_ctype(E.kind[i]) == 2); // floes / boxes only
             double contrib = 0.0;
             if (mvd) {
                 const int n = E.nv[i];
@@ -405,6 +513,14 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
     __syncthreads();
 
     store_state(P, D, L, A, env);
+#ifdef BP_PRED
+    if (D.prof != nullptr && lane == 0 && mode == MODE_STEP) { // candidate predictors of the next step's cost (tools/cost_predictability.py)
+        unsigned long long *o = D.prof + (size_t)env * 24;
+        o[0] = S.costp; o[1] = S.costp - pr_c200; o[2] = S.costp - pr_c100; o[3] = S.costp - pr_c50; o[4] = S.costp - pr_c10;
+        o[5] = (unsigned long long)S.nmv; o[6] = (unsigned long long)__popcll(S.prev_amask); o[7] = (unsigned long long)S.nslots;
+        o[8] = __builtin_amdgcn_s_memtime() - t_begin;
+    }
+#endif
 #ifdef BP_PROF
     if (D.prof != nullptr && lane == 0) {
         S.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
@@ -418,7 +534,8 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
         const d2 sp = E.pxy[0];
         const double sa = E.ang[0];
         D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
-        if (mode == MODE_STEP) D.e_cost[env] = P.cost_proxy ? S.costp : (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
+        if (mode == MODE_STEP) D.e_cost[env] = P.cost_proxy ? S.costp : (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) +
+                                                                    ((CHUNKED && c_lev > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
         D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
         D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
         if (err_any) atomicOr(&D.e_err[env], err_any);
@@ -507,6 +624,7 @@ __device__ __forceinline__ void physics_body(const DevParams &P, const DevPtrs &
             }
         }
     }
+    return true;
 }
 
 // env.step(): 400 sub-steps + work / reward / termination
@@ -532,6 +650,64 @@ __global__ __launch_bounds__(64) void k_physics_step_solo(const DevParams P, con
 {
     asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
     physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
+}
+// ---- preemptive step scheduler ------------------------------------------------------------------------------------------------------
+// A launch ends with its last env, and which envs will be heavy in a step is only half predictable from the previous one: with the static
+// heaviest-first order an env that turns out heavy after starting in the second round of the 2 048 wave slots sets the launch time (measured:
+// 22.9 ms, 19.2 ms when the order is that of the step's own costs, tools/oracle_order.py).  Here a step is cut into chunks of P.sq_chunk sub-steps;
+// at a chunk boundary a wave parks its env if another one is further behind, and a new workgroup takes the waiting env that has completed the
+// fewest chunks: every env advances at about the same sub-step pace, a heavy env is always the one furthest behind -- it is never parked and keeps
+// its slot from the first sub-step to the last -- and nothing needs to be predicted.  A parked env goes through the same store / load as at a step
+// boundary, so the results are those of k_physics_step bit for bit.  Queues are per XCD (an env's arrays stay in one L2) and per level.
+__global__ void k_sched_init(const DevParams P, const DevPtrs D)
+{
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
+    for (int i = tid; i < 8 * SQ_MAXLEV * P.sq_cap; i += nthr) D.sq_items[i] = -1;
+    for (int i = tid; i < 8 * (SQ_MAXLEV + 2) * 2; i += nthr) D.sq_ctr[i] = 0;
+}
+// One workgroup per (env, chunk) task: the hardware dispatcher is the persistent loop, and the step code is compiled as in k_physics_step.
+// The first num_envs workgroups start the envs in the heaviest-first order without touching a queue (first chunks come before everything else under
+// the least-advanced-first rule anyway, and workgroups are dispatched in index order); every later workgroup takes the least-advanced waiting env of
+// its XCD, waits if there is none yet, helps another XCD after a few empty polls, and leaves without work only when every env has finished (most of
+// the grid does: only parked envs need a second workgroup).  An env's home XCD is the one its first chunk ran on.
+__global__ __launch_bounds__(64) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                           double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    const int lane = lane_id();
+    const int home = sq_xcc_id();
+    int item = -1, lev = 0, x = home;
+    if ((int)blockIdx.x < P.num_envs) {
+        const int pos = (int)blockIdx.x;
+        // issue-priority class of the env for the whole step: the heaviest quarter of the predicted order 3, the next quarter 1
+        const int cls = (pos < P.num_envs / 4) ? 3 : (pos < P.num_envs / 2) ? 1 : 0;
+        item = (D.order != nullptr ? D.order[pos] : pos) | (cls << 24);
+        if (lane == 0) atomicAdd(sq_started(D), 1);
+    } else {
+        if (lane == 0) {
+            for (int idle = 0;; idle++) {
+                item = sq_pop(P, D, home, lev);
+                if (item < 0 && (idle & 3) == 3)
+                    for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev); if (item >= 0) x = y; }
+                if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs) break;
+                for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
+        if (item < 0) return;
+    }
+    const int env = item & 0xFFFFFF;
+    if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
+    else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
+    int lev_out = lev + 1;
+    const bool done = physics_body<MODE_STEP, 0, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+        if (done) atomicAdd(sq_finished(D), 1);
+        else sq_push(P, D, x, lev_out, item);
+    }
 }
 // a few tens of microseconds of nothing: lets the solo kernel's workgroups land on empty SIMDs before the packed grid floods the chip
 __global__ void k_delay(const unsigned ticks_100mhz)

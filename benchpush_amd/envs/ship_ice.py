@@ -226,6 +226,12 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_get_step_cycles(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_step_cycles")
         return out.astype(np.uint64) << 8
 
+    def set_cost_hint(self, costs):
+        """Dispatch-order hint for the next step (uint32 per env, larger = earlier); by default the previous step's wave cycles."""
+        c = np.ascontiguousarray(costs, dtype=np.uint32)
+        assert c.shape == (self.num_envs,)
+        _lib.check(self.L, self.h, self.L.bp_set_step_cost_hint(self.h, c.ctypes.data_as(C.c_void_p)), "bp_set_step_cost_hint")
+
     def enable_timing(self, on=True):
         self.L.bp_enable_timing(self.h, int(on))
 

@@ -209,6 +209,8 @@ int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32
 int bp_enable_timing(bp_handle *h, int32_t on);
 /* shader cycles >> 8 each env's wavefront spent in the last bp_step (the dispatch-order hint): host uint32 [E] (synchronises) */
 int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
+/* overrides that hint for the next bp_step: host uint32 [E], larger = dispatched earlier (results never depend on the order; synchronises) */
+int bp_set_step_cost_hint(bp_handle *h, const uint32_t *host_costs);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * box-delivery-v0 (benchpush/environments/box_delivery/box_delivery_env.py, config.yaml).  A handle made by bp_bd_create is

@@ -91,6 +91,18 @@ def test_parity_three_way_launch(monkeypatch):
     assert _run_parity(E=12, conc=0.3, T=3, steps=30, seed=6) > 500
 
 
+def test_parity_preemptive_scheduler(monkeypatch):
+    """k_physics_step_sched (the default step kernel: chunks of 40 sub-steps, envs parked at a chunk boundary when another one is further behind and
+    resumed by another workgroup) with other chunk sizes -- one that divides the 400 sub-steps, one that leaves a ragged last chunk -- and the
+    one-wave-per-env kernel it replaces (BP_SCHED=0): all bit-identical to the oracle."""
+    monkeypatch.setenv("BP_SCHED", "50")
+    assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
+    monkeypatch.setenv("BP_SCHED", "37")
+    assert _run_parity(E=7, conc=0.5, T=2, steps=12, seed=21) > 100
+    monkeypatch.setenv("BP_SCHED", "0")
+    assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
+
+
 def test_parity_50pct_dense_field():
     assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
 
@@ -262,8 +274,8 @@ def test_full_size_properties_4096_envs():
 
 def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     """4096 envs x 40 steps with auto-reset (deep enough for the cost-sorted dispatch order, the snake seating of the packed waves and
-    the heavy / light split of the mixed launch to matter): the packed kernels (BP_PACK=4, 2) and the mixed launch (BP_MIX) leave every
-    env in exactly the state of the one-env-per-wavefront kernel -- body state, rewards, termination, observations, episode metrics."""
+    the heavy / light split of the mixed launch to matter): the preemptive scheduler (the default), the packed kernels (BP_PACK=4, 2) and the
+    mixed launch (BP_MIX) leave every env in exactly the state of the one-env-per-wavefront kernel -- body state, rewards, termination, observations, episode metrics."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
     trials = default_trials(0.3, 24, base_seed=3)
     E, steps = 4096, 40
@@ -272,7 +284,7 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
 
     def run(env_vars):
-        for k in ("BP_PACK", "BP_MIX", "BP_MIX_LIGHT"):
+        for k in ("BP_PACK", "BP_MIX", "BP_MIX_LIGHT", "BP_SCHED"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env_vars.items():
             monkeypatch.setenv(k, v)
@@ -290,9 +302,10 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
         env.close()
         return out
 
-    ref = run({})
+    ref = run({"BP_SCHED": "0"})                               # one env per wavefront for the whole step
     assert ref[5] > 1000                                       # episodes did end and restart inside the window
-    for variant in ({"BP_PACK": "4"}, {"BP_PACK": "2"}, {"BP_MIX": "512"}):
+    # {} = the default: the preemptive scheduler (k_physics_step_sched), here with thousands of envs parked and resumed on other CUs / XCDs
+    for variant in ({}, {"BP_SCHED": "25"}, {"BP_PACK": "4"}, {"BP_PACK": "2"}, {"BP_MIX": "512"}):
         got = run(variant)
         for a, b in zip(ref[:5], got[:5]):
             assert torch.equal(a, b), variant

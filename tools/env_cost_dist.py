@@ -5,8 +5,9 @@ import numpy as np, torch
 from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-trials = default_trials(0.3, 100, base_seed=0)
-env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
+CONC = float(sys.argv[3]) if len(sys.argv) > 3 else 0.3
+trials = default_trials(CONC, 100, base_seed=0)
+env = BatchedShipIceEnv(E, cfg={"concentration": CONC}, trials=trials)
 env.reset()
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 for t in range(STEPS):
