@@ -357,6 +357,19 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     h->maze8 = (h->P.env_kind == BP_ENV_MAZE);
     for (int v : h_nv) if (v > 8) h->maze8 = false;
     if (h->maze8) {
+        int ch = (h->num_envs <= 8192) ? 40 : 0;
+        if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
+        if (ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) { // preemptive scheduler, as for ship-ice
+            h->sched_chunk = ch;
+            h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch; h->P.sq_cap = h->num_envs;
+            int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
+            if ((rc = dalloc(h, &d_items, (size_t)8 * SQ_MAXLEV * h->P.sq_cap))) return rc;
+            if ((rc = dalloc(h, &d_ctr, (size_t)8 * (SQ_MAXLEV + 2) * 2))) return rc;
+            if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
+            if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
+            h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        }
         HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         hipLaunchKernelGGL(k_physics_reset_maze, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
@@ -590,7 +603,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             // preemptive scheduler: one workgroup per (env, chunk) task (most leave at once: only parked envs need a second workgroup)
             hipLaunchKernelGGL(k_sched_init, dim3(16), dim3(1024), 0, st, h->P, h->D);
             HIPCHK(h, hipGetLastError());
-            hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+            if (h->maze8)
+                hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+            else
+                hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         }
         else if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);

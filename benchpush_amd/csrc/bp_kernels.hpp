@@ -386,6 +386,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (CHUNKED && c_lev > 0) {
             const unsigned *cy = D.sq_carry + (size_t)env * 4;
             S.yaw_violated = (int)(cy[0] & 1u); S.boundary_violated = (int)(cy[1] & 1u); S.costp = cy[2];
+            S.wall_flag = (int)((cy[0] >> 1) & 1u);
         }
         // ship control (ship_ice_env.py:265-274): set once per env step
         if ((!CHUNKED || c_lev == 0) && lane < P.nkin) { // every part of the kinematic agent carries the same velocity
@@ -471,7 +472,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
             D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
             unsigned *cy = D.sq_carry + (size_t)env * 4;
-            cy[0] = (unsigned)S.yaw_violated; cy[1] = (unsigned)S.boundary_violated; cy[2] = S.costp;
+            cy[0] = (unsigned)S.yaw_violated | ((unsigned)S.wall_flag << 1); cy[1] = (unsigned)S.boundary_violated; cy[2] = S.costp;
             cy[3] = (c_lev == 0 ? 0u : cy[3]) + (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
             if (err_c) atomicOr(&D.e_err[env], err_c);
         }
@@ -670,9 +671,10 @@ __global__ void k_sched_init(const DevParams P, const DevPtrs D)
 // the least-advanced-first rule anyway, and workgroups are dispatched in index order); every later workgroup takes the least-advanced waiting env of
 // its XCD, waits if there is none yet, helps another XCD after a few empty polls, and leaves without work only when every env has finished (most of
 // the grid does: only parked envs need a second workgroup).  An env's home XCD is the one its first chunk ran on.
-__global__ __launch_bounds__(64) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
-                                                           double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
+template <int KIND>
+__device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
+                                           double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     const int lane = lane_id();
     const int home = sq_xcc_id();
@@ -701,13 +703,25 @@ __global__ __launch_bounds__(64) void k_physics_step_sched(const DevParams P, co
     else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
     int lev_out = lev + 1;
-    const bool done = physics_body<MODE_STEP, 0, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out);
+    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
         if (done) atomicAdd(sq_finished(D), 1);
         else sq_push(P, D, x, lev_out, item);
     }
+}
+__global__ __launch_bounds__(64) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                           double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_body<0>(P, D, actions, reward, terminated, truncated, info);
+}
+__global__ __launch_bounds__(64) void k_physics_step_sched_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                                double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                                unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_body<BP_ENV_MAZE>(P, D, actions, reward, terminated, truncated, info);
 }
 // a few tens of microseconds of nothing: lets the solo kernel's workgroups land on empty SIMDs before the packed grid floods the chip
 __global__ void k_delay(const unsigned ticks_100mhz)
