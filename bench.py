@@ -300,6 +300,7 @@ def main():
                          "then %d timed steps with auto-reset" % (PH, PH, KS)}
 
     if rank == 0:
+        sched_chunk = int(env.L.bp_sched_chunk(env.h)) if hasattr(env, "L") and hasattr(env.L, "bp_sched_chunk") else 0
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
@@ -308,11 +309,15 @@ def main():
         clock_hz = 2.4e9
         roof = {
             "bound": "hbm",
-            "kernel": "k_physics_step",
+            "kernel": ("k_physics_step_sched" if sched_chunk > 0 else "k_physics_step"),
+            "scheduler": ({"chunk_substeps": sched_chunk, "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
+                           "least-advanced waiting env first (DESIGN.md 4a); BP_SCHED=0 selects one wavefront per env for the whole step"}
+                          if sched_chunk > 0 else None),
             "achieved": a_phys * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "binds": "wave issue slots and dependent-instruction latency of one wavefront per env, not HBM and not MFMA: the state stays "
-                     "on-chip for the 400 sub-steps (DESIGN.md section 4)",
+                     "on-chip for the 400 sub-steps; with the preemptive scheduler the launch is within a few per cent of BOTH the chain of its "
+                     "heaviest env and the sum of all chains / 2048 wave slots (DESIGN.md section 4a)",
             "raster_kernel": {"kernel": "k_observe", "achieved": 4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 if rast_ms > 0 else None,
                               "ms": rast_ms, "frac": (4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rast_ms > 0 else None},
             "physics_ms": phys_ms, "launches": nlaunch,

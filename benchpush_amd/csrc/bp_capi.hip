@@ -1145,6 +1145,8 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
     return BP_OK;
 }
 
+int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
+
 int bp_set_step_cost_hint(bp_handle *h, const uint32_t *host_costs)
 {
     if (!h || !host_costs) return BP_EINVAL;

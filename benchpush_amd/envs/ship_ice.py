@@ -226,6 +226,10 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_get_step_cycles(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_step_cycles")
         return out.astype(np.uint64) << 8
 
+    def sched_chunk(self):
+        """Sub-steps per chunk of the preemptive step scheduler, 0 = one wavefront per env for the whole step."""
+        return int(self.L.bp_sched_chunk(self.h))
+
     def set_cost_hint(self, costs):
         """Dispatch-order hint for the next step (uint32 per env, larger = earlier); by default the previous step's wave cycles."""
         c = np.ascontiguousarray(costs, dtype=np.uint32)

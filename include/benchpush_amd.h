@@ -209,6 +209,10 @@ int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32
 int bp_enable_timing(bp_handle *h, int32_t on);
 /* shader cycles >> 8 each env's wavefront spent in the last bp_step (the dispatch-order hint): host uint32 [E] (synchronises) */
 int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
+/* sub-steps per chunk of the preemptive step scheduler (k_physics_step_sched: envs are parked at chunk boundaries while another one is further
+ * behind, and resumed by another workgroup; results are identical), 0 = one wavefront per env for the whole step.  Default 40 for ship-ice and
+ * maze handles of up to 8192 envs; environment variable BP_SCHED=<chunk> (0 = off) overrides it at load time. */
+int32_t bp_sched_chunk(bp_handle *h);
 /* overrides that hint for the next bp_step: host uint32 [E], larger = dispatched earlier (results never depend on the order; synchronises) */
 int bp_set_step_cost_hint(bp_handle *h, const uint32_t *host_costs);
 
