@@ -82,6 +82,7 @@ for k, d in sq.items():
     if k.startswith("k_physics_step"):
         per = {c: sum(v[-6:]) / len(v[-6:]) for c, v in d.items()}
         pmc["per_launch"] = per
+        pmc["kernel"] = k
         if per.get("SQ_ACTIVE_INST_VALU") and per.get("SQ_THREAD_CYCLES_VALU"):
             pmc["lanes_active"] = per["SQ_THREAD_CYCLES_VALU"] / (64.0 * per["SQ_ACTIVE_INST_VALU"])
         if per.get("SQ_WAVE_CYCLES"):
