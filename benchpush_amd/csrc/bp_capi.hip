@@ -296,7 +296,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     // packed step kernel (bp_physics_pack.hpp, K envs per wavefront): ship-ice only, opt-in with BP_PACK=2|4 -- bit-identical
-    // to k_physics_step but slower at 4096 envs (profiles/r02_pack/README.md), so one env per wavefront stays the default
+    // to k_physics_step but slower at 4096 envs (profiles/r02_pack/README.md), so one env per wavefront (under the preemptive scheduler, below) stays the default
     h->pack = 0;
     if (h->P.env_kind == BP_ENV_SHIP_ICE && h->P.nkin == 1 && nbcap < 16384) {
         bool plain = true; // one kinematic shape (index 0), dynamic shapes without groups otherwise
