@@ -103,6 +103,41 @@ def test_parity_preemptive_scheduler(monkeypatch):
     assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
 
 
+def test_dispatch_order_hint_never_changes_results():
+    """bp_set_step_cost_hint (the dispatch order of the step kernel) with random and with reversed hints: same states, rewards and observations."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    trials = default_trials(0.3, 6, base_seed=11)
+    E, steps = 96, 25
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(3)
+    acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
+
+    def run(mode):
+        env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+        assert env.sched_chunk() == 40                      # the preemptive scheduler is the default step kernel
+        env.reset()
+        rng = np.random.default_rng(5)
+        rsum = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+        for t in range(steps):
+            if mode == "random":
+                env.set_cost_hint(rng.integers(0, 1 << 20, E))
+            elif mode == "reversed":
+                env.set_cost_hint((1 << 30) - env.step_cycles().astype(np.int64) // 256)
+            _, rew, term, _, _ = env.step(acts[t])
+            rsum += rew
+            env.reset(term)
+        env.check_errors()
+        out = (env.body_state().clone(), rsum, env.obs.clone(), env.info.clone())
+        env.close()
+        return out
+
+    ref = run(None)
+    for mode in ("random", "reversed"):
+        got = run(mode)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), mode
+
+
 def test_parity_50pct_dense_field():
     assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
 
