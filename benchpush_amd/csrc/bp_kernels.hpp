@@ -692,6 +692,8 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
                 if (item < 0 && (idle & 3) == 3)
                     for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev); if (item >= 0) x = y; }
                 if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs) break;
+                // watchdog: ~20 s of empty polls can only mean a scheduler fault -- flag it and leave rather than hold the GPU
+                if (idle > (1 << 20)) { atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT); break; }
                 for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
             }
         }

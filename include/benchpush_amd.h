@@ -42,7 +42,8 @@ enum { BP_ENV_SHIP_ICE = 0, BP_ENV_MAZE = 1, BP_ENV_BOX = 2 };
 #define BP_MAX_WHEELS 4
 
 /* per-env error bits reported by bp_check_errors */
-enum { BP_ERR_ADJ_OVERFLOW = 1, BP_ERR_ARB_OVERFLOW = 2, BP_ERR_LEVEL_OVERFLOW = 4 };
+enum { BP_ERR_ADJ_OVERFLOW = 1, BP_ERR_ARB_OVERFLOW = 2, BP_ERR_LEVEL_OVERFLOW = 4,
+       BP_ERR_SCHED_TIMEOUT = 8 /* a workgroup of the step scheduler gave up waiting for a parked env (env 0 carries the flag): the step is incomplete */ };
 
 /* info[e][k] columns written by bp_step / bp_reset (ship_ice_env.py:337-345 plus the callback
  * bookkeeping of :150-180); state is raw (the host adapter applies round(.,2)). */
