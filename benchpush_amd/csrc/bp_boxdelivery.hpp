@@ -860,26 +860,7 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
         nalive -= __popcll(remove_mask);
         __syncthreads();
     }
-    // robot spfa map for observation channel 2 (create_global_shortest_path_map, box_delivery_env.py:1131-1138), pre-scaled
-    {
-        const d2 rpos = E.pxy[0];
-        int wi, wj;
-        bd_pos_to_win(B, rpos.x, rpos.y, wi, wj);
-        const unsigned short *edt = Q.edt + ((size_t)map * B.SH * B.SW + (size_t)wi * B.SW + wj) * 2;
-        const int src = (int)edt[0] * B.SW + (int)edt[1];
-        bd_spfa(B, L, dist, src, -1, err);
-        float *rmap = Q.rmap + (size_t)env * B.SH * B.SW;
-        const float ppm32 = (float)B.ppm, scale32 = (float)B.sp_channel_scale;
-        const double div2 = (__builtin_sqrt(2.0) * (double)B.local_px) / B.ppm;
-        for (int i = lane; i < B.SH * B.SW; i += 64) {
-            const float d = bd_ld(dist + i);
-            float v = (__float_as_uint(d) == BD_INF_BITS) ? 0.0f : d;
-            v = v / ppm32;
-            v = (float)((double)v / div2);
-            v = v * scale32;
-            rmap[i] = v;
-        }
-    }
+    // the robot's spfa map (observation channel 2) is k_bd_robot_map's, launched after this kernel
     const unsigned long long em = ballot(err != 0);
     if (init) {
         for (int q = lane; q < B.nbox * 4; q += 64) prev[q] = bd_local_to_world(E, B.first_box + q / 4, q & 3);
@@ -1050,25 +1031,7 @@ __global__ __launch_bounds__(64) void k_ac_finish(const DevParams P, const DevPt
         Q.order[(size_t)env * BD_MAXBOX + lane] = (unsigned char)lane;
     }
     if (act) for (int i = 0; i < 4; i++) prev[lane * 4 + i] = mk2(nowv[i][0], nowv[i][1]);
-    // robot spfa map for channel 2 (create_global_shortest_path_map, area_clearing.py:1046-1053: no channel scale)
-    {
-        const d2 rpos = E.pxy[0];
-        int wi, wj;
-        bd_pos_to_win(B, rpos.x, rpos.y, wi, wj);
-        const unsigned short *edt = Q.edt + ((size_t)map * B.SH * B.SW + (size_t)wi * B.SW + wj) * 2;
-        const int src = (int)edt[0] * B.SW + (int)edt[1];
-        bd_spfa(B, L, dist, src, -1, err);
-        float *rmap = Q.rmap + (size_t)env * B.SH * B.SW;
-        const float ppm32 = (float)B.ppm;
-        const double div2 = (__builtin_sqrt(2.0) * (double)B.local_px) / B.ppm;
-        for (int i = lane; i < B.SH * B.SW; i += 64) {
-            const float d = bd_ld(dist + i);
-            float v = (__float_as_uint(d) == BD_INF_BITS) ? 0.0f : d;
-            v = v / ppm32;
-            v = (float)((double)v / div2);
-            rmap[i] = v;
-        }
-    }
+    // the robot's spfa map (channel 2) is k_bd_robot_map's, launched after this kernel
     const unsigned long long em = ballot(err != 0);
     if (lane == 0) {
         if (em) atomicOr(&D.e_err[env], BP_ERR_ARB_OVERFLOW);
@@ -1097,6 +1060,101 @@ __global__ __launch_bounds__(64) void k_ac_finish(const DevParams P, const DevPt
 }
 
 // reset(): box-delivery extras of the settled template -> env (k_reset_copy moves the physics state)
+// ---------------------------------------------------------------------------------------------------------------------
+// k_bd_robot_map: the spfa map from the robot for observation channel 2 (create_global_shortest_path_map, box_delivery_env.py:1131-1138 with the channel
+// scale, area_clearing.py:1046-1053 without), BDR_THREADS threads per env.  The same bucketed Dijkstra as bd_spfa -- the labels are the least fixed point of
+// the float32 relaxations, so the order in which a bucket's cells are relaxed does not matter -- with the cells of a bucket spread over four wavefronts;
+// the tentative distances live in the output array itself (Q.rmap) and are scaled in place afterwards.  Only the free-cell raster and the queues need LDS
+// (26 KB), so six workgroups = 24 wavefronts share a CU, against four single-wave workgroups when this ran at the end of k_bd_finish / k_ac_finish.
+// ---------------------------------------------------------------------------------------------------------------------
+#define BDR_THREADS 256
+__global__ __launch_bounds__(BDR_THREADS) void k_bd_robot_map(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q, const int tmpl)
+{
+    const int env = tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    const int NW = B.SH * B.SW, words = (NW + 31) / 32;
+    unsigned *freeb = (unsigned *)bp_smem;                               // [words]
+    unsigned short *q = (unsigned short *)(freeb + ((words + 3) & ~3));  // [3][BD_QCAP]
+    __shared__ int qn[4];
+    __shared__ int s_err;
+    const int map = Q.map_of_trial[D.e_trial[env]];
+    const unsigned *f = Q.free_bits + (size_t)map * words;
+    for (int i = tid; i < words; i += BDR_THREADS) freeb[i] = f[i];
+    float *dist = Q.rmap + (size_t)env * NW;
+    unsigned *du = (unsigned *)dist;
+    for (int i = tid; i < NW; i += BDR_THREADS) du[i] = BD_INF_BITS;
+    if (tid < 3) qn[tid] = 0;
+    if (tid == 0) s_err = 0;
+    const d2 rpos = D.pxy[(size_t)env * P.nbcap];
+    int wi, wj;
+    bd_pos_to_win(B, rpos.x, rpos.y, wi, wj);
+    const unsigned short *edt = Q.edt + ((size_t)map * NW + (size_t)wi * B.SW + wj) * 2;
+    const int src = (int)edt[0] * B.SW + (int)edt[1];
+    __syncthreads();
+    if (tid == 0) { du[src] = 0u; q[0] = (unsigned short)src; qn[0] = 1; }
+    __syncthreads();
+    const float SQ2 = __builtin_sqrtf(2.0f);
+    int empty_run = 0;
+    for (int b = 0; b < 8192; b++) {
+        const int qi = b % 3;
+        const int n = min(qn[qi], BD_QCAP);
+        if (n == 0) { if (++empty_run >= 3) break; continue; }   // uniform: qn is only written between the barriers below
+        empty_run = 0;
+        const unsigned short *qq = q + qi * BD_QCAP;
+        for (int base = 0; base < n; base += BDR_THREADS) {
+            const int idx = base + tid;
+            bool act = idx < n;
+            const int v = act ? (int)qq[idx] : 0;
+            const float d = bd_ld(dist + v);
+            act = act && ((int)d == b);
+            const int vi = v / B.SW, vj = v - vi * B.SW;
+            float old[8]; int nidx[8]; bool ok[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int ni = vi + BD_DI[k], nj = vj + BD_DJ[k];
+                const bool inb = ni >= 0 && nj >= 0 && ni < B.SH && nj < B.SW;
+                nidx[k] = inb ? ni * B.SW + nj : 0;
+                ok[k] = act && inb && bd_bit(freeb, nidx[k]);
+                old[k] = bd_ld(dist + nidx[k]);
+            }
+            unsigned prevb[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float nd = d + ((k & 1) ? 1.0f : SQ2);
+                ok[k] = ok[k] && nd < old[k];
+                prevb[k] = 0u;
+                if (ok[k]) prevb[k] = atomicMin(du + nidx[k], __float_as_uint(nd));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float nd = d + ((k & 1) ? 1.0f : SQ2);
+                if (ok[k] && __float_as_uint(nd) < prevb[k]) {
+                    const int tq = ((int)nd) % 3;
+                    const int pos = atomicAdd(&qn[tq], 1);
+                    if (pos < BD_QCAP) q[tq * BD_QCAP + pos] = (unsigned short)nidx[k];
+                    else s_err = 1;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid == 0) qn[qi] = 0;
+        __syncthreads();
+    }
+    __syncthreads();
+    // distances -> channel values, in place (float32 arithmetic of the reference; unreached cells 0)
+    const float ppm32 = (float)B.ppm, scale32 = (float)B.sp_channel_scale;
+    const double div2 = (__builtin_sqrt(2.0) * (double)B.local_px) / B.ppm;
+    for (int i = tid; i < NW; i += BDR_THREADS) {
+        const float d = bd_ld(dist + i);
+        float v = (__float_as_uint(d) == BD_INF_BITS) ? 0.0f : d;
+        v = v / ppm32;
+        v = (float)((double)v / div2);
+        if (B.task == 0) v = v * scale32;
+        dist[i] = v;
+    }
+    if (tid == 0 && s_err) atomicOr(&D.e_err[env], BP_ERR_ARB_OVERFLOW);
+}
+
 __global__ __launch_bounds__(256) void k_bd_reset_copy(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q,
                                                        const unsigned char *__restrict__ mask, double *__restrict__ info)
 {

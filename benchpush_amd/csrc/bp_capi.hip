@@ -44,6 +44,7 @@ struct bp_handle {
     bp_bd_config bdcfg;
     BdParams B;
     BdPtrs Q;
+    size_t bd_rmap_lds = 0;
     size_t bd_lds = 0, bd_obs_lds = 0;
     std::vector<bpgeom::BdMaps> bd_maps;
     std::vector<int> bd_map_of_trial;
@@ -577,6 +578,8 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 else
                     hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
                 HIPCHK(h, hipGetLastError());
+                hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, st, h->P, h->D, h->B, h->Q, 0);
+                HIPCHK(h, hipGetLastError());
             } else {
                 hipLaunchKernelGGL(k_reset_copy, dim3(E), dim3(256), 0, st, h->P, h->D, mask, (double *)nullptr);
                 HIPCHK(h, hipGetLastError());
@@ -1064,6 +1067,11 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_ac_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_observe, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_obs_lds));
+    {
+        const size_t words = (size_t)((h->B.SH * h->B.SW + 31) / 32);
+        h->bd_rmap_lds = ((words + 3) & ~(size_t)3) * 4 + (size_t)3 * BD_QCAP * 2 + 16;
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_robot_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_rmap_lds));
+    }
     // settle every trial once into its template slot, then the episode-start bookkeeping (box distances, robot map)
     hipLaunchKernelGGL(k_bd_settle, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
     HIPCHK(h, hipGetLastError());
@@ -1073,6 +1081,8 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     else
         hipLaunchKernelGGL(k_bd_finish, dim3(T), dim3(64), h->bd_lds, 0, h->P, h->D, h->B, h->Q, 1, 1, (double *)nullptr, (unsigned char *)nullptr,
                            (unsigned char *)nullptr, (double *)nullptr);
+    HIPCHK(h, hipGetLastError());
+    hipLaunchKernelGGL(k_bd_robot_map, dim3(T), dim3(BDR_THREADS), h->bd_rmap_lds, 0, h->P, h->D, h->B, h->Q, 1);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipDeviceSynchronize());
     h->loaded = true;
