@@ -573,13 +573,23 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 HIPCHK(h, hipGetLastError());
                 hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
                 HIPCHK(h, hipGetLastError());
+                // the robot's spfa map needs only the robot pose: it runs beside the finish kernel on a second stream
+                if (!h->st_solo) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_solo, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+                }
+                HIPCHK(h, hipEventRecord(h->ev_fork, st));
+                HIPCHK(h, hipStreamWaitEvent(h->st_solo, h->ev_fork, 0));
+                hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_solo, h->P, h->D, h->B, h->Q, 0);
+                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipEventRecord(h->ev_join, h->st_solo));
                 if (h->B.task == 1)
                     hipLaunchKernelGGL(k_ac_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
                 else
                     hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
                 HIPCHK(h, hipGetLastError());
-                hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, st, h->P, h->D, h->B, h->Q, 0);
-                HIPCHK(h, hipGetLastError());
+                HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
             } else {
                 hipLaunchKernelGGL(k_reset_copy, dim3(E), dim3(256), 0, st, h->P, h->D, mask, (double *)nullptr);
                 HIPCHK(h, hipGetLastError());
