@@ -24,16 +24,9 @@ struct bp_handle {
     bool steps_done = false;
     bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
-    int pack = 0;          // ship-ice step kernel: K envs per wavefront (4 / 2), 0 = one env per wavefront (k_physics_step)
-    size_t pack_lds = 0;
-    // mixed launch (BP_MIX=<heavy envs>): the heaviest envs one per SIMD (k_physics_step_solo, high-priority stream), the rest two to a
-    // wavefront (k_physics_step_pack2) on the caller's stream
-    int mix_heavy = 0;
-    bool mix_light_packed = true;   // BP_MIX_LIGHT=old: the light envs on one env per wave (k_physics_step_from) instead of the packed kernel
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
-    int mix_plain = 0;              // BP_MIX_PLAIN=<n>: the next n envs of the cost order on one env per wave beside the solo and the packed kernel
-    hipStream_t st_solo = nullptr, st_mid = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -173,9 +166,7 @@ int bp_destroy(bp_handle *h)
 {
     if (!h) return BP_EINVAL;
     DevGuard _dg(h->device);
-    if (h->st_solo) { hipStreamSynchronize(h->st_solo); hipStreamDestroy(h->st_solo); }
-    if (h->st_mid) { hipStreamSynchronize(h->st_mid); hipStreamDestroy(h->st_mid); }
-    if (h->ev_join2) hipEventDestroy(h->ev_join2);
+    if (h->st_aux) { hipStreamSynchronize(h->st_aux); hipStreamDestroy(h->st_aux); }
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (void *p : h->allocs) hipFree(p);
@@ -296,9 +287,6 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-    // packed step kernel (bp_physics_pack.hpp, K envs per wavefront): ship-ice only, opt-in with BP_PACK=2|4 -- bit-identical
-    // to k_physics_step but slower at 4096 envs (profiles/r02_pack/README.md), so one env per wavefront (under the preemptive scheduler, below) stays the default
-    h->pack = 0;
     if (h->P.env_kind == BP_ENV_SHIP_ICE && h->P.nkin == 1 && nbcap < 16384) {
         bool plain = true; // one kinematic shape (index 0), dynamic shapes without groups otherwise
         for (int t = 0; t < T && plain; t++)
@@ -307,16 +295,12 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 const int bt = (kd >> 16) & 3, grp = (kd >> 8) & 0xFF;
                 if (grp != 0 || bt != (b == 0 ? 1 : 0)) { plain = false; break; }
             }
-        int want = 0;
-        if (const char *ev = getenv("BP_PACK")) want = atoi(ev);
-        int mix = 0;
-        if (const char *ev = getenv("BP_MIX")) mix = atoi(ev);
         // Preemptive scheduler (k_physics_step_sched), the default step kernel of a ship-ice handle: chunks of 40 sub-steps.  It pays while the launch
         // is a few rounds of the wave slots (+14 % at 4096 envs; -1 % at 16 384, where the tail is amortised): BP_SCHED=<chunk> forces it, BP_SCHED=0
         // selects the one-wave-per-env kernel.
         int ch = (h->num_envs <= 8192) ? 40 : 0;
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
-        if (plain && ch > 0 && mix <= 0 && want == 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
+        if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch;
             h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
@@ -327,31 +311,6 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-        }
-        if (plain && mix > 0 && pk_lds_bytes(2, nbcap) <= 40 * 1024 && h->num_envs >= 4 * mix) {
-            h->mix_heavy = mix;
-            h->P.cost_proxy = 1;
-            if (const char *ev2 = getenv("BP_MIX_LIGHT")) h->mix_light_packed = std::string(ev2) != "old";
-            if (const char *ev2 = getenv("BP_MIX_PLAIN")) h->mix_plain = std::max(0, std::min(atoi(ev2), h->num_envs - mix - 2));
-            if (const char *ev2 = getenv("BP_MIX_PAIR")) h->P.pack_adjacent = std::string(ev2) == "adjacent";
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_from, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-            h->pack_lds = pk_lds_bytes(2, nbcap);
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(2, nbcap)));
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_solo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-            if (!h->st_solo) {
-                int lo = 0, hi = 0;
-                HIPCHK(h, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(h, hipStreamCreateWithPriority(&h->st_solo, hipStreamNonBlocking, hi));
-                HIPCHK(h, hipStreamCreateWithPriority(&h->st_mid, hipStreamNonBlocking, hi));
-                HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
-                HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-                HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-            }
-        } else if (plain && (want == 2 || want == 4) && pk_lds_bytes(want, nbcap) <= 40 * 1024) {
-            h->pack = want;
-            h->pack_lds = pk_lds_bytes(want, nbcap);
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(4, nbcap)));
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pack2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes(2, nbcap)));
         }
     }
     if (!settle) return BP_OK;
@@ -574,16 +533,16 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
                 HIPCHK(h, hipGetLastError());
                 // the robot's spfa map needs only the robot pose: it runs beside the finish kernel on a second stream
-                if (!h->st_solo) {
-                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_solo, hipStreamNonBlocking));
+                if (!h->st_aux) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux, hipStreamNonBlocking));
                     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
                     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
                 }
                 HIPCHK(h, hipEventRecord(h->ev_fork, st));
-                HIPCHK(h, hipStreamWaitEvent(h->st_solo, h->ev_fork, 0));
-                hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_solo, h->P, h->D, h->B, h->Q, 0);
+                HIPCHK(h, hipStreamWaitEvent(h->st_aux, h->ev_fork, 0));
+                hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_aux, h->P, h->D, h->B, h->Q, 0);
                 HIPCHK(h, hipGetLastError());
-                HIPCHK(h, hipEventRecord(h->ev_join, h->st_solo));
+                HIPCHK(h, hipEventRecord(h->ev_join, h->st_aux));
                 if (h->B.task == 1)
                     hipLaunchKernelGGL(k_ac_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
                 else
@@ -623,32 +582,6 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         }
         else if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
-        else if (mode == MODE_STEP && h->mix_heavy > 0 && h->D.order != nullptr && h->D.dbg == nullptr) {
-            const int NP = h->mix_plain;
-            const int NH = h->mix_heavy + NP, NL = h->num_envs - NH;
-            HIPCHK(h, hipEventRecord(h->ev_fork, st));
-            HIPCHK(h, hipStreamWaitEvent(h->st_solo, h->ev_fork, 0));
-            hipLaunchKernelGGL(k_physics_step_solo, dim3(h->mix_heavy), dim3(64), h->lds_bytes, h->st_solo, h->P, h->D, actions, reward, term, trunc, info);
-            HIPCHK(h, hipGetLastError());
-            HIPCHK(h, hipEventRecord(h->ev_join, h->st_solo));
-            if (NP > 0) { // the next NP envs of the cost order: one env per wave, two waves per SIMD
-                HIPCHK(h, hipStreamWaitEvent(h->st_mid, h->ev_fork, 0));
-                hipLaunchKernelGGL(k_physics_step_from, dim3(NP), dim3(64), h->lds_bytes, h->st_mid, h->P, h->D, actions, reward, term, trunc, info, h->mix_heavy);
-                HIPCHK(h, hipGetLastError());
-                HIPCHK(h, hipEventRecord(h->ev_join2, h->st_mid));
-            }
-            hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, 3000u);
-            if (h->mix_light_packed)
-                hipLaunchKernelGGL(k_physics_step_pack2, dim3((NL + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, NH, NL);
-            else
-                hipLaunchKernelGGL(k_physics_step_from, dim3(NL), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info, NH);
-            HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
-            if (NP > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join2, 0));
-        }
-        else if (mode == MODE_STEP && h->pack == 4 && h->D.dbg == nullptr)
-            hipLaunchKernelGGL(k_physics_step_pack4, dim3((h->num_envs + 3) / 4), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, 0, h->num_envs);
-        else if (mode == MODE_STEP && h->pack == 2 && h->D.dbg == nullptr)
-            hipLaunchKernelGGL(k_physics_step_pack2, dim3((h->num_envs + 1) / 2), dim3(64), h->pack_lds, st, h->P, h->D, actions, reward, term, trunc, info, 0, h->num_envs);
         else if (mode == MODE_STEP)
             hipLaunchKernelGGL(k_physics_step, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (h->resettle && h->maze8)

@@ -33,8 +33,6 @@ struct DevParams {
     double ship_head[2], ship_tail[2];
     int obs_h, obs_w, grid_h, grid_w;
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
-    int cost_proxy;                            // e_cost = work proxy (same unit in every step kernel) instead of wave cycles: mixed launches
-    int pack_adjacent;                         // packed kernels: wave b takes positions K*b .. K*b+K-1 of the cost order instead of the snake
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
     double start_x_range, ship_mass;
     unsigned long long start_seed;

@@ -535,8 +535,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         const d2 sp = E.pxy[0];
         const double sa = E.ang[0];
         D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
-        if (mode == MODE_STEP) D.e_cost[env] = P.cost_proxy ? S.costp : (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) +
-                                                                    ((CHUNKED && c_lev > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
+        if (mode == MODE_STEP) D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + ((CHUNKED && c_lev > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
         D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
         D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
         if (err_any) atomicOr(&D.e_err[env], err_any);
@@ -635,23 +634,6 @@ __global__ __launch_bounds__(64) void k_physics_step(const DevParams P, const De
 {
     physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
 }
-// the same for the envs at positions [boff, boff + gridDim.x) of the dispatch order (mixed launch, light part on one env per wave)
-__global__ __launch_bounds__(64) void k_physics_step_from(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
-                                                          double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                          unsigned char *__restrict__ truncated, double *__restrict__ info, const int boff)
-{
-    physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, boff);
-}
-// Mixed launch (BP_MIX, bp_capi.hip): the same step for the heaviest envs in a kernel whose waves claim a SIMD each -- an accumulation
-// register is touched so that the wave's register allocation exceeds what leaves room for any other wave -- so that the envs that set
-// the launch time run without a SIMD mate; the light majority runs two to a wavefront (k_physics_step_pack2) beside them.
-__global__ __launch_bounds__(64) void k_physics_step_solo(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
-                                                          double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                          unsigned char *__restrict__ truncated, double *__restrict__ info)
-{
-    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
-    physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
-}
 // ---- preemptive step scheduler ------------------------------------------------------------------------------------------------------
 // A launch ends with its last env, and which envs will be heavy in a step is only half predictable from the previous one: with the static
 // heaviest-first order an env that turns out heavy after starting in the second round of the 2 048 wave slots sets the launch time (measured:
@@ -725,12 +707,6 @@ __global__ __launch_bounds__(64) void k_physics_step_sched_maze(const DevParams 
 {
     sched_body<BP_ENV_MAZE>(P, D, actions, reward, terminated, truncated, info);
 }
-// a few tens of microseconds of nothing: lets the solo kernel's workgroups land on empty SIMDs before the packed grid floods the chip
-__global__ void k_delay(const unsigned ticks_100mhz)
-{
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks_100mhz) __builtin_amdgcn_s_sleep(32);
-}
 // reset() of the masked envs: new space from the next trial + 1000 settle sub-steps
 __global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                       double *__restrict__ info, const int tmpl)
@@ -789,7 +765,6 @@ __global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict_
     }
 }
 
-#include "bp_physics_pack.hpp"
 
 // reset() from the settled per-trial template (ship_ice_env.py:223-249 is a pure function of the trial when
 // random_start is off): copy the template state of trial (global_env_id + episode) % T into the env.

@@ -68,29 +68,6 @@ def test_parity_30pct_with_contacts_and_autoreset():
     assert _run_parity(E=8, conc=0.3, T=3, steps=40, seed=0) > 1000
 
 
-@pytest.mark.parametrize("pack,E", [("4", 7), ("4", 8), ("2", 5)])
-def test_parity_packed_step_kernel(monkeypatch, pack, E):
-    """k_physics_step_pack<K> (K envs per wavefront, bp_physics_pack.hpp; opt-in with BP_PACK) is bit-identical to the oracle too:
-    full waves, a ragged last wave, auto-resets, 30 % and 50 % fields."""
-    monkeypatch.setenv("BP_PACK", pack)
-    assert _run_parity(E=E, conc=0.3, T=3, steps=30, seed=5) > 500
-    assert _run_parity(E=E, conc=0.5, T=2, steps=10, seed=21) > 100
-
-
-def test_parity_mixed_launch(monkeypatch):
-    """BP_MIX: the heaviest envs in the one-SIMD-per-wave kernel on a second stream, the rest two to a wavefront -- same results."""
-    monkeypatch.setenv("BP_MIX", "2")
-    assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
-
-
-def test_parity_three_way_launch(monkeypatch):
-    """BP_MIX + BP_MIX_PLAIN + BP_MIX_PAIR=adjacent: heaviest envs solo, the next ones one per wave, the rest packed in cost order (ragged last wave)."""
-    monkeypatch.setenv("BP_MIX", "2")
-    monkeypatch.setenv("BP_MIX_PLAIN", "3")
-    monkeypatch.setenv("BP_MIX_PAIR", "adjacent")
-    assert _run_parity(E=12, conc=0.3, T=3, steps=30, seed=6) > 500
-
-
 def test_parity_preemptive_scheduler(monkeypatch):
     """k_physics_step_sched (the default step kernel: chunks of 40 sub-steps, envs parked at a chunk boundary when another one is further behind and
     resumed by another workgroup) with other chunk sizes -- one that divides the 400 sub-steps, one that leaves a ragged last chunk -- and the
@@ -308,9 +285,9 @@ def test_full_size_properties_4096_envs():
 
 
 def test_step_kernel_variants_agree_at_full_size(monkeypatch):
-    """4096 envs x 40 steps with auto-reset (deep enough for the cost-sorted dispatch order, the snake seating of the packed waves and
-    the heavy / light split of the mixed launch to matter): the preemptive scheduler (the default), the packed kernels (BP_PACK=4, 2) and the
-    mixed launch (BP_MIX) leave every env in exactly the state of the one-env-per-wavefront kernel -- body state, rewards, termination, observations, episode metrics."""
+    """4096 envs x 40 steps with auto-reset (deep enough for the cost-sorted dispatch order and for thousands of parked envs): the preemptive
+    scheduler (the default, and a ragged chunk size) leaves every env in exactly the state of the one-env-per-wavefront kernel (BP_SCHED=0) --
+    body state, rewards, termination, observations, episode metrics."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
     trials = default_trials(0.3, 24, base_seed=3)
     E, steps = 4096, 40
@@ -319,7 +296,7 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
 
     def run(env_vars):
-        for k in ("BP_PACK", "BP_MIX", "BP_MIX_LIGHT", "BP_SCHED"):
+        for k in ("BP_SCHED",):
             monkeypatch.delenv(k, raising=False)
         for k, v in env_vars.items():
             monkeypatch.setenv(k, v)
@@ -340,7 +317,7 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     ref = run({"BP_SCHED": "0"})                               # one env per wavefront for the whole step
     assert ref[5] > 1000                                       # episodes did end and restart inside the window
     # {} = the default: the preemptive scheduler (k_physics_step_sched), here with thousands of envs parked and resumed on other CUs / XCDs
-    for variant in ({}, {"BP_SCHED": "25"}, {"BP_PACK": "4"}, {"BP_PACK": "2"}, {"BP_MIX": "512"}):
+    for variant in ({}, {"BP_SCHED": "37"}):
         got = run(variant)
         for a, b in zip(ref[:5], got[:5]):
             assert torch.equal(a, b), variant
