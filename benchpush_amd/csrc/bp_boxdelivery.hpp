@@ -563,7 +563,8 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
     ArbReg A;
     SubState S;
 #ifdef BP_PROF
-    for (int q = 0; q < 24; q++) S.prof[q] = 0;
+    if (lane < BP_PROFN) L.prof[lane] = 0ull;
+    lds_sync();
     const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
     unsigned long long _t_ctrl = 0;
 #endif
@@ -755,10 +756,10 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
     __syncthreads();
     store_state(P, D, L, A, env);
 #ifdef BP_PROF
-    if (D.prof != nullptr && lane == 0) {
-        S.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
-        S.prof[22] = total_sub; S.prof[15] = _t_ctrl;
-        for (int q = 0; q < 24; q++) D.prof[(size_t)env * 24 + q] = S.prof[q];
+    if (D.prof != nullptr) {
+        if (lane == 0) { L.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0; L.prof[22] = total_sub; L.prof[15] = _t_ctrl; }
+        lds_sync();
+        if (lane < BP_PROFN) D.prof[(size_t)env * BP_PROFN + lane] = L.prof[lane];
     }
 #endif
     const int err_any = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |

@@ -86,11 +86,12 @@ static int dalloc(bp_handle *h, T **p, size_t n, int fill_byte = 0)
 }
 
 static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
-static size_t lds_bytes_for(int nbcap)
-{
-    return sizeof(d2) * 3 * BP_EVCAP + sizeof(unsigned) * BP_EVCAP + 16 + sizeof(d2) * (BP_NSLOT + 1) * 3 + sizeof(d2) * 128 + 2688 + sizeof(unsigned) * nbcap + sizeof(unsigned short) * nbcap * 2 +
-           sizeof(unsigned short) * mvcap_for(nbcap) + (size_t)nbcap + 64 + 64;
-}
+#ifdef BP_PROF
+#define BP_PROF_HOST true
+#else
+#define BP_PROF_HOST false
+#endif
+static size_t lds_bytes_for(int nbcap) { return bp_lds_map(nbcap, mvcap_for(nbcap), true, BP_PROF_HOST).total; }
 
 extern "C" {
 

@@ -74,7 +74,7 @@ struct DevPtrs {
     double4 *bb, *fat;       // [E][nbcap] l,b,r,t
     unsigned short *adj;     // [E][nbcap][KADJ]
     unsigned char *adjn;     // [E][nbcap]
-    unsigned char *hint;     // [E][nbcap][KADJ]
+    unsigned short *hint;    // [E][nbcap][KADJ] cached plane-search winners of the pair behind each neighbour slot (HW_* below)
     // persisted arbiter slots [E][ACAP]
     unsigned *a_key, *a_stamp, *a_sc, *a_h0, *a_h1;
     double *a_d;             // [E][ACAP][14] jn0 jt0 jn1 jt1 nx ny r1x0 r1y0 r2x0 r2y0 r1x1 r1y1 r2x1 r2y1
@@ -104,6 +104,66 @@ __device__ __forceinline__ double vlen(d2 a) { return __builtin_sqrt(vdot(a, a))
 __device__ __forceinline__ d2 vlerp(d2 a, d2 b, double t) { return vadd(vmul(a, 1.0 - t), vmul(b, t)); }
 __device__ __forceinline__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
 __device__ __forceinline__ double fclampd(double f, double lo, double hi) { return fmin(fmax(f, lo), hi); }
+
+// Hint word of a neighbour-list entry: the planes that won the two sides of the pair's plane search when it was last run in full.  A cached plane is
+// re-evaluated exactly (its separation is a lower bound of the pair's maximum: above the radii the pair is rejected at once) and every other plane is
+// first bounded from above with one vertex; only planes whose bound reaches the cached value are searched.  0 = nothing cached.
+#define HW_PLANE_A(h) ((int)((h) & 31u))
+#define HW_PLANE_B(h) ((int)(((h) >> 5) & 31u))
+#define HW_HAS_A 0x400u
+#define HW_HAS_B 0x800u
+#define HW_PRIM_B 0x1000u   // the side whose plane had the larger separation (the one tested first) is B
+#define HW_BOTH 0x2000u     // the pair got past the cached-plane test last time: both cached planes are evaluated up front
+#define BP_QCAP 96          // support queries per batch (LDS)
+
+#define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step
+#define BP_MBOX 16          // manifold mailbox entries per hand-over batch
+#define BP_NSLOT 96         // velocity slots per env (bodies with a non-zero velocity or an arbiter)
+#define BP_PROFN 48         // diagnostic build: phase timers / trip counters per env
+
+// LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the
+// host (launch size), so the two cannot drift apart.
+struct LdsMap {
+    unsigned sv, sw, sb, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mv,
+        slot_of, rf, ev_d, ev_key, prof, total;
+};
+__host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
+{
+    LdsMap m;
+    unsigned p = 0;
+    m.sv = p; p += 16u * (BP_NSLOT + 1);    // + 1: scratch slot BP_NSLOT
+    m.sw = p; p += 16u * (BP_NSLOT + 1);
+    m.sb = p; p += 16u * (BP_NSLOT + 1);
+    m.tf = p; p += 16u * 128;
+    // narrow-phase scratch; the manifold mailbox (BP_MBOX x 96 B) later reuses the query buffers from q_dir on
+    m.q_dir = p; p += 16u * BP_QCAP;
+    m.q_c = p; p += 8u * BP_QCAP;
+    m.r_val = p; p += 8u * BP_QCAP;
+    m.q_meta = p; p += 4u * BP_QCAP;
+    m.q_aux = p; p += 4u * BP_QCAP;
+    m.r_idx = p; p += 4u * BP_QCAP;
+    m.pt_a = p; p += 16u * 64;
+    m.pt_thr = p; p += 16u * 64;
+    m.res_smA = p; p += 8u * 64;              // res_smA .. res_jB are contiguous: the AABB keys of the transform phase ([64][4] u64) alias them
+    m.res_smB = p; p += 8u * 64;
+    m.res_iA = p; p += 4u * 64;
+    m.res_iB = p; p += 4u * 64;
+    m.res_jA = p; p += 4u * 64;
+    m.res_jB = p; p += 4u * 64;
+    m.mvs = p; p += 4u * (unsigned)nbcap;
+    m.owner = p; p += 2u * (unsigned)nbcap;
+    m.colmask = p; p += 2u * (unsigned)nbcap;
+    m.mv = p; p += 2u * (unsigned)mvcap;
+    m.slot_of = p; p += (unsigned)nbcap;
+    m.rf = p; p += 64u;
+    p = (p + 15u) & ~15u;
+    m.ev_d = p; if (box) p += 16u * 3 * BP_EVCAP;
+    m.ev_key = p; if (box) p += 4u * BP_EVCAP;
+    p = (p + 7u) & ~7u;
+    m.prof = p; if (prof) p += 8u * BP_PROFN;
+    m.total = (p + 15u) & ~15u;
+    return m;
+}
 
 #define SQ_MAXLEV 16
 #define BP_DBL_MIN 2.2250738585072014e-308
@@ -192,6 +252,22 @@ __device__ __forceinline__ double half_min(double v)
     v = fmin(v, dpp_mov_f64<0x141>(v));
     v = fmin(v, dpp_mov_f64<0x140>(v));
     v = fmin(v, __shfl_xor(v, 16));
+    return v;
+}
+// 8-lane groups (lanes 8g .. 8g+7): every lane receives the group's minimum
+__device__ __forceinline__ double oct_min_f64(double v)
+{
+    double p;
+    p = dpp_mov_f64<0xB1>(v); v = (p < v) ? p : v;    // quad_perm [1,0,3,2]
+    p = dpp_mov_f64<0x4E>(v); v = (p < v) ? p : v;    // quad_perm [2,3,0,1]
+    p = dpp_mov_f64<0x141>(v); v = (p < v) ? p : v;   // row_half_mirror: lane i <-> 7 - i of each half row
+    return v;
+}
+__device__ __forceinline__ int oct_min_i32(int v)
+{
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xF, 0xF, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xF, 0xF, false));
     return v;
 }
 // order-preserving bijection binary64 -> u64 (for LDS integer atomics); -0 must be folded into +0 by the caller

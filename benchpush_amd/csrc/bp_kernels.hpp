@@ -31,41 +31,34 @@ __device__ __forceinline__ d2 poly_centroid_seq(const d2 *v, int n)
     return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
 }
 
+#ifdef BP_PROF
+#define BP_PROF_ON true
+#else
+#define BP_PROF_ON false
+#endif
 template <int KIND>
 __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
 {
-    const int nbcap = P.nbcap;
-    char *p = (char *)bp_smem;
-    L.sv = (d2 *)p; p += sizeof(d2) * (BP_NSLOT + 1);   // + 1: scratch slot BP_NSLOT
-    L.sw = (d2 *)p; p += sizeof(d2) * (BP_NSLOT + 1);
-    L.sb = (d2 *)p; p += sizeof(d2) * (BP_NSLOT + 1);
-    L.tf = (d2 *)p; p += sizeof(d2) * 128;
-    // scratch region shared by the plane search (res_*, pl_*) and, afterwards, the manifold mailbox
-    char *scr = p;
-    L.mbox = (d2 *)scr;
-    L.res_smA = (unsigned long long *)p; p += 8 * 64;
-    L.res_smB = (unsigned long long *)p; p += 8 * 64;
-    L.res_iA = (unsigned *)p; p += 4 * 64;
-    L.res_iB = (unsigned *)p; p += 4 * 64;
-    L.res_jA = (unsigned *)p; p += 4 * 64;
-    L.res_jB = (unsigned *)p; p += 4 * 64;
-    L.pl_off = (unsigned short *)p; p += 2 * 128;  // [pair rank][side]
-    L.pl_sa = (unsigned short *)p; p += 2 * 64;
-    L.pl_sb = (unsigned short *)p; p += 2 * 64;
-    L.pl_na = (unsigned char *)p; p += 64;
-    L.pl_nb = (unsigned char *)p; p += 64;   // scratch = 2688 B >= mailbox 16 * 96 B
-    L.mvs = (unsigned *)p; p += sizeof(unsigned) * nbcap;
-    L.owner = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
-    L.colmask = (unsigned short *)p; p += sizeof(unsigned short) * nbcap;
-    L.mv = (unsigned short *)p; p += sizeof(unsigned short) * P.mvcap;
-    L.slot_of = (unsigned char *)p; p += nbcap;
-    L.rf = (unsigned char *)p; p += 64;
+    const LdsMap m = bp_lds_map(P.nbcap, P.mvcap, KIND == BP_ENV_BOX, BP_PROF_ON);
+    char *b = (char *)bp_smem;
+    L.sv = (d2 *)(b + m.sv); L.sw = (d2 *)(b + m.sw); L.sb = (d2 *)(b + m.sb);
+    L.tf = (d2 *)(b + m.tf);
+    L.q_dir = (d2 *)(b + m.q_dir); L.q_c = (double *)(b + m.q_c); L.r_val = (double *)(b + m.r_val);
+    L.q_meta = (unsigned *)(b + m.q_meta); L.q_aux = (unsigned *)(b + m.q_aux); L.r_idx = (unsigned *)(b + m.r_idx);
+    L.pt_a = (uint4 *)(b + m.pt_a); L.pt_thr = (d2 *)(b + m.pt_thr);
+    L.mbox = (d2 *)(b + m.q_dir);   // BP_MBOX * 96 B = 1536 B = the q_dir array
+    L.res_smA = (unsigned long long *)(b + m.res_smA); L.res_smB = (unsigned long long *)(b + m.res_smB);
+    L.res_iA = (unsigned *)(b + m.res_iA); L.res_iB = (unsigned *)(b + m.res_iB);
+    L.res_jA = (unsigned *)(b + m.res_jA); L.res_jB = (unsigned *)(b + m.res_jB);
+    L.mvs = (unsigned *)(b + m.mvs);
+    L.owner = (unsigned short *)(b + m.owner); L.colmask = (unsigned short *)(b + m.colmask);
+    L.mv = (unsigned short *)(b + m.mv);
+    L.slot_of = (unsigned char *)(b + m.slot_of); L.rf = (unsigned char *)(b + m.rf);
     L.ev_key = nullptr; L.ev_d = nullptr;
-    if (KIND == BP_ENV_BOX) {
-        p = (char *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
-        L.ev_d = (d2 *)p; p += sizeof(d2) * 3 * BP_EVCAP;
-        L.ev_key = (unsigned *)p; p += sizeof(unsigned) * BP_EVCAP;
-    }
+    if (KIND == BP_ENV_BOX) { L.ev_d = (d2 *)(b + m.ev_d); L.ev_key = (unsigned *)(b + m.ev_key); }
+#ifdef BP_PROF
+    L.prof = (unsigned long long *)(b + m.prof);
+#endif
 }
 
 __device__ __forceinline__ void env_ctx(const DevParams &P, const DevPtrs &D, int env, int trial, EnvCtx &E)
@@ -306,7 +299,8 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     ArbReg A;
     SubState S;
 #ifdef BP_PROF
-    for (int q = 0; q < 24; q++) S.prof[q] = 0;
+    if (lane < BP_PROFN) L.prof[lane] = 0ull;
+    lds_sync();
     const unsigned long long _t_kernel0 = __builtin_amdgcn_s_memtime();
 #endif
     init_regs(A, S);
@@ -476,6 +470,13 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             cy[3] = (c_lev == 0 ? 0u : cy[3]) + (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
             if (err_c) atomicOr(&D.e_err[env], err_c);
         }
+#ifdef BP_PROF
+        if (D.prof != nullptr) { // a step that is run in several chunks accumulates (the tool clears the buffer before each step)
+            if (lane == 0) L.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
+            lds_sync();
+            if (lane < BP_PROFN) D.prof[(size_t)env * BP_PROFN + lane] += L.prof[lane];
+        }
+#endif
         return false;
     }
     // ---- end of step: work / reward / termination (ship_ice_env.py:291-345) or reset snapshot ----
@@ -516,16 +517,17 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     store_state(P, D, L, A, env);
 #ifdef BP_PRED
     if (D.prof != nullptr && lane == 0 && mode == MODE_STEP) { // candidate predictors of the next step's cost (tools/cost_predictability.py)
-        unsigned long long *o = D.prof + (size_t)env * 24;
+        unsigned long long *o = D.prof + (size_t)env * BP_PROFN;
         o[0] = S.costp; o[1] = S.costp - pr_c200; o[2] = S.costp - pr_c100; o[3] = S.costp - pr_c50; o[4] = S.costp - pr_c10;
         o[5] = (unsigned long long)S.nmv; o[6] = (unsigned long long)__popcll(S.prev_amask); o[7] = (unsigned long long)S.nslots;
         o[8] = __builtin_amdgcn_s_memtime() - t_begin;
     }
 #endif
 #ifdef BP_PROF
-    if (D.prof != nullptr && lane == 0) {
-        S.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
-        for (int q = 0; q < 24; q++) D.prof[(size_t)env * 24 + q] = S.prof[q];
+    if (D.prof != nullptr) {
+        if (lane == 0) L.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
+        lds_sync();
+        if (lane < BP_PROFN) D.prof[(size_t)env * BP_PROFN + lane] += L.prof[lane];
     }
 #endif
     const int err_any = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |
@@ -794,7 +796,7 @@ __global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const Dev
     copy_span(D.bb + d, D.bb + s, nb, tid, nt);
     copy_span(D.fat + d, D.fat + s, nb, tid, nt);
     copy_span((unsigned long long *)(D.adj + d * BP_KADJ), (const unsigned long long *)(D.adj + s * BP_KADJ), nb * BP_KADJ / 4, tid, nt);
-    copy_span((unsigned long long *)(D.hint + d * BP_KADJ), (const unsigned long long *)(D.hint + s * BP_KADJ), nb * BP_KADJ / 8, tid, nt);
+    copy_span((unsigned long long *)(D.hint + d * BP_KADJ), (const unsigned long long *)(D.hint + s * BP_KADJ), nb * BP_KADJ / 4, tid, nt);
     copy_span((unsigned long long *)(D.adjn + d), (const unsigned long long *)(D.adjn + s), nb / 8, tid, nt);
     const size_t ad = (size_t)env * BP_ACAP, as = (size_t)(P.num_envs + trial) * BP_ACAP;
     copy_span(D.a_key + ad, D.a_key + as, BP_ACAP, tid, nt);
@@ -1032,7 +1034,7 @@ __device__ __forceinline__ void raster_row_convex(const double *xp, const double
 
 // Flag bits of the LDS window image
 #ifdef BP_PROF
-#define OPROF(k) { if (tid == 0 && D.prof != nullptr) D.prof[(size_t)env * 24 + (k)] = __builtin_amdgcn_s_memtime(); }
+#define OPROF(k) { if (tid == 0 && D.prof != nullptr) D.prof[(size_t)env * BP_PROFN + 40 + (k)] = __builtin_amdgcn_s_memtime(); }   // slots 40..47: k_observe's stamps
 #else
 #define OPROF(k)
 #endif

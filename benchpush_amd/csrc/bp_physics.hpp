@@ -18,9 +18,9 @@
 // Optional in-kernel phase timers (diagnostic build only: -DBP_PROF).  Stamps go to D.prof, which nothing else reads.
 #ifdef BP_PROF
 #define PROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
-#define PROF_ACC(slot) { unsigned long long _n = __builtin_amdgcn_s_memtime(); S.prof[slot] += _n - _pt; _pt = _n; }
-#define PROF_CNT(slot, v) { S.prof[slot] += (unsigned long long)(v); }
-#define PROF_MAX(slot, v) { if ((unsigned long long)(v) > S.prof[slot]) S.prof[slot] = (unsigned long long)(v); }
+#define PROF_ACC(slot) { unsigned long long _n = __builtin_amdgcn_s_memtime(); if (lane_id() == 0) L.prof[slot] += _n - _pt; _pt = _n; }
+#define PROF_CNT(slot, v) { const unsigned long long _v = (unsigned long long)(v); if (lane_id() == 0) L.prof[slot] += _v; }
+#define PROF_MAX(slot, v) { const unsigned long long _v = (unsigned long long)(v); if (lane_id() == 0 && _v > L.prof[slot]) L.prof[slot] = _v; }
 #else
 #define PROF_DECL
 #define PROF_ACC(slot)
@@ -57,7 +57,8 @@ struct EnvCtx {
     double *ang;
     double4 *bb, *fat;
     unsigned short *adj;
-    unsigned char *adjn, *hint;
+    unsigned char *adjn;
+    unsigned short *hint;
 };
 
 struct LdsCtx {
@@ -69,19 +70,26 @@ struct LdsCtx {
     d2 *tf;                    // [64][2] (cos, sin) (tx, ty) of the moving bodies of the current chunk
     unsigned short *mv;        // [P.mvcap] moving-body list
     unsigned char *rf;         // [64] refresh flags of the current chunk
-    // batched narrow phase (per candidate round, indexed by survivor rank)
-    unsigned long long *res_smA, *res_smB; // [64] order-preserving keys of the best plane separation of A / B
-    unsigned *res_iA, *res_iB, *res_jA, *res_jB; // [64] plane index / support vertex of the best plane
-    unsigned short *pl_off, *pl_sa, *pl_sb;      // [64]
-    unsigned char *pl_na, *pl_nb;                // [64]
-    d2 *mbox;                  // [BP_MBOX][6] manifold mailbox
+    // narrow phase (per candidate round, indexed by survivor rank): best plane separation of side A / B as order-preserving keys, its plane
+    // index and support vertex
+    unsigned long long *res_smA, *res_smB; // [64]
+    unsigned *res_iA, *res_iB, *res_jA, *res_jB; // [64]
+    // support queries (support_queries below): direction, (body | vertex count << 16), result value / first index; q_aux / q_c carry the plane
+    // a query belongs to (pair rank | side << 8 | plane << 16) and dot(fn, fp) of that plane
+    d2 *q_dir;                 // [BP_QCAP]
+    double *q_c, *r_val;       // [BP_QCAP]
+    unsigned *q_meta, *q_aux, *r_idx; // [BP_QCAP]
+    // pair table of a candidate round: what the plane-bound rounds need of each surviving pair
+    uint4 *pt_a;               // [64] sa | sb << 16, nA | nB << 8 | hA << 16 | hB << 24, evaluated sides | jA << 8 | jB << 16, -
+    d2 *pt_thr;                // [64] separation of the cached plane of side A / B (-inf: none)
+    d2 *mbox;                  // [BP_MBOX][6] manifold mailbox (aliases the query buffers)
     // box-delivery only (substep<BP_ENV_BOX>): (1,3)/(2,3) pre_solve calls of the current sub-step
     unsigned *ev_key;          // [BP_EVCAP] shapeA << 16 | shapeB
     d2 *ev_d;                  // [BP_EVCAP][3] normal, r1, r2 of contact 0
+#ifdef BP_PROF
+    unsigned long long *prof;  // [BP_PROFN] phase cycle counters and trip counts of this run (diagnostic build)
+#endif
 };
-#define BP_EVCAP 32
-#define BP_MBOX 16
-#define BP_NSLOT 96
 
 struct SubState {
     unsigned stamp;
@@ -101,9 +109,6 @@ struct SubState {
     int nev;                   // box-delivery: recorded pre_solve events of this sub-step
     int robot_hit;             // box-delivery: robot_hit_obstacle (box_delivery_env.py:208-210)
     unsigned long long evmask; // box-delivery: bodies (index < 64) whose position a pre_solve changed in this sub-step
-#ifdef BP_PROF
-    unsigned long long prof[24];
-#endif
 };
 
 // Velocity slot of `body` (wave-uniform call): allocate a zeroed one on first use.  Slot 0 is the ship.
@@ -123,7 +128,7 @@ __device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, int body)
     return s;
 }
 
-struct Manifold { int count; d2 n; d2 p1_0, p2_0, p1_1, p2_1; unsigned h0, h1; int newhint; };
+struct Manifold { int count; d2 n; d2 p1_0, p2_0, p1_1, p2_1; unsigned h0, h1; };
 
 __device__ __forceinline__ bool bb_overlap(double4 a, double4 b)
 {
@@ -218,6 +223,38 @@ __device__ __forceinline__ void apply_contact_impulses(const ArbReg &A, int c, d
     wb += A.ib * vcross(r2, j);
 }
 
+// Support queries: for each of the nq records in L.q_dir / L.q_meta (direction d, body | vertex count << 16) the minimum of d . v over the body's
+// world vertices and the FIRST vertex index that attains it -- what the sequential loop "for q: if (d . v[q] < mn) { mn = ...; jm = q; }" leaves in
+// (mn, jm).  Eight lanes share a query (vertex q goes to lane q mod 8; each lane scans its vertices in ascending order with the same strict '<'),
+// the group's minimum comes from three DPP steps, and among the lanes that hold it the one with the lowest index writes (value, index) to L.r_val /
+// L.r_idx: the products, the sums and the comparisons are those of the sequential loop, so the result is bit-identical.  Wave-uniform call.
+template <int VL>
+__device__ __forceinline__ void support_queries(const EnvCtx &E, const LdsCtx &L, const int nq)
+{
+    const int lane = lane_id();
+    const int l8 = lane & 7, g = lane >> 3;
+    for (int base = 0; base < nq; base += 8) {
+        const int k = base + g;
+        const bool act = k < nq;
+        const d2 dir = L.q_dir[act ? k : 0];
+        const unsigned meta = L.q_meta[act ? k : 0];
+        const int body = (int)(meta & 0xFFFFu), nv = (int)(meta >> 16);
+        double best = BP_INF;
+        int bi = 255;
+#pragma unroll
+        for (int t = 0; t < (VL + 7) / 8; t++) {
+            const int q = l8 + 8 * t;
+            const bool ok = act && (q < nv);
+            const d2 v = E.wv[body * BP_MAXV + (ok ? q : 0)];
+            const double d = vdot(dir, v);
+            if (ok && d < best) { best = d; bi = q; }
+        }
+        const double m = oct_min_f64(best);
+        const int mi = oct_min_i32((best == m) ? bi : 255);
+        if (act && best == m && bi == mi) { L.r_val[k] = best; L.r_idx[k] = (unsigned)bi; }
+    }
+}
+
 // One sub-step.  ship_rules: apply the yaw / boundary rules of ShipIceEnv.step after the sub-step.
 // KIND == BP_ENV_BOX adds box-delivery's collision handlers (box_delivery_env.py:208-229,294-311); other values compile them out.
 template <int KIND>
@@ -264,6 +301,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             L.mvs[i] = now;
         }
         lds_sync();
+        PROF_ACC(33)
         const int cnt = min(64, S.nmv - k0);
         // world vertices / normals, one (body, vertex) item per lane; AABB through LDS atomic min/max on order-preserving
         // keys (min and max are exact, so the reduction order is irrelevant).  bbk aliases the narrow-phase scratch.
@@ -292,6 +330,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             }
         }
         lds_sync();
+        PROF_ACC(34)
         if (lane < cnt) {
             const int i = L.mv[k0 + lane];
             const double rad = E.prop[i].x;
@@ -316,6 +355,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         PROF_ACC(1)
     }
     __syncthreads();
+    PROF_ACC(35)
 
     // ---- 3./4. candidate pairs of moving bodies ----------------------------------------------------------------
     int kmax = 0; // largest neighbour count among the moving bodies (wave-uniform, found with 5 ballots per chunk)
@@ -331,14 +371,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const int idx = base + lane;
         const int k = idx / kmax, s = idx - k * kmax;
         // Loads are issued unconditionally on clamped (always valid) addresses so that independent ones travel together:
-        // round trip 1: neighbour id / count / hint / own AABB; 2: partner AABB, kinds, masses, radii, vertex counts;
-        // 3: the hinted plane; 4: the partner's vertices.
+        // round trip 1: neighbour id / count / hint word / own AABB; 2: partner AABB, kinds, masses, radii, vertex counts.
         const bool inlist = k < S.nmv;
         const int i = inlist ? (int)L.mv[k] : 0;
         const int sc = min(s, BP_KADJ - 1);
         const int adjn_i = E.adjn[i];
         const int j = E.adj[i * BP_KADJ + sc] < E.nb ? (int)E.adj[i * BP_KADJ + sc] : 0;
-        const int h = E.hint[i * BP_KADJ + sc];
+        const unsigned hw = E.hint[i * BP_KADJ + sc];
         const double4 bbi = E.bb[i];
         bool valid = inlist && (s < adjn_i);
         if (valid && L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
@@ -358,118 +397,176 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             }
         }
         if (valid) valid = bb_overlap(bbi, bbj);
-        if (valid && h != 255) {
-            int pb, qb, fi;
-            if (h < nA_h) { pb = sa; qb = sb; fi = h; } else { pb = sb; qb = sa; fi = min(h - nA_h, nB_h - 1); }
-            const d2 fn = E.wn[pb * BP_MAXV + fi], fp = E.wv[pb * BP_MAXV + fi];
-            const int nq = (qb == sa) ? nA_h : nB_h;
-            double mn = BP_INF;
-#pragma unroll 10
-            for (int q = 0; q < VL; q++) { // several loads in flight at once; slots >= nq repeat vertex 0
-                const double d = vdot(fn, E.wv[qb * BP_MAXV + (q < nq ? q : 0)]);
-                if (d < mn) mn = d;
+        PROF_ACC(27)
+        PROF_CNT(24, 1)
+        PROF_CNT(36, __popcll(ballot(valid)))
+        if (ballot(valid) == 0) { PROF_ACC(2) continue; }
+        // ---- 4a. cached planes: the plane that won a side of this pair's plane search last time is evaluated exactly (its minimum over the other
+        //      shape's vertices, found by eight lanes per plane).  Any plane's separation is a lower bound of the pair's maximum, so a cached plane
+        //      that clears the radii rejects the pair (cpCollide would find no contact).  Pairs that were rejected last time test only the plane
+        //      that rejected them; pairs that got through test the cached plane of both sides.
+        const int hA = min(HW_PLANE_A(hw), nA_h - 1), hB = min(HW_PLANE_B(hw), nB_h - 1);
+        const bool evA = valid && (hw & HW_HAS_A) && ((hw & HW_BOTH) || !(hw & HW_PRIM_B));
+        const bool evB = valid && (hw & HW_HAS_B) && ((hw & HW_BOTH) || (hw & HW_PRIM_B));
+        double sepAc = -BP_INF, sepBc = -BP_INF;
+        int jAc = 0, jBc = 0;
+        {
+            const unsigned long long mqA = ballot(evA), mqB = ballot(evB);
+            const int nqA = __popcll(mqA), nq1 = nqA + __popcll(mqB);
+            PROF_CNT(37, nq1)
+            if (nq1) {
+                const int slA = popc_below(mqA, lane), slB = nqA + popc_below(mqB, lane);
+                const d2 fnA = E.wn[sa * BP_MAXV + hA], fpA = E.wv[sa * BP_MAXV + hA];
+                const d2 fnB = E.wn[sb * BP_MAXV + hB], fpB = E.wv[sb * BP_MAXV + hB];
+                const double cA = vdot(fnA, fpA), cB = vdot(fnB, fpB);
+                for (int q0 = 0; q0 < nq1; q0 += BP_QCAP) { // one batch unless more than BP_QCAP planes are cached in this round
+                    const bool inA = evA && slA >= q0 && slA < q0 + BP_QCAP, inB = evB && slB >= q0 && slB < q0 + BP_QCAP;
+                    if (inA) { L.q_dir[slA - q0] = fnA; L.q_meta[slA - q0] = (unsigned)sb | ((unsigned)nB_h << 16); }
+                    if (inB) { L.q_dir[slB - q0] = fnB; L.q_meta[slB - q0] = (unsigned)sa | ((unsigned)nA_h << 16); }
+                    lds_sync();
+                    support_queries<VL>(E, L, min(nq1 - q0, BP_QCAP));
+                    lds_sync();
+                    if (inA) { sepAc = (L.r_val[slA - q0] - cA) + 0.0; jAc = (int)L.r_idx[slA - q0]; }
+                    if (inB) { sepBc = (L.r_val[slB - q0] - cB) + 0.0; jBc = (int)L.r_idx[slB - q0]; }
+                    lds_sync();
+                }
             }
-            const double sep = mn - vdot(fn, fp);
-            if (sep > rsum) valid = false;
+        }
+        if (valid && (sepAc > rsum || sepBc > rsum)) {
+            valid = false;
+            if (hw & HW_BOTH) E.hint[i * BP_KADJ + s] = (unsigned short)((hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0u : HW_PRIM_B));
         }
         const unsigned long long cm = ballot(valid);
-        PROF_ACC(2)
+        PROF_ACC(28)
         PROF_CNT(18, __popcll(cm))
         if (cm == 0) continue;
-        // ---- 4a. face separations of every surviving pair: one (pair, plane) item per lane --------------------------
-        // The planes of one (pair, side) never straddle a 64-item round (the block is moved to the next round if it would), so
-        // the per-round LDS atomics of a side's maximum see all its planes together; the two sides of a pair are independent
-        // maxima and may sit in different rounds.
+        PROF_CNT(25, 1)
+        // ---- 4a'. every other plane of the surviving pairs: one round per pair, lanes 0..31 = planes of A, 32..63 = planes of B.  A plane's separation
+        //      is a minimum over the other shape's vertices, so its value at ONE vertex (the support vertex of the side's cached plane) bounds it from
+        //      above; only planes whose bound reaches the cached plane's exact value can win the side (ties included) and are searched exactly.
         const int nc = __popcll(cm);
         const int myr = popc_below(cm, lane); // rank of this lane's pair among the survivors
         const int nA_l = valid ? nA_h : 0, nB_l = valid ? nB_h : 0;
-        int total = 0;
+        if (valid) {
+            uint4 pa;
+            pa.x = (unsigned)sa | ((unsigned)sb << 16);
+            pa.y = (unsigned)nA_l | ((unsigned)nB_l << 8) | ((unsigned)hA << 16) | ((unsigned)hB << 24);
+            pa.z = (evA ? 1u : 0u) | (evB ? 2u : 0u) | ((unsigned)jAc << 8) | ((unsigned)jBc << 16);
+            pa.w = 0u;
+            L.pt_a[myr] = pa;
+            L.pt_thr[myr] = mk2(sepAc, sepBc);
+            L.res_smA[myr] = evA ? f64_key(sepAc) : 0ull; L.res_iA[myr] = evA ? (unsigned)hA : 0xFFFFFFFFu; L.res_jA[myr] = (unsigned)jAc;
+            L.res_smB[myr] = evB ? f64_key(sepBc) : 0ull; L.res_iB[myr] = evB ? (unsigned)hB : 0xFFFFFFFFu; L.res_jB[myr] = (unsigned)jBc;
+        }
+        lds_sync();
         {
-            unsigned long long m = cm;
-            int r = 0;
-            while (m) {
-                const int l = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const int cA = __builtin_amdgcn_readlane(nA_l, l), cB = __builtin_amdgcn_readlane(nB_l, l);
-                if ((total & 63) + cA > 64) total = (total + 63) & ~63;
-                const int offA = total;
-                total += cA;
-                if ((total & 63) + cB > 64) total = (total + 63) & ~63;
-                const int offB = total;
-                total += cB;
-                if (lane == l) {
-                    L.pl_off[2 * r] = (unsigned short)offA; L.pl_off[2 * r + 1] = (unsigned short)offB;
-                    L.pl_sa[r] = (unsigned short)sa; L.pl_sb[r] = (unsigned short)sb;
-                    L.pl_na[r] = (unsigned char)nA_l; L.pl_nb[r] = (unsigned char)nB_l;
-                    L.res_smA[r] = 0ull; L.res_smB[r] = 0ull; L.res_iA[r] = 0xFFFFFFFFu; L.res_iB[r] = 0xFFFFFFFFu;
+            int nq = 0, g0 = 0; // queries collected, first pair rank of the current group
+            const int side = lane >> 5, f = lane & 31;
+            for (int rr = 0; rr <= nc; rr++) {
+                // the queries collected so far are searched when the next round might not fit, and after the last pair
+                if (nq > 0 && (rr == nc || nq + 64 > BP_QCAP)) {
+                    PROF_ACC(29)
+                    support_queries<VL>(E, L, nq);
+                    lds_sync();
+                    PROF_CNT(26, 1)
+                    PROF_CNT(38, nq)
+                    // separation of every searched plane -> per (pair, side) maximum, lowest plane index on ties, its support vertex
+                    for (int s0 = 0; s0 < nq; s0 += 64) {
+                        const int sl = s0 + lane;
+                        if (sl < nq) {
+                            const unsigned aux = L.q_aux[sl];
+                            const int r = (int)(aux & 0xFFu);
+                            const double sp = (L.r_val[sl] - L.q_c[sl]) + 0.0; // "+ 0.0": -0 and +0 share one key
+                            const unsigned long long key = f64_key(sp);
+                            L.q_c[sl] = __builtin_bit_cast(double, key);
+                            atomicMax((aux & 0x100u) ? &L.res_smB[r] : &L.res_smA[r], key);
+                        }
+                    }
+                    lds_sync();
+                    if (valid && myr >= g0 && myr < rr) { // a cached plane that has been beaten gives up its index
+                        if (evA && f64_key(sepAc) != L.res_smA[myr]) L.res_iA[myr] = 0xFFFFFFFFu;
+                        if (evB && f64_key(sepBc) != L.res_smB[myr]) L.res_iB[myr] = 0xFFFFFFFFu;
+                    }
+                    lds_sync();
+                    for (int s0 = 0; s0 < nq; s0 += 64) {
+                        const int sl = s0 + lane;
+                        if (sl < nq) {
+                            const unsigned aux = L.q_aux[sl];
+                            const int r = (int)(aux & 0xFFu);
+                            const unsigned long long key = __builtin_bit_cast(unsigned long long, L.q_c[sl]);
+                            if (key == ((aux & 0x100u) ? L.res_smB[r] : L.res_smA[r])) atomicMin((aux & 0x100u) ? &L.res_iB[r] : &L.res_iA[r], aux >> 16);
+                        }
+                    }
+                    lds_sync();
+                    for (int s0 = 0; s0 < nq; s0 += 64) {
+                        const int sl = s0 + lane;
+                        if (sl < nq) {
+                            const unsigned aux = L.q_aux[sl];
+                            const int r = (int)(aux & 0xFFu);
+                            const unsigned long long key = __builtin_bit_cast(unsigned long long, L.q_c[sl]);
+                            const bool onB = (aux & 0x100u) != 0;
+                            if (key == (onB ? L.res_smB[r] : L.res_smA[r]) && (aux >> 16) == (onB ? L.res_iB[r] : L.res_iA[r])) {
+                                if (onB) L.res_jB[r] = L.r_idx[sl]; else L.res_jA[r] = L.r_idx[sl];
+                            }
+                        }
+                    }
+                    lds_sync();
+                    nq = 0; g0 = rr;
+                    PROF_ACC(30)
                 }
-                r++;
+                if (rr == nc) break;
+                const uint4 pa = L.pt_a[rr];
+                const d2 thr = L.pt_thr[rr];
+                const int psa = (int)(pa.x & 0xFFFFu), psb = (int)(pa.x >> 16);
+                const int pna = (int)(pa.y & 0xFFu), pnb = (int)((pa.y >> 8) & 0xFFu);
+                const int pbody = side ? psb : psa, qbody = side ? psa : psb;
+                const int np = side ? pnb : pna, nqv = side ? pna : pnb;
+                const int hX = (int)((pa.y >> (side ? 24 : 16)) & 0xFFu);
+                const bool evX = ((pa.z >> side) & 1u) != 0;
+                const int jc = (int)((pa.z >> (side ? 16 : 8)) & 0xFFu);
+                const double th = side ? thr.y : thr.x;
+                const bool pv = (f < np) && !(evX && f == hX);
+                const int fc = (f < np) ? f : 0;
+                const d2 fn = E.wn[pbody * BP_MAXV + fc], fp = E.wv[pbody * BP_MAXV + fc];
+                const d2 vb = E.wv[qbody * BP_MAXV + jc];
+                const double c = vdot(fn, fp);
+                const double bound = (vdot(fn, vb) - c) + 0.0;
+                const bool surv = pv && (!evX || bound >= th);
+                const unsigned long long sm = ballot(surv);
+                if (surv) {
+                    const int sl = nq + popc_below(sm, lane);
+                    L.q_dir[sl] = fn; L.q_meta[sl] = (unsigned)qbody | ((unsigned)nqv << 16);
+                    L.q_aux[sl] = (unsigned)rr | ((unsigned)side << 8) | ((unsigned)f << 16);
+                    L.q_c[sl] = c;
+                }
+                nq += __popcll(sm);
+                lds_sync();
             }
         }
-        lds_sync();
-        for (int t0 = 0; t0 < total; t0 += 64) {
-            const int t = t0 + lane;
-            int eb = 0;
-            {   // largest block (2 * rank + side) with pl_off[block] <= t
-                int lo = 0, hi = 2 * nc - 1;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if ((int)L.pl_off[mid] <= t) lo = mid; else hi = mid - 1; }
-                eb = lo;
-            }
-            const int r = eb >> 1;
-            const bool onA = (eb & 1) == 0;
-            const int pna = L.pl_na[r], pnb = L.pl_nb[r];
-            int fidx = t - (int)L.pl_off[eb];
-            const bool tv = (fidx >= 0) && (fidx < (onA ? pna : pnb));
-            unsigned long long skey = 0ull;
-            int jm = 0;
-            if (tv) {
-                const int psa = L.pl_sa[r], psb = L.pl_sb[r];
-                const int pbody = onA ? psa : psb, qbody = onA ? psb : psa;
-                const int f = fidx;
-                const int nq = onA ? pnb : pna;
-                const d2 fn = E.wn[pbody * BP_MAXV + f], fp = E.wv[pbody * BP_MAXV + f];
-                double mn = BP_INF;
-#pragma unroll 10
-                for (int q = 0; q < VL; q++) { // slots >= nq repeat vertex 0, which cannot win the strict '<'
-                    const double d = vdot(fn, E.wv[qbody * BP_MAXV + (q < nq ? q : 0)]);
-                    if (d < mn) { mn = d; jm = q; }
-                }
-                const double sp = (mn - vdot(fn, fp)) + 0.0; // "+ 0.0": -0 and +0 share one key
-                skey = f64_key(sp);
-                fidx = f;
-                atomicMax(onA ? &L.res_smA[r] : &L.res_smB[r], skey);
-            }
-            lds_sync();
-            bool isbest = false;
-            if (tv) {
-                isbest = (skey == (onA ? L.res_smA[r] : L.res_smB[r]));
-                if (isbest) atomicMin(onA ? &L.res_iA[r] : &L.res_iB[r], (unsigned)fidx); // ties -> lowest plane index
-            }
-            lds_sync();
-            if (isbest && (unsigned)fidx == (onA ? L.res_iA[r] : L.res_iB[r])) { if (onA) L.res_jA[r] = (unsigned)jm; else L.res_jB[r] = (unsigned)jm; }
-        }
-        lds_sync();
         PROF_ACC(3)
         // ---- 4b. closest features -> normal -> Chipmunk ContactPoints, one pair per lane ------------------------------
         Manifold M;
-        M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0); M.newhint = 255;
+        M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0);
         M.p1_0 = M.p2_0 = M.p1_1 = M.p2_1 = mk2(0, 0);
+        bool touching = false;
+        int src = 2; // where the normal comes from: 0 = plane iA of A, 1 = plane iB of B (negated), 2 = a vertex pair
+        d2 n = mk2(0, 0);
+        int iA = 0, iB = 0, jA = 0, jB = 0;
+        const int nA = nA_l, nB = nB_l;
+        const d2 *Av = E.wv + sa * BP_MAXV, *An = E.wn + sa * BP_MAXV, *Bv = E.wv + sb * BP_MAXV, *Bn = E.wn + sb * BP_MAXV;
         if (valid) {
-            const int nA = nA_l, nB = nB_l;
-            const d2 *Av = E.wv + sa * BP_MAXV, *An = E.wn + sa * BP_MAXV, *Bv = E.wv + sb * BP_MAXV, *Bn = E.wn + sb * BP_MAXV;
             const double sA = key_f64(L.res_smA[myr]), sB = key_f64(L.res_smB[myr]);
-            const int iA = (int)L.res_iA[myr], iB = (int)L.res_iB[myr], jA = (int)L.res_jA[myr], jB = (int)L.res_jB[myr];
+            iA = (int)L.res_iA[myr]; iB = (int)L.res_iB[myr]; jA = (int)L.res_jA[myr]; jB = (int)L.res_jB[myr];
             const bool useA = (sA >= sB);
             const double smax = useA ? sA : sB;
-            bool touching = true;
-            d2 n = mk2(0, 0);
+            touching = true;
             // every vertex / normal the three cases below can need is fetched up front: one round trip instead of a dependent chain
             const int iA0 = (iA == 0) ? nA - 1 : iA - 1, iB0 = (iB == 0) ? nB - 1 : iB - 1;
             const d2 nAi = An[iA], nBi = Bn[iB];
             const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
             const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
-            if (smax > rsum) { M.newhint = useA ? iA : (nA + iB); touching = false; }
-            else if (smax <= 0.0) { n = useA ? nAi : vneg(nBi); }
+            if (smax > rsum) touching = false;
+            else if (smax <= 0.0) { n = useA ? nAi : vneg(nBi); src = useA ? 0 : 1; }
             else {
                 const d2 eA = vsub(bA, aA);
                 const double uA = vdot(vsub(qA, aA), eA), eeA = vdot(eA, eA);
@@ -478,8 +575,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
                 const bool spanB = !(uB < 0.0) && !(uB > eeB);
                 if (useA) {
-                    if (spanA) n = nAi;
-                    else if (sB > 0.0 && spanB) n = vneg(nBi);
+                    if (spanA) { n = nAi; src = 0; }
+                    else if (sB > 0.0 && spanB) { n = vneg(nBi); src = 1; }
                     else {
                         const d2 pp = vsub(qA, (uA < 0.0) ? aA : bA);
                         const double dl = vlen(pp);
@@ -487,8 +584,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         n = vmul(pp, 1.0 / (dl + BP_DBL_MIN));
                     }
                 } else {
-                    if (spanB) n = vneg(nBi);
-                    else if (sA > 0.0 && spanA) n = nAi;
+                    if (spanB) { n = vneg(nBi); src = 1; }
+                    else if (sA > 0.0 && spanA) { n = nAi; src = 0; }
                     else {
                         const d2 pp = vsub((uB < 0.0) ? aB : bB, qB);
                         const double dl = vlen(pp);
@@ -497,60 +594,70 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     }
                 }
             }
-            if (touching) {
-                const d2 nn = vneg(n);
-                // support vertices (PolySupportPointIndex): first maximum of v . n
-                int i1A = 0, i1B = 0;
-                {
-                    double mx = -BP_INF;
-#pragma unroll 10
-                    for (int q = 0; q < VL; q++) { // slots >= nA repeat vertex 0: equal, cannot win the strict '>'
-                        const double d = vdot(Av[q < nA ? q : 0], n);
-                        if (d > mx) { mx = d; i1A = q; }
-                    }
-                    mx = -BP_INF;
-#pragma unroll 10
-                    for (int q = 0; q < VL; q++) {
-                        const double d = vdot(Bv[q < nB ? q : 0], nn);
-                        if (d > mx) { mx = d; i1B = q; }
-                    }
-                }
-                d2 e1a, e1b, e2a, e2b;
-                int e1ia, e1ib, e2ia, e2ib;
-                {
-                    const int i0 = (i1A == 0) ? nA - 1 : i1A - 1, i2 = (i1A + 1 == nA) ? 0 : i1A + 1;
-                    if (vdot(n, An[i1A]) > vdot(n, An[i2])) { e1a = Av[i0]; e1ia = i0; e1b = Av[i1A]; e1ib = i1A; }
-                    else { e1a = Av[i1A]; e1ia = i1A; e1b = Av[i2]; e1ib = i2; }
-                }
-                {
-                    const int i0 = (i1B == 0) ? nB - 1 : i1B - 1, i2 = (i1B + 1 == nB) ? 0 : i1B + 1;
-                    if (vdot(nn, Bn[i1B]) > vdot(nn, Bn[i2])) { e2a = Bv[i0]; e2ia = i0; e2b = Bv[i1B]; e2ib = i1B; }
-                    else { e2a = Bv[i1B]; e2ia = i1B; e2b = Bv[i2]; e2ib = i2; }
-                }
-                const double r1 = E.prop[sa].x, r2 = E.prop[sb].x;
-                const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
-                const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
-                const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
-                const double e2_denom = 1.0 / (d_e2_b - d_e2_a + BP_DBL_MIN);
-                M.n = n;
-                {
-                    const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_b - d_e1_a) * e1_denom)));
-                    const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_a - d_e2_a) * e2_denom)));
-                    const double dist = vdot(vsub(p2, p1), n);
-                    if (dist <= 0.0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = ((unsigned)e1ia << 8) | (unsigned)e2ib; M.count = 1; }
-                }
-                {
-                    const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_a - d_e1_a) * e1_denom)));
-                    const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_b - d_e2_a) * e2_denom)));
-                    const double dist = vdot(vsub(p2, p1), n);
-                    if (dist <= 0.0) {
-                        const unsigned h = ((unsigned)e1ib << 8) | (unsigned)e2ia;
-                        if (M.count == 0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = h; M.count = 1; }
-                        else { M.p1_1 = p1; M.p2_1 = p2; M.h1 = h; M.count = 2; }
-                    }
+            // the winners of both sides are the next sub-step's cached planes
+            E.hint[i * BP_KADJ + s] = (unsigned short)((unsigned)iA | ((unsigned)iB << 5) | HW_HAS_A | HW_HAS_B | (useA ? 0u : HW_PRIM_B) |
+                                                       ((smax > rsum) ? 0u : HW_BOTH));
+        }
+        PROF_ACC(31)
+        // support vertices (PolySupportPointIndex: first maximum of v . n over A, of v . -n over B).  With the normal of plane iA, v . -n over B is
+        // the negated sequence whose first minimum the plane search has already found (jA); likewise jB for a normal from B.  The other one is a
+        // support query in direction -n over A (n over B), whose first minimum is the first maximum wanted.
+        int i1A = jB, i1B = jA;
+        {
+            const bool needA = touching && src != 1, needB = touching && src != 0;
+            const unsigned long long mA = ballot(needA), mB = ballot(needB);
+            const int nqa = __popcll(mA), nq2 = nqa + __popcll(mB);
+            PROF_CNT(39, nq2)
+            const int slA = popc_below(mA, lane), slB = nqa + popc_below(mB, lane);
+            for (int q0 = 0; q0 < nq2; q0 += BP_QCAP) {
+                const bool inA = needA && slA >= q0 && slA < q0 + BP_QCAP, inB = needB && slB >= q0 && slB < q0 + BP_QCAP;
+                if (inA) { L.q_dir[slA - q0] = vneg(n); L.q_meta[slA - q0] = (unsigned)sa | ((unsigned)nA << 16); }
+                if (inB) { L.q_dir[slB - q0] = n; L.q_meta[slB - q0] = (unsigned)sb | ((unsigned)nB << 16); }
+                lds_sync();
+                support_queries<VL>(E, L, min(nq2 - q0, BP_QCAP));
+                lds_sync();
+                if (inA) i1A = (int)L.r_idx[slA - q0];
+                if (inB) i1B = (int)L.r_idx[slB - q0];
+                lds_sync();
+            }
+        }
+        PROF_ACC(32)
+        if (touching) {
+            const d2 nn = vneg(n);
+            d2 e1a, e1b, e2a, e2b;
+            int e1ia, e1ib, e2ia, e2ib;
+            {
+                const int i0 = (i1A == 0) ? nA - 1 : i1A - 1, i2 = (i1A + 1 == nA) ? 0 : i1A + 1;
+                if (vdot(n, An[i1A]) > vdot(n, An[i2])) { e1a = Av[i0]; e1ia = i0; e1b = Av[i1A]; e1ib = i1A; }
+                else { e1a = Av[i1A]; e1ia = i1A; e1b = Av[i2]; e1ib = i2; }
+            }
+            {
+                const int i0 = (i1B == 0) ? nB - 1 : i1B - 1, i2 = (i1B + 1 == nB) ? 0 : i1B + 1;
+                if (vdot(nn, Bn[i1B]) > vdot(nn, Bn[i2])) { e2a = Bv[i0]; e2ia = i0; e2b = Bv[i1B]; e2ib = i1B; }
+                else { e2a = Bv[i1B]; e2ia = i1B; e2b = Bv[i2]; e2ib = i2; }
+            }
+            const double r1 = E.prop[sa].x, r2 = E.prop[sb].x;
+            const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
+            const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
+            const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
+            const double e2_denom = 1.0 / (d_e2_b - d_e2_a + BP_DBL_MIN);
+            M.n = n;
+            {
+                const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_b - d_e1_a) * e1_denom)));
+                const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_a - d_e2_a) * e2_denom)));
+                const double dist = vdot(vsub(p2, p1), n);
+                if (dist <= 0.0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = ((unsigned)e1ia << 8) | (unsigned)e2ib; M.count = 1; }
+            }
+            {
+                const d2 p1 = vadd(vmul(n, r1), vlerp(e1a, e1b, clamp01((d_e2_a - d_e1_a) * e1_denom)));
+                const d2 p2 = vadd(vmul(n, -r2), vlerp(e2a, e2b, clamp01((d_e1_b - d_e2_a) * e2_denom)));
+                const double dist = vdot(vsub(p2, p1), n);
+                if (dist <= 0.0) {
+                    const unsigned h = ((unsigned)e1ib << 8) | (unsigned)e2ia;
+                    if (M.count == 0) { M.p1_0 = p1; M.p2_0 = p2; M.h0 = h; M.count = 1; }
+                    else { M.p1_1 = p1; M.p2_1 = p2; M.h1 = h; M.count = 2; }
                 }
             }
-            E.hint[i * BP_KADJ + s] = (unsigned char)M.newhint;
         }
         PROF_ACC(10)
         if (KIND == BP_ENV_BOX) {

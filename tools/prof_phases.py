@@ -14,12 +14,13 @@ STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 trials = default_trials(0.3, 100, base_seed=0)
 env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
 env.reset()
-prof = torch.zeros((E, 24), dtype=torch.int64, device=env.device)
+prof = torch.zeros((E, 48), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 names = ["integrate", "refresh", "cand+hint", "face_seps", "deliver", "filter", "prestep+warmset", "velint+warm", "solver", "post+mvlist", "manifolds"]
 for t in range(STEPS):
     a = (torch.rand(E, generator=g, device=env.device, dtype=torch.float64) * 2 - 1).float().double()
+    prof.zero_()
     _, _, term, _, _ = env.step(a)
     torch.cuda.synchronize()
     p = prof.cpu().numpy().astype(np.float64)
@@ -32,4 +33,8 @@ for t in range(STEPS):
             print("        cycles per sub-step: " + " ".join("%s=%.0f" % (n, row[i] / 400) for i, n in enumerate(names)) + " total=%.0f" % (row[23] / 400))
             print("        per-substep: nmv=%.2f refresh=%.3f fullpairs=%.2f nact=%.2f levels=%.2f nwarm=%.2f" % (
                 row[16] / 400, row[17] / 400, row[18] / 400, row[19] / 400, row[20] / 400, row[21] / 400))
+            print("        narrow-phase stages, cycles per sub-step: " + " ".join("%s=%.0f" % (n, row[k] / 400) for n, k in (
+                ("pose", 33), ("transform", 34), ("aabb", 0), ("drain", 35), ("candidates", 27), ("cached_planes", 28), ("bound_rounds", 29), ("plane_search+resolve", 30), ("normal", 31), ("support", 32))))
+            print("        per-substep: cand_rounds=%.2f rounds_with_pairs=%.2f aabb_pairs=%.2f cached_plane_queries=%.2f search_batches=%.2f searched_planes=%.2f "
+                  "support_queries=%.2f" % tuple(row[k] / 400 for k in (24, 25, 36, 37, 26, 38, 39)))
     env.reset(term)
