@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
                 if (lane == 0) {
                     E.pxy[body] = mk2(nx, ny);
                     const int sl = L.slot_of[body];
-                    if (sl != 255) L.sv[sl] = mk2(0.0, 0.0);
+                    if (sl != 255) { L.sv[sl] = mk2(0.0, 0.0); L.sp[sl] = mk2(nx, ny); }
                 }
                 // make sure the body is re-cached by the next sub-step
                 bool present = false;

@@ -91,7 +91,7 @@ static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
 #else
 #define BP_PROF_HOST false
 #endif
-static size_t lds_bytes_for(int nbcap) { return bp_lds_map(nbcap, mvcap_for(nbcap), true, BP_PROF_HOST).total; }
+static size_t lds_bytes_for(int nbcap, bool box) { return bp_lds_map(nbcap, mvcap_for(nbcap), box, BP_PROF_HOST).total; }
 
 extern "C" {
 
@@ -191,7 +191,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     h->P.nbcap = nbcap;
     h->P.mvcap = mvcap_for(nbcap);
     h->P.num_trials = T;
-    h->lds_bytes = lds_bytes_for(nbcap);
+    h->lds_bytes = lds_bytes_for(nbcap, h->P.env_kind == BP_ENV_BOX);
     if (h->lds_bytes > 160 * 1024) return fail(h, BP_EINVAL, "nb_cap too large for LDS");
 
     std::vector<int> h_nb(T), h_nv((size_t)T * nbcap, 0), h_kind((size_t)T * nbcap, 0);

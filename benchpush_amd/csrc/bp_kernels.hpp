@@ -41,7 +41,7 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
 {
     const LdsMap m = bp_lds_map(P.nbcap, P.mvcap, KIND == BP_ENV_BOX, BP_PROF_ON);
     char *b = (char *)bp_smem;
-    L.sv = (d2 *)(b + m.sv); L.sw = (d2 *)(b + m.sw); L.sb = (d2 *)(b + m.sb);
+    L.sv = (d2 *)(b + m.sv); L.sw = (d2 *)(b + m.sw); L.sb = (d2 *)(b + m.sb); L.sp = (d2 *)(b + m.sp);
     L.tf = (d2 *)(b + m.tf);
     L.q_dir = (d2 *)(b + m.q_dir); L.q_c = (double *)(b + m.q_c); L.r_val = (double *)(b + m.r_val);
     L.q_meta = (unsigned *)(b + m.q_meta); L.q_aux = (unsigned *)(b + m.q_aux); L.r_idx = (unsigned *)(b + m.r_idx);
@@ -103,7 +103,7 @@ __device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &
         const int i = base + lane;
         if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     }
-    if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; }
+    if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; L.sp[lane] = E.pxy[lane]; }
     S.nslots = P.nkin;
     S.wall_flag = (P.env_kind == BP_ENV_MAZE) ? (D.e_flags[env] & 1) : 0;
     const size_t ab = (size_t)env * BP_ACAP + lane;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void load_state_b(const DevParams &P, const DevPtrs &
             int sl = S.nslots + popc_below(ms, lane);
             if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
             L.slot_of[i] = (unsigned char)sl;
-            L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb;
+            L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb; L.sp[sl] = E.pxy[i];
         }
         n += __popcll(m);
         S.nslots = min(S.nslots + __popcll(ms), BP_NSLOT);
@@ -167,7 +167,7 @@ __device__ __forceinline__ void load_state_b(const DevParams &P, const DevPtrs &
             const int l = __ffsll((long long)m) - 1;
             m &= m - 1;
             const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
-            const int s1 = slot_get(L, S, (int)(key >> 16)), s2 = slot_get(L, S, (int)(key & 0xFFFFu));
+            const int s1 = slot_get(L, S, E.pxy, (int)(key >> 16)), s2 = slot_get(L, S, E.pxy, (int)(key & 0xFFFFu));
             if (lane == l) { A.slotA = s1; A.slotB = s2; }
         }
     }
@@ -321,6 +321,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                     double sn, cs;
                     bp_sincos(ps.z, sn, cs);
                     E.pxy[i] = mk2(ps.x, ps.y); E.ang[i] = ps.z; E.rot[i] = mk2(cs, sn);
+                    if (i < P.nkin) L.sp[i] = mk2(ps.x, ps.y);
                     E.adjn[i] = 0;
                 }
             }
@@ -630,7 +631,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
 }
 
 // env.step(): 400 sub-steps + work / reward / termination
-__global__ __launch_bounds__(64) void k_physics_step(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+__global__ __launch_bounds__(64, 2) void k_physics_step(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                      double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                      unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
@@ -697,38 +698,38 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         else sq_push(P, D, x, lev_out, item);
     }
 }
-__global__ __launch_bounds__(64) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+__global__ __launch_bounds__(64, 2) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     sched_body<0>(P, D, actions, reward, terminated, truncated, info);
 }
-__global__ __launch_bounds__(64) void k_physics_step_sched_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+__global__ __launch_bounds__(64, 2) void k_physics_step_sched_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                                 double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                                 unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     sched_body<BP_ENV_MAZE>(P, D, actions, reward, terminated, truncated, info);
 }
 // reset() of the masked envs: new space from the next trial + 1000 settle sub-steps
-__global__ __launch_bounds__(64) void k_physics_reset(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+__global__ __launch_bounds__(64, 2) void k_physics_reset(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                       double *__restrict__ info, const int tmpl)
 {
     physics_body<MODE_RESET, 0>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
 }
 // maze-NAMO-v0 instantiations (vertex loops of 8)
-__global__ __launch_bounds__(64) void k_physics_step_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+__global__ __launch_bounds__(64, 2) void k_physics_step_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                           double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     physics_body<MODE_STEP, BP_ENV_MAZE>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
 }
-__global__ __launch_bounds__(64) void k_physics_reset_maze(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+__global__ __launch_bounds__(64, 2) void k_physics_reset_maze(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                            double *__restrict__ info, const int tmpl)
 {
     physics_body<MODE_RESET, BP_ENV_MAZE>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
 }
 // box-delivery: new space + 1000 settle sub-steps with the boundary handlers (box_delivery_env.py:239-285)
-__global__ __launch_bounds__(64) void k_bd_settle(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+__global__ __launch_bounds__(64, 2) void k_bd_settle(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
                                                   double *__restrict__ info, const int tmpl)
 {
     physics_body<MODE_RESET, BP_ENV_BOX>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);

@@ -63,10 +63,11 @@ struct EnvCtx {
 
 struct LdsCtx {
     d2 *sv, *sw, *sb;          // [BP_NSLOT] (vx,vy) (w,w_bias) (vbx,vby) of the bodies that hold a velocity slot
+    d2 *sp;                    // [BP_NSLOT] their positions (copy of E.pxy, kept current by whoever moves the body)
     unsigned char *slot_of;    // [nbcap] velocity slot of a body, 255 = none (velocity is exactly zero)
     unsigned *mvs;             // [nbcap] stamp of the sub-step in which the body last moved
-    unsigned short *owner;     // [nbcap]
-    unsigned short *colmask;   // [nbcap] colours already used at a body (solve-order colouring)
+    unsigned short *owner;     // [BP_NSLOT] per velocity slot: scratch of the warm-set closure and of the moving-list arbitration
+    unsigned short *colmask;   // [BP_NSLOT] colours already used at the body of a slot (solve-order colouring)
     d2 *tf;                    // [64][2] (cos, sin) (tx, ty) of the moving bodies of the current chunk
     unsigned short *mv;        // [P.mvcap] moving-body list
     unsigned char *rf;         // [64] refresh flags of the current chunk
@@ -112,7 +113,7 @@ struct SubState {
 };
 
 // Velocity slot of `body` (wave-uniform call): allocate a zeroed one on first use.  Slot 0 is the ship.
-__device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, int body)
+__device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, const d2 *pxy, int body)
 {
     int s = L.slot_of[body];
     if (BP_UNLIKELY(s == 255)) {
@@ -122,6 +123,7 @@ __device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, int body)
         if (lane_id() == 0) {
             L.slot_of[body] = (unsigned char)s;
             L.sv[s] = mk2(0.0, 0.0); L.sw[s] = mk2(0.0, 0.0); L.sb[s] = mk2(0.0, 0.0);
+            L.sp[s] = pxy[body];
         }
         lds_sync();
     }
@@ -277,21 +279,28 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     // ---- 1. integrate positions of the moving bodies; world geometry; AABBs ----------------------------------
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {
         const int k = k0 + lane;
+        // everything the lane's body needs in this phase is requested together: pose, mass / centre of gravity, radius, fat AABB, vertex count
+        double rad = 0.0;
+        double4 fatb; fatb.x = fatb.y = -BP_INF; fatb.z = fatb.w = BP_INF;
         if (k < S.nmv) {
             const int i = L.mv[k];
             const int sl = L.slot_of[i];
             d2 v = mk2(0.0, 0.0), w2 = mk2(0.0, 0.0), vb = mk2(0.0, 0.0);
             if (sl != 255) { v = L.sv[sl]; w2 = L.sw[sl]; vb = L.sb[sl]; }
             d2 p = E.pxy[i];
+            if (sl != 255) p = L.sp[sl];
+            const double a = E.ang[i];
+            d2 r = E.rot[i];
+            const double4 ms = E.mass[i];
+            rad = E.prop[i].x;
+            fatb = E.fat[i];
+            L.rf[lane] = (unsigned char)E.nv[i];
             p.x = p.x + (v.x + vb.x) * dt;
             p.y = p.y + (v.y + vb.y) * dt;
-            const double a = E.ang[i];
             const double a2 = a + (w2.x + w2.y) * dt;
-            d2 r = E.rot[i];
             if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
             E.pxy[i] = p; E.ang[i] = a2; E.rot[i] = r;
-            if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(w2.x, 0.0); }
-            const double4 ms = E.mass[i];
+            if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(w2.x, 0.0); L.sp[sl] = p; }
             double4 t;
             t.x = r.x; t.y = r.y;
             t.z = p.x - (ms.z * r.x - ms.w * r.y);
@@ -300,20 +309,19 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             L.tf[2 * lane + 1] = mk2(t.z, t.w);
             L.mvs[i] = now;
         }
-        lds_sync();
-        PROF_ACC(33)
         const int cnt = min(64, S.nmv - k0);
         // world vertices / normals, one (body, vertex) item per lane; AABB through LDS atomic min/max on order-preserving
         // keys (min and max are exact, so the reduction order is irrelevant).  bbk aliases the narrow-phase scratch.
         unsigned long long *bbk = L.res_smA; // [64][4] = min x, max x, min y, max y
         if (lane < cnt) { bbk[lane * 4 + 0] = ~0ull; bbk[lane * 4 + 1] = 0ull; bbk[lane * 4 + 2] = ~0ull; bbk[lane * 4 + 3] = 0ull; }
         lds_sync();
+        PROF_ACC(33)
         for (int t0 = 0; t0 < cnt * VL; t0 += 64) {
             const int t = t0 + lane;
             const int kk = t / VL, q = t - kk * VL;
             if (kk < cnt) {
                 const int i = L.mv[k0 + kk];
-                if (q < E.nv[i]) {
+                if (q < (int)L.rf[kk]) {
                     const d2 t0_ = L.tf[2 * kk], t1_ = L.tf[2 * kk + 1];
                     const double c = t0_.x, s = t0_.y;
                     const d2 lv = E.lv[i * BP_MAXV + q], ln = E.ln[i * BP_MAXV + q];
@@ -331,20 +339,18 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         lds_sync();
         PROF_ACC(34)
+        bool leftfat = false;
         if (lane < cnt) {
             const int i = L.mv[k0 + lane];
-            const double rad = E.prop[i].x;
             double4 nbb;
             nbb.x = key_f64(bbk[lane * 4 + 0]) - rad; nbb.y = key_f64(bbk[lane * 4 + 2]) - rad;
             nbb.z = key_f64(bbk[lane * 4 + 1]) + rad; nbb.w = key_f64(bbk[lane * 4 + 3]) + rad;
             E.bb[i] = nbb;
-            const double4 f = E.fat[i];
-            L.rf[lane] = !(nbb.x >= f.x && nbb.y >= f.y && nbb.z <= f.z && nbb.w <= f.w);
+            leftfat = !(nbb.x >= fatb.x && nbb.y >= fatb.y && nbb.z <= fatb.z && nbb.w <= fatb.w);
         }
-        lds_sync();
         PROF_ACC(0)
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
-        unsigned long long rm = ballot((lane < cnt) && L.rf[lane < cnt ? lane : 0]);
+        unsigned long long rm = ballot(leftfat);
         if (BP_UNLIKELY(rm != 0)) __syncthreads(); // refresh_body reads the AABBs other lanes have just stored
         while (BP_UNLIKELY(rm != 0)) {
             const int kk = __ffsll((long long)rm) - 1;
@@ -385,8 +391,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const int ki = E.kind[i], kj = E.kind[j];
         const double mi = E.mass[i].x, mj = E.mass[j].x;
         const int sa = min(i, j), sb = max(i, j);
-        const double rsum = E.prop[sa].x + E.prop[sb].x;
+        const double radA = E.prop[sa].x, radB = E.prop[sb].x;
+        const double rsum = radA + radB;
         const int nA_h = E.nv[sa], nB_h = E.nv[sb];
+        // the cached planes (hint word) of both sides travel with this round trip too: plane indices only need to be valid addresses here
+        const int hA = HW_PLANE_A(hw) < BP_MAXV ? HW_PLANE_A(hw) : 0, hB = HW_PLANE_B(hw) < BP_MAXV ? HW_PLANE_B(hw) : 0;
+        const d2 fnA = E.wn[sa * BP_MAXV + hA], fpA = E.wv[sa * BP_MAXV + hA];
+        const d2 fnB = E.wn[sb * BP_MAXV + hB], fpB = E.wv[sb * BP_MAXV + hB];
         bool flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
         if (valid) {
             if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
@@ -405,7 +416,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         //      shape's vertices, found by eight lanes per plane).  Any plane's separation is a lower bound of the pair's maximum, so a cached plane
         //      that clears the radii rejects the pair (cpCollide would find no contact).  Pairs that were rejected last time test only the plane
         //      that rejected them; pairs that got through test the cached plane of both sides.
-        const int hA = min(HW_PLANE_A(hw), nA_h - 1), hB = min(HW_PLANE_B(hw), nB_h - 1);
         const bool evA = valid && (hw & HW_HAS_A) && ((hw & HW_BOTH) || !(hw & HW_PRIM_B));
         const bool evB = valid && (hw & HW_HAS_B) && ((hw & HW_BOTH) || (hw & HW_PRIM_B));
         double sepAc = -BP_INF, sepBc = -BP_INF;
@@ -416,8 +426,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             PROF_CNT(37, nq1)
             if (nq1) {
                 const int slA = popc_below(mqA, lane), slB = nqA + popc_below(mqB, lane);
-                const d2 fnA = E.wn[sa * BP_MAXV + hA], fpA = E.wv[sa * BP_MAXV + hA];
-                const d2 fnB = E.wn[sb * BP_MAXV + hB], fpB = E.wv[sb * BP_MAXV + hB];
                 const double cA = vdot(fnA, fpA), cB = vdot(fnB, fpB);
                 for (int q0 = 0; q0 < nq1; q0 += BP_QCAP) { // one batch unless more than BP_QCAP planes are cached in this round
                     const bool inA = evA && slA >= q0 && slA < q0 + BP_QCAP, inB = evB && slB >= q0 && slB < q0 + BP_QCAP;
@@ -462,7 +470,67 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         {
             int nq = 0, g0 = 0; // queries collected, first pair rank of the current group
             const int side = lane >> 5, f = lane & 31;
-            for (int rr = 0; rr <= nc; rr++) {
+            // One bound round: lanes 0..31 = planes of A, 32..63 = planes of B of the pair with rank rr.
+            auto round_addr = [&](const uint4 pa, int &pbody, int &qbody, int &np, int &nqv, int &hX, bool &evX, int &jc) {
+                const int psa = (int)(pa.x & 0xFFFFu), psb = (int)(pa.x >> 16);
+                const int pna = (int)(pa.y & 0xFFu), pnb = (int)((pa.y >> 8) & 0xFFu);
+                pbody = side ? psb : psa; qbody = side ? psa : psb;
+                np = side ? pnb : pna; nqv = side ? pna : pnb;
+                hX = (int)((pa.y >> (side ? 24 : 16)) & 0xFFu);
+                evX = ((pa.z >> side) & 1u) != 0;
+                jc = (int)((pa.z >> (side ? 16 : 8)) & 0xFFu);
+            };
+            // Fast path: the rounds are taken two at a time so that their loads travel together; the surviving planes go straight into the query
+            // buffer.  If they do not all fit (rare: pairs without cached planes), the sequential loop below redoes the rounds group by group.
+            int rr_start = nc;
+            {
+                bool fits = true;
+                for (int r0 = 0; r0 < nc && fits; r0 += 2) {
+                    const bool two = r0 + 1 < nc;
+                    const uint4 pa0 = L.pt_a[r0], pa1 = L.pt_a[two ? r0 + 1 : r0];
+                    const d2 thr0 = L.pt_thr[r0], thr1 = L.pt_thr[two ? r0 + 1 : r0];
+                    int pb0, qb0, np0, nqv0, hX0, jc0, pb1, qb1, np1, nqv1, hX1, jc1; bool ev0, ev1;
+                    round_addr(pa0, pb0, qb0, np0, nqv0, hX0, ev0, jc0);
+                    round_addr(pa1, pb1, qb1, np1, nqv1, hX1, ev1, jc1);
+                    const int fc0 = (f < np0) ? f : 0, fc1 = (f < np1) ? f : 0;
+                    const d2 fn0 = E.wn[pb0 * BP_MAXV + fc0], fp0 = E.wv[pb0 * BP_MAXV + fc0], vb0 = E.wv[qb0 * BP_MAXV + jc0];
+                    const d2 fn1 = E.wn[pb1 * BP_MAXV + fc1], fp1 = E.wv[pb1 * BP_MAXV + fc1], vb1 = E.wv[qb1 * BP_MAXV + jc1];
+                    {
+                        const double th = side ? thr0.y : thr0.x;
+                        const bool pv = (f < np0) && !(ev0 && f == hX0);
+                        const double c = vdot(fn0, fp0);
+                        const double bound = (vdot(fn0, vb0) - c) + 0.0;
+                        const bool surv = pv && (!ev0 || bound >= th);
+                        const unsigned long long sm = ballot(surv);
+                        const int sl = nq + popc_below(sm, lane);
+                        if (surv && sl < BP_QCAP) {
+                            L.q_dir[sl] = fn0; L.q_meta[sl] = (unsigned)qb0 | ((unsigned)nqv0 << 16);
+                            L.q_aux[sl] = (unsigned)r0 | ((unsigned)side << 8) | ((unsigned)f << 16);
+                            L.q_c[sl] = c;
+                        }
+                        nq += __popcll(sm);
+                    }
+                    {
+                        const double th = side ? thr1.y : thr1.x;
+                        const bool pv = two && (f < np1) && !(ev1 && f == hX1);
+                        const double c = vdot(fn1, fp1);
+                        const double bound = (vdot(fn1, vb1) - c) + 0.0;
+                        const bool surv = pv && (!ev1 || bound >= th);
+                        const unsigned long long sm = ballot(surv);
+                        const int sl = nq + popc_below(sm, lane);
+                        if (surv && sl < BP_QCAP) {
+                            L.q_dir[sl] = fn1; L.q_meta[sl] = (unsigned)qb1 | ((unsigned)nqv1 << 16);
+                            L.q_aux[sl] = (unsigned)(r0 + 1) | ((unsigned)side << 8) | ((unsigned)f << 16);
+                            L.q_c[sl] = c;
+                        }
+                        nq += __popcll(sm);
+                    }
+                    fits = nq <= BP_QCAP;
+                }
+                if (!fits) { nq = 0; rr_start = 0; }
+                lds_sync();
+            }
+            for (int rr = rr_start; rr <= nc; rr++) {
                 // the queries collected so far are searched when the next round might not fit, and after the last pair
                 if (nq > 0 && (rr == nc || nq + 64 > BP_QCAP)) {
                     PROF_ACC(29)
@@ -517,13 +585,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (rr == nc) break;
                 const uint4 pa = L.pt_a[rr];
                 const d2 thr = L.pt_thr[rr];
-                const int psa = (int)(pa.x & 0xFFFFu), psb = (int)(pa.x >> 16);
-                const int pna = (int)(pa.y & 0xFFu), pnb = (int)((pa.y >> 8) & 0xFFu);
-                const int pbody = side ? psb : psa, qbody = side ? psa : psb;
-                const int np = side ? pnb : pna, nqv = side ? pna : pnb;
-                const int hX = (int)((pa.y >> (side ? 24 : 16)) & 0xFFu);
-                const bool evX = ((pa.z >> side) & 1u) != 0;
-                const int jc = (int)((pa.z >> (side ? 16 : 8)) & 0xFFu);
+                int pbody, qbody, np, nqv, hX, jc; bool evX;
+                round_addr(pa, pbody, qbody, np, nqv, hX, evX, jc);
                 const double th = side ? thr.y : thr.x;
                 const bool pv = (f < np) && !(evX && f == hX);
                 const int fc = (f < np) ? f : 0;
@@ -626,17 +689,17 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const d2 nn = vneg(n);
             d2 e1a, e1b, e2a, e2b;
             int e1ia, e1ib, e2ia, e2ib;
-            {
-                const int i0 = (i1A == 0) ? nA - 1 : i1A - 1, i2 = (i1A + 1 == nA) ? 0 : i1A + 1;
-                if (vdot(n, An[i1A]) > vdot(n, An[i2])) { e1a = Av[i0]; e1ia = i0; e1b = Av[i1A]; e1ib = i1A; }
-                else { e1a = Av[i1A]; e1ia = i1A; e1b = Av[i2]; e1ib = i2; }
+            {   // both candidate edges of each shape are fetched together, then selected
+                const int a0 = (i1A == 0) ? nA - 1 : i1A - 1, a2 = (i1A + 1 == nA) ? 0 : i1A + 1;
+                const int b0 = (i1B == 0) ? nB - 1 : i1B - 1, b2 = (i1B + 1 == nB) ? 0 : i1B + 1;
+                const d2 nA1 = An[i1A], nA2 = An[a2], vA0 = Av[a0], vA1 = Av[i1A], vA2 = Av[a2];
+                const d2 nB1 = Bn[i1B], nB2 = Bn[b2], vB0 = Bv[b0], vB1 = Bv[i1B], vB2 = Bv[b2];
+                const bool fa = vdot(n, nA1) > vdot(n, nA2);
+                e1a = fa ? vA0 : vA1; e1ia = fa ? a0 : i1A; e1b = fa ? vA1 : vA2; e1ib = fa ? i1A : a2;
+                const bool fb = vdot(nn, nB1) > vdot(nn, nB2);
+                e2a = fb ? vB0 : vB1; e2ia = fb ? b0 : i1B; e2b = fb ? vB1 : vB2; e2ib = fb ? i1B : b2;
             }
-            {
-                const int i0 = (i1B == 0) ? nB - 1 : i1B - 1, i2 = (i1B + 1 == nB) ? 0 : i1B + 1;
-                if (vdot(nn, Bn[i1B]) > vdot(nn, Bn[i2])) { e2a = Bv[i0]; e2ia = i0; e2b = Bv[i1B]; e2ib = i1B; }
-                else { e2a = Bv[i1B]; e2ia = i1B; e2b = Bv[i2]; e2ib = i2; }
-            }
-            const double r1 = E.prop[sa].x, r2 = E.prop[sb].x;
+            const double r1 = radA, r2 = radB;
             const double d_e1_a = vcross(e1a, n), d_e1_b = vcross(e1b, n);
             const double d_e2_a = vcross(e2a, n), d_e2_b = vcross(e2b, n);
             const double e1_denom = 1.0 / (d_e1_b - d_e1_a + BP_DBL_MIN);
@@ -695,35 +758,39 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             bool fresh = false;
             unsigned long long m = dm;
             int dr = 0;
-            while (m) { // slot search / allocation in pair order (wave-uniform)
+            const unsigned keyv = ((unsigned)sa << 16) | (unsigned)sb;
+            while (m) { // every arbiter lane looks for its pair among the delivered ones; a pair nobody owns gets a free slot (rare)
                 const int l = __ffsll((long long)m) - 1;
                 m &= m - 1;
                 if (dr >= dbase && dr < dbase + BP_MBOX) {
-                    const unsigned key = ((unsigned)__builtin_amdgcn_readlane(sa, l) << 16) | (unsigned)__builtin_amdgcn_readlane(sb, l);
-                    unsigned long long om = ballot(A.key == key);
-                    bool fr = false;
-                    if (BP_UNLIKELY2(!om)) { om = ballot(A.key == ARB_FREE_KEY); fr = true; }
-                    if (BP_UNLIKELY2(!om)) { S.err |= BP_ERR_ARB_OVERFLOW; }
-                    else {
-                        const int owner = __ffsll((long long)om) - 1;
-                        int s1 = 0, s2 = 0;
-                        if (BP_UNLIKELY2(fr)) { s1 = slot_get(L, S, (int)(key >> 16)); s2 = slot_get(L, S, (int)(key & 0xFFFFu)); }
-                        if (lane == owner) {
-                            my_mb = dr - dbase; fresh = fr; A.key = key;
-                            if (fr) { A.slotA = s1; A.slotB = s2; }
+                    const unsigned key = (unsigned)__builtin_amdgcn_readlane((int)keyv, l);
+                    const bool own = (A.key == key);
+                    if (BP_UNLIKELY2(!ballot(own))) {
+                        const unsigned long long om = ballot(A.key == ARB_FREE_KEY);
+                        if (!om) S.err |= BP_ERR_ARB_OVERFLOW;
+                        else {
+                            const int owner = __ffsll((long long)om) - 1;
+                            const int s1 = slot_get(L, S, E.pxy, (int)(key >> 16)), s2 = slot_get(L, S, E.pxy, (int)(key & 0xFFFFu));
+                            if (lane == owner) { my_mb = dr - dbase; fresh = true; A.key = key; A.slotA = s1; A.slotB = s2; }
                         }
-                    }
+                    } else if (own) my_mb = dr - dbase;
                 }
                 dr++;
             }
             if (my_mb >= 0) {
                 const d2 *mb = L.mbox + my_mb * 6;
                 const d2 mn_ = mb[0], mp10 = mb[1], mp20 = mb[2], mp11 = mb[3], mp21 = mb[4], mh = mb[5];
+                const d2 pa = L.sp[A.slotA], pbp = L.sp[A.slotB];
                 const unsigned mh0 = (unsigned)__double2hiint(mh.x), mh1 = (unsigned)__double2hiint(mh.y);
                 const int mcount = __double2loint(mh.x);
-                if (fresh) { A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0; }
-                const int usa = (int)(A.key >> 16), usb = (int)(A.key & 0xFFFFu);
-                const d2 pa = E.pxy[usa], pbp = E.pxy[usb];
+                if (BP_UNLIKELY2(fresh)) { // masses and material products of a pair stay with its arbiter
+                    A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0;
+                    const int usa = (int)(A.key >> 16), usb = (int)(A.key & 0xFFFFu);
+                    const double4 m1 = E.mass[usa], m2 = E.mass[usb];
+                    A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
+                    const double4 q1 = E.prop[usa], q2 = E.prop[usb];
+                    A.e = q1.y * q2.y; A.u = q1.z * q2.z;
+                }
                 double njn0 = 0.0, njt0 = 0.0, njn1 = 0.0, njt1 = 0.0;
                 if (A.count > 0 && A.h0 == mh0) { njn0 = A.jn0; njt0 = A.jt0; }
                 if (A.count > 1 && A.h1 == mh0) { njn0 = A.jn1; njt0 = A.jt1; }
@@ -739,10 +806,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 A.n = mn_;
                 if (A.state == ARB_CACHED) A.state = ARB_FIRST;
                 A.stamp = now;
-                const double4 m1 = E.mass[usa], m2 = E.mass[usb];
-                A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
-                const double4 q1 = E.prop[usa], q2 = E.prop[usb];
-                A.e = q1.y * q2.y; A.u = q1.z * q2.z;
             }
             lds_sync();
         }
@@ -775,10 +838,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             if (robot) S.robot_hit = depth < 0;
             __syncthreads(); // all lanes have read pa before it is overwritten
             if (robot) {
-                if (lane < P.nkin) { E.pxy[lane] = pn; L.sv[lane] = nv; }
+                if (lane < P.nkin) { E.pxy[lane] = pn; L.sp[lane] = pn; L.sv[lane] = nv; }
                 if (pn.x != pa.x || pn.y != pa.y) S.evmask |= 1ull;
             } else {
-                if (lane == 0) { E.pxy[a] = pn; if (sl != 255) L.sv[sl] = nv; }
+                if (lane == 0) { E.pxy[a] = pn; if (sl != 255) { L.sv[sl] = nv; L.sp[sl] = pn; } }
                 if (pn.x != pa.x || pn.y != pa.y) S.evmask |= 1ull << a;
             }
             __syncthreads();
@@ -803,7 +866,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     PROF_CNT(20, S.nlevels)
     // ---- 6a. prestep (cpArbiterPreStep) -----------------------------------------------------------------------
     if (active) {
-        const d2 pa = E.pxy[ba], pb = E.pxy[bbi];
+        const d2 pa = L.sp[A.slotA], pb = L.sp[A.slotB];
         const d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
         const double wa = L.sw[A.slotA].x, wb = L.sw[A.slotB].x;
         const d2 n = A.n;
@@ -843,16 +906,16 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         if (A.count > 1) warm = warm || (A.jn1 != 0.0) || (A.jt1 != 0.0) || (A.bias1 != 0.0) || (A.bounce1 != 0.0);
         if (A.ma == 0.0) { const d2 v = L.sv[A.slotA]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotA].x != 0.0); }
         if (A.mb == 0.0) { const d2 v = L.sv[A.slotB]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotB].x != 0.0); }
-        if (A.ma != 0.0) L.owner[ba] = 0;
-        if (A.mb != 0.0) L.owner[bbi] = 0;
+        if (A.ma != 0.0) L.owner[A.slotA] = 0;
+        if (A.mb != 0.0) L.owner[A.slotB] = 0;
     }
     unsigned long long wmask = ballot(warm);
     if (wmask != 0 && wmask != amask) {
         lds_sync();
         for (;;) {
-            if (warm) { if (A.ma != 0.0) L.owner[ba] = 1; if (A.mb != 0.0) L.owner[bbi] = 1; }
+            if (warm) { if (A.ma != 0.0) L.owner[A.slotA] = 1; if (A.mb != 0.0) L.owner[A.slotB] = 1; }
             lds_sync();
-            if (active && !warm) warm = (A.ma != 0.0 && L.owner[ba] != 0) || (A.mb != 0.0 && L.owner[bbi] != 0);
+            if (active && !warm) warm = (A.ma != 0.0 && L.owner[A.slotA] != 0) || (A.mb != 0.0 && L.owner[A.slotB] != 0);
             const unsigned long long nm = ballot(warm);
             if (nm == wmask) break;
             wmask = nm;
@@ -872,17 +935,16 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         A.rank = rank;
         lds_sync();
-        if (active) { L.colmask[ba] = 0; L.colmask[bbi] = 0; }
+        if (active) { L.colmask[A.slotA] = 0; L.colmask[A.slotB] = 0; }
         lds_sync();
         const int nact = __popcll(amask);
         int nlev = 0;
         for (int r = 0; r < nact; r++) {
             const unsigned long long rm = ballot(active && A.rank == r);
             const int l = __ffsll((long long)rm) - 1;
-            const unsigned k = (unsigned)__builtin_amdgcn_readlane((int)A.key, l);
             const bool adyn = __builtin_amdgcn_readlane(__double2hiint(A.ma), l) != 0 || __builtin_amdgcn_readlane(__double2loint(A.ma), l) != 0;
             const bool bdyn = __builtin_amdgcn_readlane(__double2hiint(A.mb), l) != 0 || __builtin_amdgcn_readlane(__double2loint(A.mb), l) != 0;
-            const int a = (int)(k >> 16), b = (int)(k & 0xFFFFu);
+            const int a = __builtin_amdgcn_readlane(A.slotA, l), b = __builtin_amdgcn_readlane(A.slotB, l); // the bodies' slots
             const unsigned ua = adyn ? (unsigned)L.colmask[a] : 0u, ub = bdyn ? (unsigned)L.colmask[b] : 0u;
             const unsigned used = ua | ub;
             int c = __ffs(~used) - 1;
@@ -1078,12 +1140,12 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (A.mb != 0.0 && ((S.evmask >> bbi) & 1ull)) wantB = true;
             }
         }
-        if (wantA) L.owner[ba] = (unsigned short)(lane * 2);
+        if (wantA) L.owner[A.slotA] = (unsigned short)(lane * 2);
         lds_sync();
-        if (wantB) L.owner[bbi] = (unsigned short)(lane * 2 + 1);
+        if (wantB) L.owner[A.slotB] = (unsigned short)(lane * 2 + 1);
         lds_sync();
-        const bool gotA = wantA && L.owner[ba] == (unsigned short)(lane * 2);
-        const bool gotB = wantB && L.owner[bbi] == (unsigned short)(lane * 2 + 1);
+        const bool gotA = wantA && L.owner[A.slotA] == (unsigned short)(lane * 2);
+        const bool gotB = wantB && L.owner[A.slotB] == (unsigned short)(lane * 2 + 1);
         const d2 v0 = L.sv[0], w0 = L.sw[0];
         // every part of the kinematic agent; the box-delivery robot is re-cached every sub-step (its controller rewrites the
         // velocity between sub-steps; re-evaluating an unmoved body reproduces the carried-over result exactly)
