@@ -604,7 +604,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
     if (B.action_type == 2) {
         if (B.task == 1) {
             // area-clearing velocity control (area_clearing.py:660-667): set once; the common sim steps follow
-            const d2 r = E.rot[0];
+            const d2 r = L.ag[1];
             const double sv = B.target_speed * sf[6];
             if (lane < P.nkin) {
                 L.sw[lane] = mk2(B.yaw_rate_step * sf[7] / 2, L.sw[lane].y);
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
 #ifdef BP_PROF
             const unsigned long long _tc0 = __builtin_amdgcn_s_memtime();
 #endif
-            const double prevx = E.pxy[0].x, prevy = E.pxy[0].y, prevh = bd_restrict(E.ang[0]); // pose left by the last sim step
+            const double prevx = L.sp[0].x, prevy = L.sp[0].y, prevh = bd_restrict(L.ag[0].x); // pose left by the last sim step
             const double hd = bd_hdiff(prevh, wp[3 * wi + 2]);
             if (!(__builtin_fabs(hd) > 15 * (BP_PI / 180.0) && __builtin_fabs(hd - prev_hd) > 0.001)) done_turning = true;
             prev_hd = hd; // prev_heading_diff of the next iteration (only read above)
@@ -660,7 +660,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
             _t_ctrl += __builtin_amdgcn_s_memtime() - _tc0;
 #endif
         } else if (phase == PH_VEL) {
-            const d2 r = E.rot[0]; // (cos, sin) of body.angle, refreshed by the previous sim step
+            const d2 r = L.ag[1]; // (cos, sin) of body.angle, refreshed by the previous sim step
             double lin = sf[6];
             const double angv = sf[7];
             if (__builtin_fabs(lin) >= B.target_speed) lin = B.target_speed * (double)((lin > 0) - (lin < 0));
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
             }
             d2 cur = mk2(0.0, 0.0);
             if (lane < nalive) cur = E.pxy[B.first_box + order[lane]];
-            else if (lane == nalive) cur = E.pxy[0];
+            else if (lane == nalive) cur = L.sp[0];
             if (have_prev) {
                 // python loop with break: the comparison is pure, so "any" gives the same answer
                 const bool moved = lane <= nalive && bd_dist2(prevp.x, prevp.y, cur.x, cur.y) > 0.005;
@@ -725,7 +725,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
         // ---------------- after the sim step ----------------
         const int after_move = (B.task == 1) ? PH_FIXED : PH_STILL;
         if (phase == PH_PATH) {
-            const double px = E.pxy[0].x, py = E.pxy[0].y, ph = bd_restrict(E.ang[0]);
+            const double px = L.sp[0].x, py = L.sp[0].y, ph = bd_restrict(L.ag[0].x);
             const double pwx = wp[3 * (wi - 1)], pwy = wp[3 * (wi - 1) + 1]; // robot_prev_waypoint_position
             const double wpx_ = wp[3 * wi], wpy_ = wp[3 * wi + 1], wph_ = wp[3 * wi + 2];
             bool leave = false;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
         } else if (phase == PH_VEL) {
             kcount++;
             if (S.robot_hit || kcount >= P.steps) {
-                robot_distance = bd_dist2(ix, iy, E.pxy[0].x, E.pxy[0].y);
+                robot_distance = bd_dist2(ix, iy, L.sp[0].x, L.sp[0].y);
                 phase = after_move; sim_steps = 0; kcount = 0;
             }
         } else if (phase == PH_FIXED) {

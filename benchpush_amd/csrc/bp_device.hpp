@@ -124,7 +124,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the
 // host (launch size), so the two cannot drift apart.
 struct LdsMap {
-    unsigned sv, sw, sb, sp, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mv,
+    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mv,
         slot_of, rf, ev_d, ev_key, prof, total;
 };
 __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
@@ -135,6 +135,7 @@ __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, c
     m.sw = p; p += 16u * (BP_NSLOT + 1);
     m.sb = p; p += 16u * (BP_NSLOT + 1);
     m.sp = p; p += 16u * (BP_NSLOT + 1);    // position of the body that holds the slot (LDS copy of pxy)
+    m.ag = p; p += 32u;                     // agent (body 0): (angle, -), (cos, sin)
     // narrow-phase scratch; the transforms of the integrate phase ([64][2] d2 = 2 KB <= q_dir + q_c) and, later, the manifold mailbox
     // (BP_MBOX x 96 B) reuse the query buffers from q_dir on
     m.tf = p;

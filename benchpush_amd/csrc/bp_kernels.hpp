@@ -41,7 +41,7 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
 {
     const LdsMap m = bp_lds_map(P.nbcap, P.mvcap, KIND == BP_ENV_BOX, BP_PROF_ON);
     char *b = (char *)bp_smem;
-    L.sv = (d2 *)(b + m.sv); L.sw = (d2 *)(b + m.sw); L.sb = (d2 *)(b + m.sb); L.sp = (d2 *)(b + m.sp);
+    L.sv = (d2 *)(b + m.sv); L.sw = (d2 *)(b + m.sw); L.sb = (d2 *)(b + m.sb); L.sp = (d2 *)(b + m.sp); L.ag = (d2 *)(b + m.ag);
     L.tf = (d2 *)(b + m.tf);
     L.q_dir = (d2 *)(b + m.q_dir); L.q_c = (double *)(b + m.q_c); L.r_val = (double *)(b + m.r_val);
     L.q_meta = (unsigned *)(b + m.q_meta); L.q_aux = (unsigned *)(b + m.q_aux); L.r_idx = (unsigned *)(b + m.r_idx);
@@ -104,6 +104,7 @@ __device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &
         if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     }
     if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; L.sp[lane] = E.pxy[lane]; }
+    if (lane == 0) { L.ag[0] = mk2(E.ang[0], 0.0); L.ag[1] = E.rot[0]; }
     S.nslots = P.nkin;
     S.wall_flag = (P.env_kind == BP_ENV_MAZE) ? (D.e_flags[env] & 1) : 0;
     const size_t ab = (size_t)env * BP_ACAP + lane;
@@ -322,6 +323,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                     bp_sincos(ps.z, sn, cs);
                     E.pxy[i] = mk2(ps.x, ps.y); E.ang[i] = ps.z; E.rot[i] = mk2(cs, sn);
                     if (i < P.nkin) L.sp[i] = mk2(ps.x, ps.y);
+                    if (i == 0) { L.ag[0] = mk2(ps.z, 0.0); L.ag[1] = mk2(cs, sn); }
                     E.adjn[i] = 0;
                 }
             }

@@ -63,6 +63,7 @@ struct EnvCtx {
 
 struct LdsCtx {
     d2 *sv, *sw, *sb;          // [BP_NSLOT] (vx,vy) (w,w_bias) (vbx,vby) of the bodies that hold a velocity slot
+    d2 *ag;                    // agent (body 0): (angle, -), (cos, sin), kept current by the integrate phase
     d2 *sp;                    // [BP_NSLOT] their positions (copy of E.pxy, kept current by whoever moves the body)
     unsigned char *slot_of;    // [nbcap] velocity slot of a body, 255 = none (velocity is exactly zero)
     unsigned *mvs;             // [nbcap] stamp of the sub-step in which the body last moved
@@ -300,6 +301,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const double a2 = a + (w2.x + w2.y) * dt;
             if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
             E.pxy[i] = p; E.ang[i] = a2; E.rot[i] = r;
+            if (i == 0) { L.ag[0] = mk2(a2, 0.0); L.ag[1] = r; }
             if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(w2.x, 0.0); L.sp[sl] = p; }
             double4 t;
             t.x = r.x; t.y = r.y;
@@ -967,7 +969,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         if (k < S.nmv) {
             const int i = L.mv[k];
             const int sl = L.slot_of[i];
-            if (sl != 255 && E.mass[i].x != 0.0) { L.sv[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(0.0, L.sw[sl].y); }
+            // bodies of the moving list are parts of the kinematic agent (indices below nkin) or dynamic; a static shape in the list (first sub-step
+            // of a new space) has zero velocity already
+            if (sl != 255 && i >= P.nkin) { L.sv[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(0.0, L.sw[sl].y); }
         }
     }
     lds_sync();
@@ -1114,8 +1118,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     // ---- agent rules applied after every sub-step: yaw limits + channel boundary (ship_ice_env.py:284-290),
     //      boundary only for the maze robot (maze_NAMO_env.py:417-419) ------------------------------------------------
     if (ship_rules) {
-        const double a0 = E.ang[0];
-        const double x0 = E.pxy[0].x;
+        const double a0 = L.ag[0].x;
+        const double x0 = L.sp[0].x;
         if (P.env_kind == BP_ENV_SHIP_ICE && (a0 <= 0.0 || a0 >= BP_PI)) {
             if (lane < P.nkin) L.sw[lane] = mk2(0.0, L.sw[lane].y);
             S.yaw_violated = 1;
