@@ -74,7 +74,7 @@ struct DevPtrs {
     double4 *bb, *fat;       // [E][nbcap] l,b,r,t
     unsigned short *adj;     // [E][nbcap][KADJ]
     unsigned char *adjn;     // [E][nbcap]
-    unsigned short *hint;    // [E][nbcap][KADJ] cached plane-search winners of the pair behind each neighbour slot (HW_* below)
+    unsigned long long *hint; // [E][nbcap][KADJ] cached plane-search winners of the pair behind each neighbour slot (HW_* below)
     // persisted arbiter slots [E][ACAP]
     unsigned *a_key, *a_stamp, *a_sc, *a_h0, *a_h1;
     double *a_d;             // [E][ACAP][14] jn0 jt0 jn1 jt1 nx ny r1x0 r1y0 r2x0 r2y0 r1x1 r1y1 r2x1 r2y1
@@ -105,15 +105,24 @@ __device__ __forceinline__ d2 vlerp(d2 a, d2 b, double t) { return vadd(vmul(a, 
 __device__ __forceinline__ double clamp01(double f) { return fmax(0.0, fmin(f, 1.0)); }
 __device__ __forceinline__ double fclampd(double f, double lo, double hi) { return fmin(fmax(f, lo), hi); }
 
-// Hint word of a neighbour-list entry: the planes that won the two sides of the pair's plane search when it was last run in full.  A cached plane is
-// re-evaluated exactly (its separation is a lower bound of the pair's maximum: above the radii the pair is rejected at once) and every other plane is
-// first bounded from above with one vertex; only planes whose bound reaches the cached value are searched.  0 = nothing cached.
-#define HW_PLANE_A(h) ((int)((h) & 31u))
-#define HW_PLANE_B(h) ((int)(((h) >> 5) & 31u))
-#define HW_HAS_A 0x400u
-#define HW_HAS_B 0x800u
-#define HW_PRIM_B 0x1000u   // the side whose plane had the larger separation (the one tested first) is B
-#define HW_BOTH 0x2000u     // the pair got past the cached-plane test last time: both cached planes are evaluated up front
+// Hint word of a neighbour-list entry (64 bits): the planes that won the two sides of the pair's plane search when it was last run, their support
+// vertices on the other shape, and the two vertex counts (for the cyclic neighbours of a support vertex).  A cached plane is re-evaluated exactly:
+// its separation is a lower bound of the pair's maximum, so above the radii the pair is rejected at once; every other plane is first bounded from
+// above with a few vertices and searched only if the bound reaches the cached value.  0 = nothing cached.
+#define HW_PLANE_A(h) ((int)((h) & 31ull))
+#define HW_PLANE_B(h) ((int)(((h) >> 5) & 31ull))
+#define HW_VERT_A(h) ((int)(((h) >> 10) & 31ull))   // support vertex (on B) of the cached plane of A
+#define HW_VERT_B(h) ((int)(((h) >> 15) & 31ull))   // support vertex (on A) of the cached plane of B
+#define HW_NV_A(h) ((int)(((h) >> 20) & 31ull))
+#define HW_NV_B(h) ((int)(((h) >> 25) & 31ull))
+#define HW_HAS_A (1ull << 32)
+#define HW_HAS_B (1ull << 33)
+#define HW_PRIM_B (1ull << 34)   // the side whose plane had the larger separation (the one tested first) is B
+#define HW_BOTH (1ull << 35)     // the pair got past the cached-plane test last time: both cached planes are evaluated up front
+// A minimum of d . v over a convex polygon's vertices found at vertex j is exact as soon as both cyclic neighbours of j exceed it by this margin:
+// the true sequence is unimodal and the computed dot products are within ~1e-13 of the true ones (coordinates below 64 m), so every other vertex
+// is then larger too and j is the unique first minimum.
+#define BP_SUPPORT_MARGIN 1e-10
 #define BP_QCAP 96          // support queries per batch (LDS)
 
 #define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step

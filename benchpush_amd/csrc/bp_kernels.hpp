@@ -799,7 +799,7 @@ __global__ __launch_bounds__(256) void k_reset_copy(const DevParams P, const Dev
     copy_span(D.bb + d, D.bb + s, nb, tid, nt);
     copy_span(D.fat + d, D.fat + s, nb, tid, nt);
     copy_span((unsigned long long *)(D.adj + d * BP_KADJ), (const unsigned long long *)(D.adj + s * BP_KADJ), nb * BP_KADJ / 4, tid, nt);
-    copy_span((unsigned long long *)(D.hint + d * BP_KADJ), (const unsigned long long *)(D.hint + s * BP_KADJ), nb * BP_KADJ / 4, tid, nt);
+    copy_span(D.hint + d * BP_KADJ, D.hint + s * BP_KADJ, nb * BP_KADJ, tid, nt);
     copy_span((unsigned long long *)(D.adjn + d), (const unsigned long long *)(D.adjn + s), nb / 8, tid, nt);
     const size_t ad = (size_t)env * BP_ACAP, as = (size_t)(P.num_envs + trial) * BP_ACAP;
     copy_span(D.a_key + ad, D.a_key + as, BP_ACAP, tid, nt);

@@ -58,7 +58,7 @@ struct EnvCtx {
     double4 *bb, *fat;
     unsigned short *adj;
     unsigned char *adjn;
-    unsigned short *hint;
+    unsigned long long *hint;
 };
 
 struct LdsCtx {
@@ -385,7 +385,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const int sc = min(s, BP_KADJ - 1);
         const int adjn_i = E.adjn[i];
         const int j = E.adj[i * BP_KADJ + sc] < E.nb ? (int)E.adj[i * BP_KADJ + sc] : 0;
-        const unsigned hw = E.hint[i * BP_KADJ + sc];
+        const unsigned long long hw = E.hint[i * BP_KADJ + sc];
         const double4 bbi = E.bb[i];
         bool valid = inlist && (s < adjn_i);
         if (valid && L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
@@ -396,10 +396,17 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const double radA = E.prop[sa].x, radB = E.prop[sb].x;
         const double rsum = radA + radB;
         const int nA_h = E.nv[sa], nB_h = E.nv[sb];
-        // the cached planes (hint word) of both sides travel with this round trip too: plane indices only need to be valid addresses here
+        // the cached planes (hint word) of both sides travel with this round trip too, and so do the cached support vertex of each with its two
+        // cyclic neighbours: plane and vertex indices only need to be valid addresses here
         const int hA = HW_PLANE_A(hw) < BP_MAXV ? HW_PLANE_A(hw) : 0, hB = HW_PLANE_B(hw) < BP_MAXV ? HW_PLANE_B(hw) : 0;
+        const int cnA = HW_NV_A(hw), cnB = HW_NV_B(hw);
+        const int jA0 = HW_VERT_A(hw) < BP_MAXV ? HW_VERT_A(hw) : 0, jB0 = HW_VERT_B(hw) < BP_MAXV ? HW_VERT_B(hw) : 0;
+        const int jAm = (jA0 == 0) ? max(min(cnB, BP_MAXV) - 1, 0) : jA0 - 1, jAp = (jA0 + 1 >= cnB) ? 0 : jA0 + 1;   // on B
+        const int jBm = (jB0 == 0) ? max(min(cnA, BP_MAXV) - 1, 0) : jB0 - 1, jBp = (jB0 + 1 >= cnA) ? 0 : jB0 + 1;   // on A
         const d2 fnA = E.wn[sa * BP_MAXV + hA], fpA = E.wv[sa * BP_MAXV + hA];
         const d2 fnB = E.wn[sb * BP_MAXV + hB], fpB = E.wv[sb * BP_MAXV + hB];
+        const d2 vAm = E.wv[sb * BP_MAXV + jAm], vA0 = E.wv[sb * BP_MAXV + jA0], vAp = E.wv[sb * BP_MAXV + jAp];
+        const d2 vBm = E.wv[sa * BP_MAXV + jBm], vB0 = E.wv[sa * BP_MAXV + jB0], vBp = E.wv[sa * BP_MAXV + jBp];
         bool flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
         if (valid) {
             if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
@@ -421,16 +428,25 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const bool evA = valid && (hw & HW_HAS_A) && ((hw & HW_BOTH) || !(hw & HW_PRIM_B));
         const bool evB = valid && (hw & HW_HAS_B) && ((hw & HW_BOTH) || (hw & HW_PRIM_B));
         double sepAc = -BP_INF, sepBc = -BP_INF;
-        int jAc = 0, jBc = 0;
+        int jAc = jA0, jBc = jB0;
+        const double cA = vdot(fnA, fpA), cB = vdot(fnB, fpB);
+        bool qryA = evA, qryB = evB; // sides whose cached support vertex does not pass the local test: searched by support_queries
+        {   // the cached support vertex against its two neighbours (BP_SUPPORT_MARGIN): exact minimum and first index without a search
+            const double dm = vdot(fnA, vAm), d0 = vdot(fnA, vA0), dp = vdot(fnA, vAp);
+            if (evA && cnB == nB_h && cnB >= 2 && d0 + BP_SUPPORT_MARGIN <= dm && d0 + BP_SUPPORT_MARGIN <= dp) { sepAc = (d0 - cA) + 0.0; qryA = false; }
+        }
         {
-            const unsigned long long mqA = ballot(evA), mqB = ballot(evB);
+            const double dm = vdot(fnB, vBm), d0 = vdot(fnB, vB0), dp = vdot(fnB, vBp);
+            if (evB && cnA == nA_h && cnA >= 2 && d0 + BP_SUPPORT_MARGIN <= dm && d0 + BP_SUPPORT_MARGIN <= dp) { sepBc = (d0 - cB) + 0.0; qryB = false; }
+        }
+        {
+            const unsigned long long mqA = ballot(qryA), mqB = ballot(qryB);
             const int nqA = __popcll(mqA), nq1 = nqA + __popcll(mqB);
             PROF_CNT(37, nq1)
-            if (nq1) {
+            if (BP_UNLIKELY(nq1)) {
                 const int slA = popc_below(mqA, lane), slB = nqA + popc_below(mqB, lane);
-                const double cA = vdot(fnA, fpA), cB = vdot(fnB, fpB);
-                for (int q0 = 0; q0 < nq1; q0 += BP_QCAP) { // one batch unless more than BP_QCAP planes are cached in this round
-                    const bool inA = evA && slA >= q0 && slA < q0 + BP_QCAP, inB = evB && slB >= q0 && slB < q0 + BP_QCAP;
+                for (int q0 = 0; q0 < nq1; q0 += BP_QCAP) { // one batch unless more than BP_QCAP planes need the search in this round
+                    const bool inA = qryA && slA >= q0 && slA < q0 + BP_QCAP, inB = qryB && slB >= q0 && slB < q0 + BP_QCAP;
                     if (inA) { L.q_dir[slA - q0] = fnA; L.q_meta[slA - q0] = (unsigned)sb | ((unsigned)nB_h << 16); }
                     if (inB) { L.q_dir[slB - q0] = fnB; L.q_meta[slB - q0] = (unsigned)sa | ((unsigned)nA_h << 16); }
                     lds_sync();
@@ -444,7 +460,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         if (valid && (sepAc > rsum || sepBc > rsum)) {
             valid = false;
-            if (hw & HW_BOTH) E.hint[i * BP_KADJ + s] = (unsigned short)((hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0u : HW_PRIM_B));
+            if (hw & HW_BOTH) E.hint[i * BP_KADJ + s] = (hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0ull : HW_PRIM_B);
         }
         const unsigned long long cm = ballot(valid);
         PROF_ACC(28)
@@ -660,8 +676,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 }
             }
             // the winners of both sides are the next sub-step's cached planes
-            E.hint[i * BP_KADJ + s] = (unsigned short)((unsigned)iA | ((unsigned)iB << 5) | HW_HAS_A | HW_HAS_B | (useA ? 0u : HW_PRIM_B) |
-                                                       ((smax > rsum) ? 0u : HW_BOTH));
+            E.hint[i * BP_KADJ + s] = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
+                                                           ((unsigned)nA << 20) | ((unsigned)nB << 25)) |
+                                      HW_HAS_A | HW_HAS_B | (useA ? 0ull : HW_PRIM_B) | ((smax > rsum) ? 0ull : HW_BOTH);
         }
         PROF_ACC(31)
         // support vertices (PolySupportPointIndex: first maximum of v . n over A, of v . -n over B).  With the normal of plane iA, v . -n over B is
