@@ -123,7 +123,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // the true sequence is unimodal and the computed dot products are within ~1e-13 of the true ones (coordinates below 64 m), so every other vertex
 // is then larger too and j is the unique first minimum.
 #define BP_SUPPORT_MARGIN 1e-10
-#define BP_QCAP 96          // support queries per batch (LDS)
+#define BP_QCAP 128         // support queries per batch (LDS)
 
 #define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step
 #define BP_MBOX 16          // manifold mailbox entries per hand-over batch
@@ -265,6 +265,20 @@ __device__ __forceinline__ double half_min(double v)
     v = fmin(v, dpp_mov_f64<0x140>(v));
     v = fmin(v, __shfl_xor(v, 16));
     return v;
+}
+// maxima of the two half waves (lanes 0..31 -> lo, 32..63 -> hi), wave-uniform; max is exact, so the reduction order is irrelevant
+__device__ __forceinline__ double readlane_f64(double v, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+__device__ __forceinline__ void halves_max_f64(double v, double &lo, double &hi)
+{
+    v = fmax(v, dpp_mov_f64<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_mov_f64<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_mov_f64<0x141>(v));  // row_half_mirror
+    v = fmax(v, dpp_mov_f64<0x140>(v));  // row_mirror: every lane holds the maximum of its row of 16
+    lo = fmax(readlane_f64(v, 0), readlane_f64(v, 16));
+    hi = fmax(readlane_f64(v, 32), readlane_f64(v, 48));
 }
 // 8-lane groups (lanes 8g .. 8g+7): every lane receives the group's minimum
 __device__ __forceinline__ double oct_min_f64(double v)

@@ -84,8 +84,6 @@ __device__ __forceinline__ void init_regs(ArbReg &A, SubState &S)
     A.e = 0.0; A.u = 0.0;
     S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
     A.level = 0; A.rank = 0;
-    A.nMass0 = A.tMass0 = A.bias0 = A.bounce0 = A.jBias0 = 0.0;
-    A.nMass1 = A.tMass1 = A.bias1 = A.bounce1 = A.jBias1 = 0.0;
     A.ma = A.ia = A.mb = A.ib = 0.0;
 
 }

@@ -39,8 +39,6 @@ struct ArbReg {
     int state, count, level, rank;
     double jn0, jt0, jn1, jt1;
     d2 n, r1_0, r2_0, r1_1, r2_1;
-    double nMass0, tMass0, bias0, bounce0, jBias0;
-    double nMass1, tMass1, bias1, bounce1, jBias1;
     double ma, ia, mb, ib;
     double e, u;               // elasticity / friction products of the two shapes (cpArbiterUpdate)
     int slotA, slotB;          // velocity slots of the two bodies
@@ -468,8 +466,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         if (cm == 0) continue;
         PROF_CNT(25, 1)
         // ---- 4a'. every other plane of the surviving pairs: one round per pair, lanes 0..31 = planes of A, 32..63 = planes of B.  A plane's separation
-        //      is a minimum over the other shape's vertices, so its value at ONE vertex (the support vertex of the side's cached plane) bounds it from
-        //      above; only planes whose bound reaches the cached plane's exact value can win the side (ties included) and are searched exactly.
+        //      is a minimum over the other shape's vertices, so its minimum over THREE of them (the support vertex of the side's cached plane and its two
+        //      neighbours) bounds it from above; only planes whose bound reaches the cached plane's exact value can win the side (ties included) and are searched exactly.
         const int nc = __popcll(cm);
         const int myr = popc_below(cm, lane); // rank of this lane's pair among the survivors
         const int nA_l = valid ? nA_h : 0, nB_l = valid ? nB_h : 0;
@@ -489,7 +487,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             int nq = 0, g0 = 0; // queries collected, first pair rank of the current group
             const int side = lane >> 5, f = lane & 31;
             // One bound round: lanes 0..31 = planes of A, 32..63 = planes of B of the pair with rank rr.
-            auto round_addr = [&](const uint4 pa, int &pbody, int &qbody, int &np, int &nqv, int &hX, bool &evX, int &jc) {
+            auto round_addr = [&](const uint4 pa, int &pbody, int &qbody, int &np, int &nqv, int &hX, bool &evX, int &jc, int &jm, int &jp) {
                 const int psa = (int)(pa.x & 0xFFFFu), psb = (int)(pa.x >> 16);
                 const int pna = (int)(pa.y & 0xFFu), pnb = (int)((pa.y >> 8) & 0xFFu);
                 pbody = side ? psb : psa; qbody = side ? psa : psb;
@@ -497,6 +495,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 hX = (int)((pa.y >> (side ? 24 : 16)) & 0xFFu);
                 evX = ((pa.z >> side) & 1u) != 0;
                 jc = (int)((pa.z >> (side ? 16 : 8)) & 0xFFu);
+                jm = (jc == 0) ? max(nqv, 1) - 1 : jc - 1; jp = (jc + 1 >= nqv) ? 0 : jc + 1;   // cyclic neighbours of the support vertex
             };
             // Fast path: the rounds are taken two at a time so that their loads travel together; the surviving planes go straight into the query
             // buffer.  If they do not all fit (rare: pairs without cached planes), the sequential loop below redoes the rounds group by group.
@@ -507,17 +506,17 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     const bool two = r0 + 1 < nc;
                     const uint4 pa0 = L.pt_a[r0], pa1 = L.pt_a[two ? r0 + 1 : r0];
                     const d2 thr0 = L.pt_thr[r0], thr1 = L.pt_thr[two ? r0 + 1 : r0];
-                    int pb0, qb0, np0, nqv0, hX0, jc0, pb1, qb1, np1, nqv1, hX1, jc1; bool ev0, ev1;
-                    round_addr(pa0, pb0, qb0, np0, nqv0, hX0, ev0, jc0);
-                    round_addr(pa1, pb1, qb1, np1, nqv1, hX1, ev1, jc1);
+                    int pb0, qb0, np0, nqv0, hX0, jc0, jm0, jp0, pb1, qb1, np1, nqv1, hX1, jc1, jm1, jp1; bool ev0, ev1;
+                    round_addr(pa0, pb0, qb0, np0, nqv0, hX0, ev0, jc0, jm0, jp0);
+                    round_addr(pa1, pb1, qb1, np1, nqv1, hX1, ev1, jc1, jm1, jp1);
                     const int fc0 = (f < np0) ? f : 0, fc1 = (f < np1) ? f : 0;
-                    const d2 fn0 = E.wn[pb0 * BP_MAXV + fc0], fp0 = E.wv[pb0 * BP_MAXV + fc0], vb0 = E.wv[qb0 * BP_MAXV + jc0];
-                    const d2 fn1 = E.wn[pb1 * BP_MAXV + fc1], fp1 = E.wv[pb1 * BP_MAXV + fc1], vb1 = E.wv[qb1 * BP_MAXV + jc1];
+                    const d2 fn0 = E.wn[pb0 * BP_MAXV + fc0], fp0 = E.wv[pb0 * BP_MAXV + fc0], vb0 = E.wv[qb0 * BP_MAXV + jc0], vm0 = E.wv[qb0 * BP_MAXV + jm0], vp0 = E.wv[qb0 * BP_MAXV + jp0];
+                    const d2 fn1 = E.wn[pb1 * BP_MAXV + fc1], fp1 = E.wv[pb1 * BP_MAXV + fc1], vb1 = E.wv[qb1 * BP_MAXV + jc1], vm1 = E.wv[qb1 * BP_MAXV + jm1], vp1 = E.wv[qb1 * BP_MAXV + jp1];
                     {
                         const double th = side ? thr0.y : thr0.x;
                         const bool pv = (f < np0) && !(ev0 && f == hX0);
                         const double c = vdot(fn0, fp0);
-                        const double bound = (vdot(fn0, vb0) - c) + 0.0;
+                        const double bound = (fmin(vdot(fn0, vb0), fmin(vdot(fn0, vm0), vdot(fn0, vp0))) - c) + 0.0;
                         const bool surv = pv && (!ev0 || bound >= th);
                         const unsigned long long sm = ballot(surv);
                         const int sl = nq + popc_below(sm, lane);
@@ -532,7 +531,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         const double th = side ? thr1.y : thr1.x;
                         const bool pv = two && (f < np1) && !(ev1 && f == hX1);
                         const double c = vdot(fn1, fp1);
-                        const double bound = (vdot(fn1, vb1) - c) + 0.0;
+                        const double bound = (fmin(vdot(fn1, vb1), fmin(vdot(fn1, vm1), vdot(fn1, vp1))) - c) + 0.0;
                         const bool surv = pv && (!ev1 || bound >= th);
                         const unsigned long long sm = ballot(surv);
                         const int sl = nq + popc_below(sm, lane);
@@ -603,15 +602,15 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (rr == nc) break;
                 const uint4 pa = L.pt_a[rr];
                 const d2 thr = L.pt_thr[rr];
-                int pbody, qbody, np, nqv, hX, jc; bool evX;
-                round_addr(pa, pbody, qbody, np, nqv, hX, evX, jc);
+                int pbody, qbody, np, nqv, hX, jc, jm, jp; bool evX;
+                round_addr(pa, pbody, qbody, np, nqv, hX, evX, jc, jm, jp);
                 const double th = side ? thr.y : thr.x;
                 const bool pv = (f < np) && !(evX && f == hX);
                 const int fc = (f < np) ? f : 0;
                 const d2 fn = E.wn[pbody * BP_MAXV + fc], fp = E.wv[pbody * BP_MAXV + fc];
-                const d2 vb = E.wv[qbody * BP_MAXV + jc];
+                const d2 vb = E.wv[qbody * BP_MAXV + jc], vm = E.wv[qbody * BP_MAXV + jm], vp = E.wv[qbody * BP_MAXV + jp];
                 const double c = vdot(fn, fp);
-                const double bound = (vdot(fn, vb) - c) + 0.0;
+                const double bound = (fmin(vdot(fn, vb), fmin(vdot(fn, vm), vdot(fn, vp))) - c) + 0.0;
                 const bool surv = pv && (!evX || bound >= th);
                 const unsigned long long sm = ballot(surv);
                 if (surv) {
@@ -633,6 +632,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         int src = 2; // where the normal comes from: 0 = plane iA of A, 1 = plane iB of B (negated), 2 = a vertex pair
         d2 n = mk2(0, 0);
         int iA = 0, iB = 0, jA = 0, jB = 0;
+        int i1A = 0, i1B = 0;              // support vertices of the contact (PolySupportPointIndex)
+        bool needA = false, needB = false; // ... that a support query has to find
         const int nA = nA_l, nB = nB_l;
         const d2 *Av = E.wv + sa * BP_MAXV, *An = E.wn + sa * BP_MAXV, *Bv = E.wv + sb * BP_MAXV, *Bn = E.wn + sb * BP_MAXV;
         if (valid) {
@@ -646,6 +647,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const d2 nAi = An[iA], nBi = Bn[iB];
             const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
             const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
+            // the outer neighbours of the two winning edges: they certify the support vertex of the shape that owns the normal (below)
+            const int iA0m = (iA0 == 0) ? nA - 1 : iA0 - 1, iAp = (iA + 1 >= nA) ? 0 : iA + 1;
+            const int iB0m = (iB0 == 0) ? nB - 1 : iB0 - 1, iBp = (iB + 1 >= nB) ? 0 : iB + 1;
+            const d2 oA0 = Av[iA0m], oA1 = Av[iAp], oB0 = Bv[iB0m], oB1 = Bv[iBp];
             if (smax > rsum) touching = false;
             else if (smax <= 0.0) { n = useA ? nAi : vneg(nBi); src = useA ? 0 : 1; }
             else {
@@ -675,18 +680,32 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     }
                 }
             }
+            // Support vertices (PolySupportPointIndex: first maximum of v . n over A, of v . -n over B).  With the normal of plane iA, v . -n over B is the
+            // negated sequence whose first minimum the plane search has already found (jA); likewise jB for a normal from B.  The shape that owns the
+            // normal: the maximum lies on the winning edge, i.e. at one of its two end vertices (equal in exact arithmetic); when both outer neighbours
+            // stay BP_SUPPORT_MARGIN below, no other vertex of the convex hull can reach it, and the first maximum of the sequential scan is the larger of
+            // the two, the lower index on a tie.  Otherwise (and for vertex-vertex normals) a support query finds it.
+            i1A = jB; i1B = jA;
+            needA = touching && src != 1; needB = touching && src != 0;
+            if (touching && src == 0) {
+                const double c0 = vdot(aA, n), c1 = vdot(bA, n), o0 = vdot(oA0, n), o1 = vdot(oA1, n);
+                const double cm = (c0 > c1) ? c0 : c1, om = (o0 > o1) ? o0 : o1;
+                if (nA == 2 || cm >= om + BP_SUPPORT_MARGIN) { i1A = (c0 > c1) ? iA0 : (c1 > c0) ? iA : min(iA0, iA); needA = false; }
+            }
+            if (touching && src == 1) {
+                const d2 nn = vneg(n);
+                const double c0 = vdot(aB, nn), c1 = vdot(bB, nn), o0 = vdot(oB0, nn), o1 = vdot(oB1, nn);
+                const double cm = (c0 > c1) ? c0 : c1, om = (o0 > o1) ? o0 : o1;
+                if (nB == 2 || cm >= om + BP_SUPPORT_MARGIN) { i1B = (c0 > c1) ? iB0 : (c1 > c0) ? iB : min(iB0, iB); needB = false; }
+            }
             // the winners of both sides are the next sub-step's cached planes
             E.hint[i * BP_KADJ + s] = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
                                                            ((unsigned)nA << 20) | ((unsigned)nB << 25)) |
                                       HW_HAS_A | HW_HAS_B | (useA ? 0ull : HW_PRIM_B) | ((smax > rsum) ? 0ull : HW_BOTH);
         }
         PROF_ACC(31)
-        // support vertices (PolySupportPointIndex: first maximum of v . n over A, of v . -n over B).  With the normal of plane iA, v . -n over B is
-        // the negated sequence whose first minimum the plane search has already found (jA); likewise jB for a normal from B.  The other one is a
-        // support query in direction -n over A (n over B), whose first minimum is the first maximum wanted.
-        int i1A = jB, i1B = jA;
+        // support queries for the support vertices that could not be certified: direction -n over A (n over B); the first minimum is the first maximum wanted
         {
-            const bool needA = touching && src != 1, needB = touching && src != 0;
             const unsigned long long mA = ballot(needA), mB = ballot(needB);
             const int nqa = __popcll(mA), nq2 = nqa + __popcll(mB);
             PROF_CNT(39, nq2)
@@ -884,6 +903,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     PROF_MAX(15, S.nmv)
     PROF_CNT(20, S.nlevels)
     // ---- 6a. prestep (cpArbiterPreStep) -----------------------------------------------------------------------
+    // per-sub-step terms of the lane's arbiter: defined here for every lane, so that nothing keeps them alive across the collision phase
+    double nMass0 = 0.0, tMass0 = 0.0, bias0 = 0.0, bounce0 = 0.0, jBias0 = 0.0;
+    double nMass1 = 0.0, tMass1 = 0.0, bias1 = 0.0, bounce1 = 0.0, jBias1 = 0.0;
     if (active) {
         const d2 pa = L.sp[A.slotA], pb = L.sp[A.slotB];
         const d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
@@ -893,27 +915,27 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const d2 t = vperp(n);
         {
             const double rcn1 = vcross(A.r1_0, n), rcn2 = vcross(A.r2_0, n);
-            A.nMass0 = 1.0 / ((A.ma + A.ia * rcn1 * rcn1) + (A.mb + A.ib * rcn2 * rcn2));
+            nMass0 = 1.0 / ((A.ma + A.ia * rcn1 * rcn1) + (A.mb + A.ib * rcn2 * rcn2));
             const double rct1 = vcross(A.r1_0, t), rct2 = vcross(A.r2_0, t);
-            A.tMass0 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
+            tMass0 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
             const double dist = vdot(vadd(vsub(A.r2_0, A.r1_0), body_delta), n);
-            A.bias0 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
-            A.jBias0 = 0.0;
+            bias0 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
+            jBias0 = 0.0;
             const d2 v1 = vadd(va, vmul(vperp(A.r1_0), wa));
             const d2 v2 = vadd(vb, vmul(vperp(A.r2_0), wb));
-            A.bounce0 = vdot(vsub(v2, v1), n) * A.e;
+            bounce0 = vdot(vsub(v2, v1), n) * A.e;
         }
         if (A.count > 1) {
             const double rcn1 = vcross(A.r1_1, n), rcn2 = vcross(A.r2_1, n);
-            A.nMass1 = 1.0 / ((A.ma + A.ia * rcn1 * rcn1) + (A.mb + A.ib * rcn2 * rcn2));
+            nMass1 = 1.0 / ((A.ma + A.ia * rcn1 * rcn1) + (A.mb + A.ib * rcn2 * rcn2));
             const double rct1 = vcross(A.r1_1, t), rct2 = vcross(A.r2_1, t);
-            A.tMass1 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
+            tMass1 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
             const double dist = vdot(vadd(vsub(A.r2_1, A.r1_1), body_delta), n);
-            A.bias1 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
-            A.jBias1 = 0.0;
+            bias1 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
+            jBias1 = 0.0;
             const d2 v1 = vadd(va, vmul(vperp(A.r1_1), wa));
             const d2 v2 = vadd(vb, vmul(vperp(A.r2_1), wb));
-            A.bounce1 = vdot(vsub(v2, v1), n) * A.e;
+            bounce1 = vdot(vsub(v2, v1), n) * A.e;
         }
     }
     // ---- warm set: arbiters that can produce a non-zero impulse this sub-step ------------------------------------
@@ -921,8 +943,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     // body".  Every other arbiter provably keeps all its impulses at exactly 0 and is skipped.
     bool warm = false;
     if (active) {
-        warm = (A.jn0 != 0.0) || (A.jt0 != 0.0) || (A.bias0 != 0.0) || (A.bounce0 != 0.0);
-        if (A.count > 1) warm = warm || (A.jn1 != 0.0) || (A.jt1 != 0.0) || (A.bias1 != 0.0) || (A.bounce1 != 0.0);
+        warm = (A.jn0 != 0.0) || (A.jt0 != 0.0) || (bias0 != 0.0) || (bounce0 != 0.0);
+        if (A.count > 1) warm = warm || (A.jn1 != 0.0) || (A.jt1 != 0.0) || (bias1 != 0.0) || (bounce1 != 0.0);
         if (A.ma == 0.0) { const d2 v = L.sv[A.slotA]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotA].x != 0.0); }
         if (A.mb == 0.0) { const d2 v = L.sv[A.slotB]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotB].x != 0.0); }
         if (A.ma != 0.0) L.owner[A.slotA] = 0;
@@ -940,7 +962,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             wmask = nm;
         }
     }
-    const bool any_bias = ballot(warm && ((A.bias0 != 0.0) || (A.count > 1 && A.bias1 != 0.0))) != 0;
+    const bool any_bias = ballot(warm && ((bias0 != 0.0) || (A.count > 1 && bias1 != 0.0))) != 0;
     // ---- solve order: greedy colouring of the active set in ascending key order (cached while the set is unchanged);
     //      arbiters of one colour share no dynamic body, so a colour runs in parallel; order = (colour, key) ----------
     if (BP_UNLIKELY(amask != S.prev_amask)) {
@@ -1040,14 +1062,14 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 for (int c = 0; c < 2; c++) {
                     if (c == 0 || A.count > 1) { // an arbiter always has its first contact
                         const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
-                        const double nMass = c ? A.nMass1 : A.nMass0, tMass = c ? A.tMass1 : A.tMass0;
-                        const double bias = c ? A.bias1 : A.bias0, bounce = c ? A.bounce1 : A.bounce0;
+                        const double nMass = c ? nMass1 : nMass0, tMass = c ? tMass1 : tMass0;
+                        const double bias = c ? bias1 : bias0, bounce = c ? bounce1 : bounce0;
                         const d2 v1 = vadd(va, vmul(vperp(r1), wa2.x));
                         const d2 v2 = vadd(vb, vmul(vperp(r2), wb2.x));
                         const d2 vr = vsub(v2, v1);
                         const double vrn = vdot(vr, n);
                         const double vrt = vdot(vr, vperp(n));
-                        const double jbnOld = c ? A.jBias1 : A.jBias0;
+                        const double jbnOld = c ? jBias1 : jBias0;
                         double jBias = jbnOld;
                         if (AB) { // with no bias term anywhere every bias impulse stays exactly 0
                             const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
@@ -1064,8 +1086,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         const double jtOld = c ? A.jt1 : A.jt0;
                         const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
                         changed = changed || (jnAcc != jnOld) || (jtAcc != jtOld) || (jBias != jbnOld);
-                        if (c) { A.jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
-                        else   { A.jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
+                        if (c) { jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
+                        else   { jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
                         if (AB) {
                             const d2 jb = vmul(n, jBias - jbnOld);
                             const d2 jbneg = vneg(jb);
@@ -1113,10 +1135,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 double ke = 0.0;
                 d2 js = mk2(0.0, 0.0);
                 if (ws) {
-                    ke += eCoef * A.jn0 * A.jn0 / A.nMass0 + A.jt0 * A.jt0 / A.tMass0;
+                    ke += eCoef * A.jn0 * A.jn0 / nMass0 + A.jt0 * A.jt0 / tMass0;
                     js = vadd(js, vrotate(A.n, mk2(A.jn0, A.jt0)));
                     if (A.count > 1) {
-                        ke += eCoef * A.jn1 * A.jn1 / A.nMass1 + A.jt1 * A.jt1 / A.tMass1;
+                        ke += eCoef * A.jn1 * A.jn1 / nMass1 + A.jt1 * A.jt1 / tMass1;
                         js = vadd(js, vrotate(A.n, mk2(A.jn1, A.jt1)));
                     }
                 }
