@@ -128,12 +128,12 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 #define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step
 #define BP_MBOX 16          // manifold mailbox entries per hand-over batch
 #define BP_NSLOT 96         // velocity slots per env (bodies with a non-zero velocity or an arbiter)
-#define BP_PROFN 48         // diagnostic build: phase timers / trip counters per env
+#define BP_PROFN 64         // diagnostic build: phase timers / trip counters per env
 
 // LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the
 // host (launch size), so the two cannot drift apart.
 struct LdsMap {
-    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mv,
+    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, mv,
         slot_of, rf, ev_d, ev_key, prof, total;
 };
 __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
@@ -165,6 +165,7 @@ __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, c
     m.mvs = p; p += 4u * (unsigned)nbcap;
     m.owner = p; p += 2u * (BP_NSLOT + 2);    // per velocity slot
     m.colmask = p; p += 2u * (BP_NSLOT + 2);
+    m.mvo = p; p += 4u * (BP_NSLOT + 2);      // per velocity slot: stamp of the sub-step whose moving list the body has joined
     m.mv = p; p += 2u * (unsigned)mvcap;
     m.slot_of = p; p += (unsigned)nbcap;
     m.rf = p; p += 64u;

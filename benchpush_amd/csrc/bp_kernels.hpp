@@ -52,7 +52,7 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
     L.res_jA = (unsigned *)(b + m.res_jA); L.res_jB = (unsigned *)(b + m.res_jB);
     L.mvs = (unsigned *)(b + m.mvs);
     L.owner = (unsigned short *)(b + m.owner); L.colmask = (unsigned short *)(b + m.colmask);
-    L.mv = (unsigned short *)(b + m.mv);
+    L.mv = (unsigned short *)(b + m.mv); L.mvo = (unsigned *)(b + m.mvo);
     L.slot_of = (unsigned char *)(b + m.slot_of); L.rf = (unsigned char *)(b + m.rf);
     L.ev_key = nullptr; L.ev_d = nullptr;
     if (KIND == BP_ENV_BOX) { L.ev_d = (d2 *)(b + m.ev_d); L.ev_key = (unsigned *)(b + m.ev_key); }
@@ -101,6 +101,7 @@ __device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &
         const int i = base + lane;
         if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     }
+    for (int i = lane; i < BP_NSLOT + 2; i += 64) L.mvo[i] = 0u;
     if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; L.sp[lane] = E.pxy[lane]; }
     if (lane == 0) { L.ag[0] = mk2(E.ang[0], 0.0); L.ag[1] = E.rot[0]; }
     S.nslots = P.nkin;
@@ -309,6 +310,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             const int i = base + lane;
             if (i < nbcap) {
                 L.mvs[i] = 0u;
+                if (i < BP_NSLOT + 2) L.mvo[i] = 0u;
                 L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255;
                 if (i < P.nkin) { L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, 0.0); L.sb[i] = mk2(0.0, 0.0); }
                 if (i < E.nb) {
@@ -1035,7 +1037,7 @@ __device__ __forceinline__ void raster_row_convex(const double *xp, const double
 
 // Flag bits of the LDS window image
 #ifdef BP_PROF
-#define OPROF(k) { if (tid == 0 && D.prof != nullptr) D.prof[(size_t)env * BP_PROFN + 40 + (k)] = __builtin_amdgcn_s_memtime(); }   // slots 40..47: k_observe's stamps
+#define OPROF(k) { if (tid == 0 && D.prof != nullptr) D.prof[(size_t)env * BP_PROFN + 56 + (k)] = __builtin_amdgcn_s_memtime(); }   // slots 56..63: k_observe's stamps
 #else
 #define OPROF(k)
 #endif

@@ -69,6 +69,7 @@ struct LdsCtx {
     unsigned short *colmask;   // [BP_NSLOT] colours already used at the body of a slot (solve-order colouring)
     d2 *tf;                    // [64][2] (cos, sin) (tx, ty) of the moving bodies of the current chunk
     unsigned short *mv;        // [P.mvcap] moving-body list
+    unsigned *mvo;             // [BP_NSLOT] stamp of the sub-step whose (next) moving list the slot's body has joined
     unsigned char *rf;         // [64] refresh flags of the current chunk
     // narrow phase (per candidate round, indexed by survivor rank): best plane separation of side A / B as order-preserving keys, its plane
     // index and support vertex
@@ -958,6 +959,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             lds_sync();
             if (active && !warm) warm = (A.ma != 0.0 && L.owner[A.slotA] != 0) || (A.mb != 0.0 && L.owner[A.slotB] != 0);
             const unsigned long long nm = ballot(warm);
+            PROF_CNT(40, 1)
             if (nm == wmask) break;
             wmask = nm;
         }
@@ -966,6 +968,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     // ---- solve order: greedy colouring of the active set in ascending key order (cached while the set is unchanged);
     //      arbiters of one colour share no dynamic body, so a colour runs in parallel; order = (colour, key) ----------
     if (BP_UNLIKELY(amask != S.prev_amask)) {
+        PROF_CNT(41, 1)
         int rank = 0;
         unsigned long long m = amask;
         while (m) {
@@ -1049,9 +1052,12 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     auto iterate = [&](auto bias_tag) {
     constexpr bool AB = decltype(bias_tag)::value;
     for (int it = 0; it < P.iterations; it++) {
+        PROF_CNT(42, 1)
         bool changed = false;
         for (unsigned lm = lvlmask; lm; lm &= lm - 1u) { // colours that hold a warm arbiter, ascending
             const int lvl = __ffs((int)lm) - 1;
+            PROF_CNT(43, 1)
+            PROF_CNT(44, ballot(warm && A.level == lvl && A.count > 1) ? 1 : 0)
             if (warm && A.level == lvl) {
                 d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
                 d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
@@ -1148,8 +1154,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     const unsigned long long rm = ballot(ws && A.rank == r);
                     if (!rm) continue;
                     const int l = __ffsll((long long)rm) - 1;
-                    S.total_ke += __shfl(ke, l);
-                    S.total_imp += __shfl(imp, l);
+                    S.total_ke += readlane_f64(ke, l);
+                    S.total_imp += readlane_f64(imp, l);
                 }
             }
         }
@@ -1183,12 +1189,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (A.mb != 0.0 && ((S.evmask >> bbi) & 1ull)) wantB = true;
             }
         }
-        if (wantA) L.owner[A.slotA] = (unsigned short)(lane * 2);
-        lds_sync();
-        if (wantB) L.owner[A.slotB] = (unsigned short)(lane * 2 + 1);
-        lds_sync();
-        const bool gotA = wantA && L.owner[A.slotA] == (unsigned short)(lane * 2);
-        const bool gotB = wantB && L.owner[A.slotB] == (unsigned short)(lane * 2 + 1);
+        // a body that several arbiters want joins the list once: the first claim of this sub-step's stamp wins (one LDS atomic per side)
+        const bool gotA = wantA && atomicMax(&L.mvo[A.slotA], now) < now;
+        const bool gotB = wantB && atomicMax(&L.mvo[A.slotB], now) < now;
         const d2 v0 = L.sv[0], w0 = L.sw[0];
         // every part of the kinematic agent; the box-delivery robot is re-cached every sub-step (its controller rewrites the
         // velocity between sub-steps; re-evaluating an unmoved body reproduces the carried-over result exactly)

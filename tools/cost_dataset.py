@@ -11,7 +11,7 @@ OUT = sys.argv[4] if len(sys.argv) > 4 else "gpurun_out/cost_dataset.npz"
 trials = default_trials(0.3, 100, base_seed=0)
 env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
 env.reset()
-prof = torch.zeros((E, 48), dtype=torch.int64, device=env.device)
+prof = torch.zeros((E, 64), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 nb = torch.as_tensor(env.num_bodies(), device=env.device)

@@ -10,7 +10,7 @@ STEPS = int(sys.argv[3]) if len(sys.argv) > 3 else 12
 trials = default_trials(0.3, 100, base_seed=0)
 env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, auto_reset=True) if "auto_reset" in BatchedShipIceEnv.__init__.__code__.co_varnames else BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
 env.reset()
-prof = torch.zeros((E, 48), dtype=torch.int64, device=env.device)
+prof = torch.zeros((E, 64), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 names = ["proxy 400", "proxy last 200", "last 100", "last 50", "last 10", "nmv end", "nact end", "nslots end", "cycles"]

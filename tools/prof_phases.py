@@ -14,7 +14,7 @@ STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 14
 trials = default_trials(0.3, 100, base_seed=0)
 env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
 env.reset()
-prof = torch.zeros((E, 48), dtype=torch.int64, device=env.device)
+prof = torch.zeros((E, 64), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 names = ["integrate", "refresh", "cand+hint", "face_seps", "deliver", "filter", "prestep+warmset", "velint+warm", "solver", "post+mvlist", "manifolds"]
@@ -37,4 +37,6 @@ for t in range(STEPS):
                 ("pose", 33), ("transform", 34), ("aabb", 0), ("drain", 35), ("candidates", 27), ("cached_planes", 28), ("bound_rounds", 29), ("plane_search+resolve", 30), ("normal", 31), ("support", 32))))
             print("        per-substep: cand_rounds=%.2f rounds_with_pairs=%.2f aabb_pairs=%.2f cached_plane_queries=%.2f search_batches=%.2f searched_planes=%.2f "
                   "support_queries=%.2f" % tuple(row[k] / 400 for k in (24, 25, 36, 37, 26, 38, 39)))
+            print("        per-substep: warm_closure_iterations=%.2f recolourings=%.3f solver_iterations=%.2f colour_passes=%.2f passes_with_two_contacts=%.2f" %
+                  tuple(row[k] / 400 for k in (40, 41, 42, 43, 44)))
     env.reset(term)

@@ -13,7 +13,7 @@ E = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 env = BatchedBoxDeliveryEnv(E, cfg={"boxes": {"num_boxes_small": 12}}, num_trials=32)
 env.reset()
-prof = torch.zeros((E, 48), dtype=torch.int64, device=env.device)
+prof = torch.zeros((E, 64), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
 g = torch.Generator(device=env.device); g.manual_seed(1234)
 names = ["integrate", "refresh", "cand+hint", "face_seps", "deliver", "filter", "prestep+warmset", "velint+warm", "solver", "post+mvlist", "manifolds"]
