@@ -1099,7 +1099,10 @@ __global__ __launch_bounds__(BDR_THREADS) void k_bd_robot_map(const DevParams P,
     for (int b = 0; b < 8192; b++) {
         const int qi = b % 3;
         const int n = min(qn[qi], BD_QCAP);
-        if (n == 0) { if (++empty_run >= 3) break; continue; }   // uniform: qn is only written between the barriers below
+        // An empty bucket takes a barrier too: a wave that ran ahead into bucket b + 1 would push into qn[(b + 3) % 3] = qn[qi] while a slower wave has
+        // not read it yet, and that wave would then take the other branch (buckets can be empty between non-empty ones: a diagonal-only passage
+        // gives distances k * sqrt(2), which skip bucket 3).  After the barrier every wave has made the same decision from the same value.
+        if (n == 0) { __syncthreads(); if (++empty_run >= 3) break; continue; }
         empty_run = 0;
         const unsigned short *qq = q + qi * BD_QCAP;
         for (int base = 0; base < n; base += BDR_THREADS) {

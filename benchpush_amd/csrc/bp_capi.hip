@@ -311,6 +311,13 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
+            { int *d_done, *d_lev, *d_warn;
+              if ((rc = dalloc(h, &d_done, (size_t)h->num_envs))) return rc;
+              if ((rc = dalloc(h, &d_lev, (size_t)h->num_envs))) return rc;
+              if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
+              HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
+              h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn; }
+            if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         }
     }
@@ -329,6 +336,13 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
+            { int *d_done, *d_lev, *d_warn;
+              if ((rc = dalloc(h, &d_done, (size_t)h->num_envs))) return rc;
+              if ((rc = dalloc(h, &d_lev, (size_t)h->num_envs))) return rc;
+              if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
+              HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
+              h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn; }
+            if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         }
         HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -580,6 +594,14 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             else
                 hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+            HIPCHK(h, hipGetLastError());
+            // completion launch: workgroup b finishes the b-th env that the scheduled launch left unfinished (scheduler watchdog); normally all leave at once
+            DevParams PC = h->P;
+            PC.sq_mode = 1;
+            if (h->maze8)
+                hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(std::min(h->num_envs, 256)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
+            else
+                hipLaunchKernelGGL(k_physics_step_sched, dim3(std::min(h->num_envs, 256)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
         }
         else if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
@@ -1100,6 +1122,17 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 }
 
 int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
+
+int bp_sched_warnings(bp_handle *h, int32_t *out2_host)
+{
+    if (!h || !out2_host) return BP_EINVAL;
+    out2_host[0] = out2_host[1] = 0;
+    if (h->sched_chunk <= 0 || !h->D.sq_warn) return BP_OK;
+    BP_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out2_host, h->D.sq_warn, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return BP_OK;
+}
 
 int bp_set_step_cost_hint(bp_handle *h, const uint32_t *host_costs)
 {

@@ -33,6 +33,8 @@ struct DevParams {
     double ship_head[2], ship_tail[2];
     int obs_h, obs_w, grid_h, grid_w;
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
+    int sq_mode;                               // 0 = scheduled launch, 1 = completion launch: workgroup b finishes env b if the scheduled launch left it unfinished
+    int sq_debug;                              // test hook (BP_SCHED_DEBUG_DROP=1): env 1 is parked after its first chunk and never queued, the watchdog is short
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
     double start_x_range, ship_mass;
     unsigned long long start_seed;
@@ -66,6 +68,9 @@ struct DevPtrs {
     int *sq_ctr;             // [8][SQ_MAXLEV + 2][2]: (head, tail) per level; row SQ_MAXLEV = (finished, total) of the XCD
     unsigned *sq_carry;      // [E][4] step-local state across chunks: yaw_violated, boundary_violated, work proxy, wave cycles >> 8
     unsigned char *sq_moved; // [E][nbcap] shape moved in an earlier chunk of this step
+    int *sq_done;            // [E] the env's step is complete (cleared by k_sched_init)
+    int *sq_lev;             // [E] chunks completed when the env was last parked
+    int *sq_warn;            // [2] scheduler watchdog events, envs finished by the completion launch (cumulative; bp_sched_warnings)
     d2 *pxy;                 // [E][nbcap] position of COG
     double *ang;             // [E][nbcap]
     d2 *rot;                 // [E][nbcap] cos, sin

@@ -205,15 +205,20 @@ __device__ __forceinline__ void store_state(const DevParams &P, const DevPtrs &D
 // (envs finished, first chunks started).  D.sq_items: [8][SQ_MAXLEV][sq_cap] env | priority class << 24, -1 = claimed but not yet written.
 __device__ __forceinline__ int sq_xcc_id()
 {
+#if defined(__gfx942__) || defined(__gfx950__)
     unsigned v;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
     return (int)(v & 7u);
+#else
+    return 0; // no XCC id register: one queue set (the library is built for gfx950; this keeps other targets assembling)
+#endif
 }
 __device__ __forceinline__ int sq_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ int *sq_row(const DevPtrs &D, const int x, const int row) { return D.sq_ctr + ((size_t)x * (SQ_MAXLEV + 2) + row) * 2; }
 __device__ __forceinline__ int *sq_finished(const DevPtrs &D) { return sq_row(D, 0, SQ_MAXLEV + 1); }
 __device__ __forceinline__ int *sq_started(const DevPtrs &D) { return sq_row(D, 0, SQ_MAXLEV + 1) + 1; }
 __device__ __forceinline__ int *sq_waiting(const DevPtrs &D, const int x) { return sq_row(D, x, SQ_MAXLEV); }
+__device__ __forceinline__ int *sq_abort(const DevPtrs &D) { return sq_row(D, 1, SQ_MAXLEV + 1); }   // set by the watchdog: every poller leaves
 // lane 0: take the waiting env of XCD x that has completed the fewest chunks; -1 = nothing waiting
 __device__ __forceinline__ int sq_pop(const DevParams &P, const DevPtrs &D, const int x, int &lev)
 {
@@ -259,7 +264,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
                                              double *__restrict__ info, const int tmpl, const int boff = 0, const int c_env = 0, const int c_lev = 0,
-                                             const int c_x = 0, int *c_lev_out = nullptr)
+                                             const int c_x = 0, int *c_lev_out = nullptr, const bool c_noyield = false)
 {
     // MODE_RESET with tmpl != 0 settles the per-trial reset templates: state slot num_envs + t holds trial t
     // MODE_STEP: workgroup b steps the env at position boff + b of the dispatch order
@@ -412,7 +417,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (CHUNKED) {
             if (to_boundary == 0) { // chunk boundary: yield to an env that is further behind, otherwise carry on without a context switch
                 int yield = 0;
-                if (lane == 0) yield = sq_someone_behind(P, D, c_x, it / P.sq_chunk) ? 1 : 0;
+                if (lane == 0 && !c_noyield) yield = (sq_someone_behind(P, D, c_x, it / P.sq_chunk) || (P.sq_debug && c_env == 1 && it == P.sq_chunk)) ? 1 : 0;
                 if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = it / P.sq_chunk; break; }
                 to_boundary = P.sq_chunk;
             }
@@ -652,6 +657,7 @@ __global__ void k_sched_init(const DevParams P, const DevPtrs D)
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
     for (int i = tid; i < 8 * SQ_MAXLEV * P.sq_cap; i += nthr) D.sq_items[i] = -1;
     for (int i = tid; i < 8 * (SQ_MAXLEV + 2) * 2; i += nthr) D.sq_ctr[i] = 0;
+    for (int i = tid; i < P.num_envs; i += nthr) { D.sq_done[i] = 0; D.sq_lev[i] = 0; }
 }
 // One workgroup per (env, chunk) task: the hardware dispatcher is the persistent loop, and the step code is compiled as in k_physics_step.
 // The first num_envs workgroups start the envs in the heaviest-first order without touching a queue (first chunks come before everything else under
@@ -666,7 +672,33 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     const int lane = lane_id();
     const int home = sq_xcc_id();
     int item = -1, lev = 0, x = home;
-    if ((int)blockIdx.x < P.num_envs) {
+    const bool completion = P.sq_mode == 1;
+    if (completion) {
+        // Completion launch (always follows the scheduled one, a few hundred workgroups): workgroup b looks for the b-th env whose step is not complete
+        // and leaves at once if there is none -- the normal case.  After a scheduler fault (watchdog) such an env's state is that of its last chunk
+        // boundary: the step is resumed there and run to its end.  More unfinished envs than workgroups is reported as BP_ERR_SCHED_TIMEOUT.
+        if (sq_ld(sq_finished(D)) >= P.num_envs) return;   // every env reported its step complete
+        int before = 0, mine = -1;
+        for (int base = 0; base < P.num_envs && mine < 0; base += 64) {
+            const int e = base + lane;
+            const unsigned long long um = ballot(e < P.num_envs && D.sq_done[e] == 0);
+            const int cnt = __popcll(um);
+            if ((int)blockIdx.x < before + cnt) { // the wanted env is in this group of 64: the (blockIdx.x - before)-th set bit
+                unsigned long long m = um;
+                for (int k = (int)blockIdx.x - before; k > 0; k--) m &= m - 1;
+                mine = base + __ffsll((long long)m) - 1;
+            }
+            before += cnt;
+        }
+        if (blockIdx.x == 0 && mine >= 0) { // count what is left beyond the grid
+            int total = 0;
+            for (int base = 0; base < P.num_envs; base += 64) total += __popcll(ballot(base + lane < P.num_envs && D.sq_done[base + lane] == 0));
+            if (total > (int)gridDim.x && lane == 0) atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT);
+        }
+        if (mine < 0) return;
+        item = mine; lev = D.sq_lev[mine];
+        if (lane == 0) atomicAdd(&D.sq_warn[1], 1);
+    } else if ((int)blockIdx.x < P.num_envs) {
         const int pos = (int)blockIdx.x;
         // issue-priority class of the env for the whole step: the heaviest quarter of the predicted order 3, the next quarter 1
         const int cls = (pos < P.num_envs / 4) ? 3 : (pos < P.num_envs / 2) ? 1 : 0;
@@ -674,13 +706,15 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         if (lane == 0) atomicAdd(sq_started(D), 1);
     } else {
         if (lane == 0) {
+            const int limit = P.sq_debug ? 64 : (1 << 20);
             for (int idle = 0;; idle++) {
                 item = sq_pop(P, D, home, lev);
                 if (item < 0 && (idle & 3) == 3)
                     for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev); if (item >= 0) x = y; }
-                if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs) break;
-                // watchdog: ~20 s of empty polls can only mean a scheduler fault -- flag it and leave rather than hold the GPU
-                if (idle > (1 << 20)) { atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT); break; }
+                if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs || sq_ld(sq_abort(D)) != 0) break;
+                // watchdog: ~20 s of empty polls can only mean a scheduler fault -- raise the abort flag (every poller leaves on it) and leave rather
+                // than hold the GPU; the completion launch finishes the envs that are still parked
+                if (idle > limit) { if (atomicExch(sq_abort(D), 1) == 0) atomicAdd(&D.sq_warn[0], 1); break; }
                 for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
             }
         }
@@ -692,12 +726,15 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
     int lev_out = lev + 1;
-    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out);
+    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, completion);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
-        if (done) atomicAdd(sq_finished(D), 1);
-        else sq_push(P, D, x, lev_out, item);
+        if (done) { D.sq_done[env] = 1; if (!completion) atomicAdd(sq_finished(D), 1); }
+        else {
+            D.sq_lev[env] = lev_out;
+            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x, lev_out, item);   // test hook: the item is lost
+        }
     }
 }
 __global__ __launch_bounds__(64, 2) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,

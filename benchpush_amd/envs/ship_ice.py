@@ -226,6 +226,12 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_get_step_cycles(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_step_cycles")
         return out.astype(np.uint64) << 8
 
+    def sched_warnings(self):
+        """(watchdog events, envs finished by the completion launch) of the step scheduler since load: (0, 0) unless a scheduler fault occurred."""
+        out = np.zeros(2, np.int32)
+        _lib.check(self.L, self.h, self.L.bp_sched_warnings(self.h, out.ctypes.data_as(C.c_void_p)), "bp_sched_warnings")
+        return int(out[0]), int(out[1])
+
     def sched_chunk(self):
         """Sub-steps per chunk of the preemptive step scheduler, 0 = one wavefront per env for the whole step."""
         return int(self.L.bp_sched_chunk(self.h))

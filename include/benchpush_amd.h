@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 6
+#define BP_ABI_VERSION 7
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -43,7 +43,8 @@ enum { BP_ENV_SHIP_ICE = 0, BP_ENV_MAZE = 1, BP_ENV_BOX = 2 };
 
 /* per-env error bits reported by bp_check_errors */
 enum { BP_ERR_ADJ_OVERFLOW = 1, BP_ERR_ARB_OVERFLOW = 2, BP_ERR_LEVEL_OVERFLOW = 4,
-       BP_ERR_SCHED_TIMEOUT = 8 /* a workgroup of the step scheduler gave up waiting for a parked env (env 0 carries the flag): the step is incomplete */ };
+       BP_ERR_SCHED_TIMEOUT = 8 /* a scheduler fault left more envs unfinished than the completion launch can finish (256): the step is incomplete;
+                                   smaller faults are finished by the completion launch and counted by bp_sched_warnings (ABI 7) */ };
 
 /* info[e][k] columns written by bp_step / bp_reset (ship_ice_env.py:337-345 plus the callback
  * bookkeeping of :150-180); state is raw (the host adapter applies round(.,2)). */
@@ -214,6 +215,10 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
  * behind, and resumed by another workgroup; results are identical), 0 = one wavefront per env for the whole step.  Default 40 for ship-ice and
  * maze handles of up to 8192 envs; environment variable BP_SCHED=<chunk> (0 = off) overrides it at load time. */
 int32_t bp_sched_chunk(bp_handle *h);
+/* Scheduler robustness counters since bp_load_*: out2_host[0] = launches in which the watchdog of the step scheduler fired (a workgroup gave up
+ * waiting for a parked env -- a scheduler fault, never seen in practice), out2_host[1] = envs whose step the completion launch that follows every
+ * scheduled launch had to finish.  Results are complete and identical either way; non-zero values are a warning, not an error (synchronises). */
+int bp_sched_warnings(bp_handle *h, int32_t *out2_host);
 /* overrides that hint for the next bp_step: host uint32 [E], larger = dispatched earlier (results never depend on the order; synchronises) */
 int bp_set_step_cost_hint(bp_handle *h, const uint32_t *host_costs);
 

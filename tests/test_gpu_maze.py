@@ -125,6 +125,45 @@ def test_full_size_properties_4096_envs():
     env.check_errors()
 
 
+def test_scheduler_parks_and_resumes_maze_envs_bit_identically(monkeypatch):
+    """k_physics_step_sched_maze at full size (4096 envs x 60 steps with auto-reset, thousands of envs parked and resumed): the default scheduler and a
+    ragged chunk size leave every env in exactly the state of the one-env-per-wavefront kernel (BP_SCHED=0) -- body state (incl. the five kinematic robot
+    slots reloaded from velv), rewards, termination (sticky wall flag carried through D.sq_carry), observations, info and episode metrics."""
+    from benchpush_amd.envs.maze_namo import BatchedMazeEnv
+    E, T, steps = 4096, 16, 60
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(9)
+    acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
+    acts[:, 0::4] = 1.0                                        # hard-over: these envs end on a wall and restart inside the window
+    acts[:, 1::4] = -1.0
+
+    def run(env_vars):
+        monkeypatch.delenv("BP_SCHED", raising=False)
+        for k, v in env_vars.items():
+            monkeypatch.setenv(k, v)
+        env = BatchedMazeEnv(E, cfg={"num_obstacles": 20}, num_layouts=T, base_seed=2, device="cuda:0")
+        env.reset()
+        rsum = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+        nterm = 0
+        for t in range(steps):
+            obs, rew, term, _, info = env.step(acts[t])
+            rsum += rew
+            nterm += int(term.sum().item())
+            env.reset(term)
+        env.check_errors()
+        out = (env.body_state().clone(), rsum, env.obs.clone(), env.info.clone(), env.episode_metrics()[0].clone(), nterm)
+        env.close()
+        return out
+
+    ref = run({"BP_SCHED": "0"})
+    assert ref[5] > 100                                        # episodes ended (wall hits) and restarted inside the window
+    for variant in ({}, {"BP_SCHED": "37"}):
+        got = run(variant)
+        for a, b in zip(ref[:5], got[:5]):
+            assert torch.equal(a, b), variant
+        assert got[5] == ref[5]
+
+
 def test_episode_metrics_equal_host_maze_namo_metric():
     """On-device episode rows (bp_get_episode_metrics) == MazeNamoMetric.reset / update (maze_namo_metric.py:25-75) fed step by step:
     L from the wavefront map at the rounded start pixel, path length from the rounded state, effort with the robot's mass."""

@@ -324,6 +324,46 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
         assert got[5] == ref[5]
 
 
+def test_scheduler_fault_is_finished_by_the_completion_launch(monkeypatch):
+    """Scheduler fault path (bp_kernels.hpp: sched_body): with the test hook BP_SCHED_DEBUG_DROP=1 env 1 is parked after its first chunk and its queue
+    item is dropped, so the scheduled launch cannot finish it; the pollers leave on the (short) watchdog and the completion launch that follows every
+    scheduled launch resumes the env at its chunk boundary.  Results equal the unscheduled kernel's bit for bit, the fault is reported as a warning."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    trials = default_trials(0.3, 3, base_seed=5)
+    E, steps = 9, 12
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(11)
+    acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
+
+    def run(env_vars):
+        for k in ("BP_SCHED", "BP_SCHED_DEBUG_DROP"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env_vars.items():
+            monkeypatch.setenv(k, v)
+        env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+        env.reset()
+        rews = []
+        for t in range(steps):
+            obs, rew, term, _, info = env.step(acts[t])
+            rews.append(rew.clone())
+            env.reset(term)
+        env.check_errors()
+        out = (env.body_state().clone(), torch.stack(rews), env.obs.clone(), env.info.clone(), env.sched_warnings())
+        env.close()
+        return out
+
+    ref = run({"BP_SCHED": "0"})
+    got = run({"BP_SCHED_DEBUG_DROP": "1"})
+    for a, b in zip(ref[:4], got[:4]):
+        assert torch.equal(a, b)
+    assert ref[4] == (0, 0)
+    assert got[4][0] == steps and got[4][1] == steps          # one watchdog event and one env finished by the completion launch per step
+    clean = run({})
+    assert clean[4] == (0, 0)
+    for a, b in zip(ref[:4], clean[:4]):
+        assert torch.equal(a, b)
+
+
 def test_gym_adapter_surface_and_metric_plumbing():
     import benchpush_amd
     from benchpush_amd.envs.ship_ice import default_trials
