@@ -15,6 +15,7 @@ BD_MAXBOX, BD_MAXWP = 24, 64
 BD_INFO_KEYS = ["x", "y", "theta", "cumulative_distance", "cumulative_boxes", "cumulative_reward", "total_work", "ministeps", "inactivity",
                 "robot_hit_obstacle", "substeps", "robot_distance", "boxes_distance", "num_waypoints", "num_boxes_left", "work"]
 INFO_COUNT = 16
+EPM_COUNT, EPM_RING = 6, 8
 INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scaled_collision_reward", "dist_reward",
              "trial_success", "boundary_violated", "yaw_violated", "total_ke", "total_impulse", "n_post_solve",
              "n_contact_pts", "n_first_contact"]
@@ -23,7 +24,7 @@ EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp
            "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_costmap_update", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_set_step_cost_hint", "bp_sched_chunk", "bp_sched_warnings", "bp_last_error",
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
-           "bp_get_episode_metrics", "bp_start_uniform", "bp_debug_round2"]
+           "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2"]
 
 
 class BpCostmapConfig(C.Structure):
@@ -111,6 +112,8 @@ def load():
     L.bp_get_body_state.argtypes = [vp, vp, vp]
     L.bp_get_low_dim_obs.argtypes = [vp, vp, vp]
     L.bp_get_episode_metrics.argtypes = [vp, vp, vp, vp]
+    if hasattr(L, "bp_get_episode_history"):
+        L.bp_get_episode_history.argtypes = [vp, vp, vp, vp, vp]
     L.bp_start_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64]
     L.bp_start_uniform.restype = C.c_double
     L.bp_debug_round2.argtypes = [vp, vp, C.c_int32, vp]

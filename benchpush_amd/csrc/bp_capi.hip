@@ -282,6 +282,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     if ((rc = dalloc(h, &D.e_lastflag, E))) return rc;
     if ((rc = dalloc(h, &D.m_acc, E * 8))) return rc;
     if ((rc = dalloc(h, &D.m_rows, E * BP_EPM_COUNT))) return rc;
+    if ((rc = dalloc(h, &D.m_ring, E * BP_EPM_RING * BP_EPM_COUNT))) return rc;
+    if ((rc = dalloc(h, &D.m_sum, E * BP_EPM_COUNT))) return rc;
     if ((rc = dalloc(h, &D.m_count, E))) return rc;
     if ((rc = dalloc(h, &D.m_open, E))) return rc;
     D.dbg = nullptr; D.dbg_env = -1; D.prof = nullptr;
@@ -311,7 +313,9 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
-            { int *d_done, *d_lev, *d_warn;
+            { int *d_done, *d_lev, *d_warn, *d_resc;
+              if ((rc = dalloc(h, &d_resc, (size_t)1 + SQ_RESCUE))) return rc;
+              h->D.sq_rescue = d_resc;
               if ((rc = dalloc(h, &d_done, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_lev, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
@@ -336,7 +340,9 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
-            { int *d_done, *d_lev, *d_warn;
+            { int *d_done, *d_lev, *d_warn, *d_resc;
+              if ((rc = dalloc(h, &d_resc, (size_t)1 + SQ_RESCUE))) return rc;
+              h->D.sq_rescue = d_resc;
               if ((rc = dalloc(h, &d_done, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_lev, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
@@ -495,7 +501,11 @@ __global__ __launch_bounds__(256) void k_episode_metrics(const DevParams P, cons
         r[BP_EPM_EFFICIENCY] = (success != 0.0) ? L / l0 : 0.0;   // compute_efficiency_score
         r[BP_EPM_EFFORT] = own / (own + work);                    // compute_effort_score
         r[BP_EPM_REWARD] = a[0]; r[BP_EPM_SUCCESS] = success; r[BP_EPM_LENGTH] = a[5]; r[BP_EPM_TOTAL_WORK] = work;
-        D.m_count[env] += 1u;
+        // the lists of BaseMetric (base_metric.py:12-16): ring of the last episodes and running sums over all of them
+        const unsigned n = D.m_count[env];
+        double *ring = D.m_ring + ((size_t)env * BP_EPM_RING + n % BP_EPM_RING) * BP_EPM_COUNT, *sum = D.m_sum + (size_t)env * BP_EPM_COUNT;
+        for (int q = 0; q < BP_EPM_COUNT; q++) { ring[q] = r[q]; sum[q] += r[q]; }
+        D.m_count[env] = n + 1u;
     };
     if (mode == 1) {
         if (mask != nullptr && mask[env] == 0) return;
@@ -596,12 +606,17 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             HIPCHK(h, hipGetLastError());
             // completion launch: workgroup b finishes the b-th env that the scheduled launch left unfinished (scheduler watchdog); normally all leave at once
-            DevParams PC = h->P;
-            PC.sq_mode = 1;
-            if (h->maze8)
-                hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(std::min(h->num_envs, 256)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
-            else
-                hipLaunchKernelGGL(k_physics_step_sched, dim3(std::min(h->num_envs, 256)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
+            static const bool completion = !(getenv("BP_SCHED_COMPLETION") && atoi(getenv("BP_SCHED_COMPLETION")) == 0);   // diagnostic switch
+            if (completion) {
+                hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(256), 0, st, h->P, h->D);
+                HIPCHK(h, hipGetLastError());
+                DevParams PC = h->P;
+                PC.sq_mode = 1;
+                if (h->maze8)
+                    hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
+                else
+                    hipLaunchKernelGGL(k_physics_step_sched, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
+            }
         }
         else if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
@@ -753,6 +768,20 @@ int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *s
     BP_DEVICE(h);
     if (rows) HIPCHK(h, hipMemcpyAsync(rows, h->D.m_rows, sizeof(double) * BP_EPM_COUNT * h->num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->D.m_count, sizeof(unsigned) * h->num_envs, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BP_OK;
+}
+
+int bp_get_episode_history(bp_handle *h, double *ring, double *sums, uint32_t *counts, void *stream)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    if (h->P.env_kind != BP_ENV_SHIP_ICE && h->P.env_kind != BP_ENV_MAZE)
+        return fail(h, BP_EINVAL, "episode metrics are kept for ship-ice and maze handles only");
+    BP_DEVICE(h);
+    const size_t E = (size_t)h->num_envs;
+    if (ring) HIPCHK(h, hipMemcpyAsync(ring, h->D.m_ring, sizeof(double) * BP_EPM_RING * BP_EPM_COUNT * E, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (sums) HIPCHK(h, hipMemcpyAsync(sums, h->D.m_sum, sizeof(double) * BP_EPM_COUNT * E, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (counts) HIPCHK(h, hipMemcpyAsync(counts, h->D.m_count, sizeof(unsigned) * E, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BP_OK;
 }
 

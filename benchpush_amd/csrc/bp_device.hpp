@@ -70,6 +70,7 @@ struct DevPtrs {
     unsigned char *sq_moved; // [E][nbcap] shape moved in an earlier chunk of this step
     int *sq_done;            // [E] the env's step is complete (cleared by k_sched_init)
     int *sq_lev;             // [E] chunks completed when the env was last parked
+    int *sq_rescue;          // [1 + SQ_RESCUE] count and ids of the envs the scheduled launch left unfinished (k_sched_scan)
     int *sq_warn;            // [2] scheduler watchdog events, envs finished by the completion launch (cumulative; bp_sched_warnings)
     d2 *pxy;                 // [E][nbcap] position of COG
     double *ang;             // [E][nbcap]
@@ -88,6 +89,8 @@ struct DevPtrs {
     int *e_lastflag;         // [E] bit0 terminated, bit1 trial_success
     double *m_acc;           // [E][8] episode reward, path length l0, previous rounded x, y, L, steps, total_work, success
     double *m_rows;          // [E][BP_EPM_COUNT] most recently finished episode
+    double *m_ring;          // [E][BP_EPM_RING][BP_EPM_COUNT] the last BP_EPM_RING finished episodes (episode n in slot n % BP_EPM_RING)
+    double *m_sum;           // [E][BP_EPM_COUNT] row fields summed over all finished episodes
     unsigned *m_count;       // [E] finished episodes
     unsigned char *m_open;   // [E] an episode is running (reset seen, not yet terminated)
     // debug

@@ -659,6 +659,23 @@ __global__ void k_sched_init(const DevParams P, const DevPtrs D)
     for (int i = tid; i < 8 * (SQ_MAXLEV + 2) * 2; i += nthr) D.sq_ctr[i] = 0;
     for (int i = tid; i < P.num_envs; i += nthr) { D.sq_done[i] = 0; D.sq_lev[i] = 0; }
 }
+// After the scheduled launch: the envs whose step is not complete (none, unless the scheduler's watchdog fired) are listed for the completion launch;
+// more than SQ_RESCUE of them is reported as BP_ERR_SCHED_TIMEOUT (the step is then incomplete).
+#define SQ_RESCUE 256
+__global__ __launch_bounds__(256) void k_sched_scan(const DevParams P, const DevPtrs D)
+{
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    if (sq_ld(sq_finished(D)) < P.num_envs)
+        for (int e = threadIdx.x; e < P.num_envs; e += blockDim.x)
+            if (D.sq_done[e] == 0) { const int pos = atomicAdd(&cnt, 1); if (pos < SQ_RESCUE) D.sq_rescue[1 + pos] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        D.sq_rescue[0] = min(cnt, SQ_RESCUE);
+        if (cnt > SQ_RESCUE) atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT);
+    }
+}
 // One workgroup per (env, chunk) task: the hardware dispatcher is the persistent loop, and the step code is compiled as in k_physics_step.
 // The first num_envs workgroups start the envs in the heaviest-first order without touching a queue (first chunks come before everything else under
 // the least-advanced-first rule anyway, and workgroups are dispatched in index order); every later workgroup takes the least-advanced waiting env of
@@ -674,29 +691,11 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     int item = -1, lev = 0, x = home;
     const bool completion = P.sq_mode == 1;
     if (completion) {
-        // Completion launch (always follows the scheduled one, a few hundred workgroups): workgroup b looks for the b-th env whose step is not complete
-        // and leaves at once if there is none -- the normal case.  After a scheduler fault (watchdog) such an env's state is that of its last chunk
-        // boundary: the step is resumed there and run to its end.  More unfinished envs than workgroups is reported as BP_ERR_SCHED_TIMEOUT.
-        if (sq_ld(sq_finished(D)) >= P.num_envs) return;   // every env reported its step complete
-        int before = 0, mine = -1;
-        for (int base = 0; base < P.num_envs && mine < 0; base += 64) {
-            const int e = base + lane;
-            const unsigned long long um = ballot(e < P.num_envs && D.sq_done[e] == 0);
-            const int cnt = __popcll(um);
-            if ((int)blockIdx.x < before + cnt) { // the wanted env is in this group of 64: the (blockIdx.x - before)-th set bit
-                unsigned long long m = um;
-                for (int k = (int)blockIdx.x - before; k > 0; k--) m &= m - 1;
-                mine = base + __ffsll((long long)m) - 1;
-            }
-            before += cnt;
-        }
-        if (blockIdx.x == 0 && mine >= 0) { // count what is left beyond the grid
-            int total = 0;
-            for (int base = 0; base < P.num_envs; base += 64) total += __popcll(ballot(base + lane < P.num_envs && D.sq_done[base + lane] == 0));
-            if (total > (int)gridDim.x && lane == 0) atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT);
-        }
-        if (mine < 0) return;
-        item = mine; lev = D.sq_lev[mine];
+        // Completion launch (always follows the scheduled one and k_sched_scan, SQ_RESCUE workgroups): workgroup b takes the b-th env of the list of
+        // unfinished envs and leaves at once if the list is shorter -- the normal case: it is empty.  After a scheduler fault (watchdog) such an env's
+        // state is that of its last chunk boundary: the step is resumed there and run to its end.
+        if ((int)blockIdx.x >= D.sq_rescue[0]) return;
+        item = D.sq_rescue[1 + blockIdx.x]; lev = D.sq_lev[item];
         if (lane == 0) atomicAdd(&D.sq_warn[1], 1);
     } else if ((int)blockIdx.x < P.num_envs) {
         const int pos = (int)blockIdx.x;

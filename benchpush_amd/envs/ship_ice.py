@@ -200,6 +200,26 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_get_episode_metrics(self.h, _ptr(rows), _ptr(cnt), self._stream()), "bp_get_episode_metrics")
         return rows, cnt
 
+    def episode_history(self):
+        """The episode lists of BaseMetric (base_metric.py:12-16) kept on the device: (ring [E, 8, 6] float64: the last 8 finished episodes of each
+        env, episode n in slot n % 8; sums [E, 6] float64: the six row fields summed over all finished episodes; counts [E] int32).  No host
+        round trip per step is needed to follow the episodes: see episode_lists() and benchpush_amd.parallel.gather_episode_sums."""
+        ring = torch.zeros((self.num_envs, _lib.EPM_RING, _lib.EPM_COUNT), dtype=torch.float64, device=self.device)
+        sums = torch.zeros((self.num_envs, _lib.EPM_COUNT), dtype=torch.float64, device=self.device)
+        cnt = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self.L, self.h, self.L.bp_get_episode_history(self.h, _ptr(ring), _ptr(sums), _ptr(cnt), self._stream()), "bp_get_episode_history")
+        return ring, sums, cnt
+
+    def episode_lists(self):
+        """Per env, the rows of its finished episodes in order (the last 8 at most): a list of E float64 arrays [n_e, 6] (host)."""
+        ring, _, cnt = self.episode_history()
+        ring, cnt = ring.cpu().numpy(), cnt.cpu().numpy()
+        out = []
+        for e in range(self.num_envs):
+            n = int(cnt[e])
+            out.append(np.stack([ring[e, k % _lib.EPM_RING] for k in range(max(0, n - _lib.EPM_RING), n)]) if n else np.zeros((0, _lib.EPM_COUNT)))
+        return out
+
     def start_uniform(self, env, episode):
         """The uniform of the counter RNG that places env's ship in `episode` when cfg.random_start is set (bp_start_uniform)."""
         return float(self.L.bp_start_uniform(int(self.params["start_seed"]), int(self.env_id_offset) + int(env), int(episode)))

@@ -39,6 +39,23 @@ def gather_episode_block(rows, counts, dist=None):
     return allb[:, :-1].contiguous(), allb[:, -1].to(torch.int64)
 
 
+def gather_episode_sums(sums, counts, dist=None):
+    """The per-rank [E/R, 6] sums over ALL finished episodes of every env (BatchedShipIceEnv.episode_history()) plus the episode counts -> the whole
+    job's ([E, 6], [E]) in global env order: one all-gather of a fixed [E/R, 7] float64 block per evaluation, whatever the number of episodes."""
+    block = torch.cat([sums.to(torch.float64), counts.to(torch.float64).reshape(-1, 1)], dim=1)
+    allb = allgather_episode_metrics(block, dist)
+    return allb[:, :-1].contiguous(), allb[:, -1].to(torch.int64)
+
+
+def summarize_episode_sums(sums, counts):
+    """Means over every finished episode of the job -- the averages of BaseMetric's lists (base_metric.py:12-16)."""
+    n = int(counts.sum().item())
+    if n == 0:
+        return {"episodes": 0}
+    mean = (sums.to(torch.float64).sum(dim=0) / n).tolist()
+    return {"episodes": n, "efficiency": mean[0], "effort": mean[1], "reward": mean[2], "success_rate": mean[3], "length": mean[4], "total_work": mean[5]}
+
+
 def summarize_episode_block(rows, counts):
     """Means over the envs that have finished at least one episode -- what BaseMetric's lists hold per algorithm
     (base_metric.py:12-16) reduced to scalars: efficiency, effort, reward, success rate, episode length, total work."""

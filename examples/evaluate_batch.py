@@ -1,7 +1,7 @@
 """Batched counterpart of BasePolicy.evaluate (benchpush/baselines/ship_ice_nav/ppo/policy.py:73-99): run a policy on E environments until
 every env has finished `episodes` episodes and report the benchmark's scores -- efficiency, effort, reward, success -- from the on-device
-episode metrics (no per-step host round trip).  Multi-GPU: launch with torch.distributed.run; every rank owns E envs and the [E/R, 6] episode
-rows are all-gathered once at the end.
+episode lists (ring of the last episodes + sums over all of them: no per-step host round trip, one check every 50 steps).  Multi-GPU: launch with
+torch.distributed.run; every rank owns E envs and the [E/R, 7] block of sums and counts is all-gathered once at the end.
 
     python examples/evaluate_batch.py [E=1024] [episodes=2] [concentration=0.3]
 """
@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
-from benchpush_amd.parallel import gather_episode_block, summarize_episode_block
+from benchpush_amd.parallel import gather_episode_sums, summarize_episode_sums
 
 
 def straight_ahead_policy(obs, info):
@@ -33,27 +33,25 @@ def main():
                             device="cuda:%d" % int(os.environ.get("LOCAL_RANK", "0")))
     obs, info = env.reset()
     age = torch.zeros(E, dtype=torch.int64, device=env.device)
-    sums = torch.zeros(6, dtype=torch.float64, device=env.device)
-    nfin = 0
-    finished = torch.zeros(E, dtype=torch.int64, device=env.device)
-    while int(finished.min().item()) < episodes:
+    steps = 0
+    while True:
         obs, rew, term, trunc, info = env.step(straight_ahead_policy(obs, info))
         age += 1
         done = term.bool() | (age >= 300)                      # TimeLimit of the registered id (environments/__init__.py:6)
-        if bool(done.any()):
-            env.reset(done)                                    # a reset of a running episode closes it as truncated
-            rows, cnt = env.episode_metrics()                  # rows of the envs that just finished are fresh
-            sums += rows[done].sum(dim=0)
-            nfin += int(done.sum().item())
-            finished += done.to(torch.int64)
-            age[done] = 0
+        obs, info = env.reset(done)                            # device mask, no host round trip: a reset of a running episode closes it as truncated,
+        age = torch.where(done, torch.zeros_like(age), age)    # and the returned obs / info carry the first observation of the new episodes
+        steps += 1
+        if steps % 50 == 0:                                    # the only host synchronisation: every 50 steps, are we there yet?
+            _, _, cnt = env.episode_history()
+            if int(cnt.min().item()) >= episodes:
+                break
     env.check_errors()
-    rows, cnt = env.episode_metrics()
-    allr, allc = gather_episode_block(rows, cnt, dist)
+    ring, sums, cnt = env.episode_history()                    # every finished episode is accounted on the device (lists: env.episode_lists())
+    alls, allc = gather_episode_sums(sums, cnt, dist)          # one [E/R, 7] all-gather for the whole evaluation
     if rank == 0:
-        mean = (sums / max(nfin, 1)).tolist()
-        print("rank 0: %d episodes: efficiency %.3f effort %.3f reward %.1f success %.2f length %.1f total_work %.2f" % (nfin, *mean))
-        print("all ranks, last episode of every env:", summarize_episode_block(allr, allc))
+        print("all ranks, every finished episode:", summarize_episode_sums(alls, allc))
+        lists = env.episode_lists()
+        print("rank 0, env 0: %d episodes, efficiency / effort of the last ones:" % int(cnt[0].item()), [tuple(round(float(v), 3) for v in r[:2]) for r in lists[0][-3:]])
     if dist is not None:
         dist.destroy_process_group()
 

@@ -195,6 +195,14 @@ int bp_get_low_dim_obs(bp_handle *h, double *out, void *stream);
 #define BP_EPM_COUNT 6
 enum { BP_EPM_EFFICIENCY = 0, BP_EPM_EFFORT, BP_EPM_REWARD, BP_EPM_SUCCESS, BP_EPM_LENGTH, BP_EPM_TOTAL_WORK };
 int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *stream);
+/* The episode LISTS that BaseMetric keeps (base_metric.py:12-16: one entry per finished episode), without a host round trip per step:
+ *   ring   device double [E][BP_EPM_RING][BP_EPM_COUNT]: episode n of an env (n = 0, 1, ...) is in slot n % BP_EPM_RING, so the last BP_EPM_RING
+ *          finished episodes of every env are available in order,
+ *   sums   device double [E][BP_EPM_COUNT]: the six row fields summed over ALL finished episodes of the env (the means of an evaluation are
+ *          sums / counts; [E][7] with the count is the block that crosses GPUs),
+ *   counts device uint32 [E] episodes finished so far.  Any pointer may be NULL. */
+#define BP_EPM_RING 8
+int bp_get_episode_history(bp_handle *h, double *ring, double *sums, uint32_t *counts, void *stream);
 /* test hook: out[i] = the device's restatement of python's round(in[i], 2) (device doubles [n]) */
 int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream);
 

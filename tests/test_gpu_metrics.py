@@ -102,6 +102,60 @@ def test_episode_metrics_equal_host_ship_ice_metric():
     env.close()
 
 
+def test_episode_lists_equal_host_metric_lists_without_per_step_sync():
+    """bp_get_episode_history: the ring of the last episodes and the running sums equal the LISTS ShipIceMetric keeps (base_metric.py:12-16,
+    ship_ice_metric.py:57-60) over >= 3 episodes per env, with the device never consulted between steps: the loop only records what it feeds the host
+    metric; the device buffers are read once at the end."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    from benchpush_amd.metrics import ShipIceMetric
+    E, T = 5, 3
+    trials = default_trials(0.3, T, base_seed=21, goal_y=2.2)
+    env = _mk(E, 0.3, trials, goal_y=2.2)
+    mass = float(env.cfg.ship.mass)
+    host = [ShipIceMetric("x", ship_mass=mass, goal=env.goal) for _ in range(E)]
+
+    def info_dict(row):
+        return {"state": (round(float(row[0]), 2), round(float(row[1]), 2), round(float(row[2]), 2)), "total_work": float(row[3]),
+                "trial_success": bool(row[8])}
+
+    _, info = env.reset()
+    for e in range(E):
+        host[e].reset(info_dict(info[e].cpu().numpy()))
+    rng = np.random.default_rng(4)
+    lengths, all_len = np.zeros(E, int), [[] for _ in range(E)]
+    for t in range(90):
+        a = rng.uniform(-0.3, 0.3, E)
+        _, rew, term, _, info = env.step(torch.from_numpy(a))
+        inf, rw, tm = info.cpu().numpy(), rew.cpu().numpy(), term.cpu().numpy().astype(bool)   # (the reset below rewrites the info rows it resets)
+        _, info2 = env.reset(term)                         # device mask; rows of finished envs restart
+        inf2 = info2.cpu().numpy()
+        lengths += 1
+        for e in range(E):
+            host[e].update(info_dict(inf[e]), float(rw[e]), eps_complete=bool(tm[e]))
+            if tm[e]:
+                all_len[e].append(int(lengths[e])); lengths[e] = 0
+                host[e].reset(info_dict(inf2[e]))
+    ring, sums, cnt = env.episode_history()
+    lists = env.episode_lists()
+    ring, sums, cnt = ring.cpu().numpy(), sums.cpu().numpy(), cnt.cpu().numpy()
+    assert cnt.min() >= 3 and cnt.max() > 8                     # enough episodes, and the ring has wrapped for some env
+    for e in range(E):
+        n = int(cnt[e])
+        assert n == len(host[e].rewards) == len(host[e].efficiency_scores) == len(host[e].effort_scores) == len(all_len[e])
+        got = lists[e]
+        k0 = max(0, n - 8)
+        assert got.shape == (n - k0, 6)
+        for i, k in enumerate(range(k0, n)):
+            assert got[i, 2] == host[e].rewards[k] and got[i, 4] == all_len[e][k]
+            assert math.isclose(got[i, 0], host[e].efficiency_scores[k], rel_tol=1e-12, abs_tol=0.0)
+            assert math.isclose(got[i, 1], host[e].effort_scores[k], rel_tol=1e-12, abs_tol=0.0)
+        assert math.isclose(sums[e, 2], sum(host[e].rewards), rel_tol=1e-12, abs_tol=1e-9)
+        assert math.isclose(sums[e, 0], sum(host[e].efficiency_scores), rel_tol=1e-12) and math.isclose(sums[e, 1], sum(host[e].effort_scores), rel_tol=1e-12)
+        assert sums[e, 4] == sum(all_len[e])
+    env.check_errors()
+    env.close()
+
+
 def test_random_start_matches_oracle_and_redraws_every_episode():
     """cfg.random_start (ship_ice_env.py:201-203): start = (1 + u * (start_x_range - 1), 1, pi/2) drawn per (env, episode) from the counter
     RNG, then the 1000 settle sub-steps with the ship there; bit-identical to the oracle reset with that start."""

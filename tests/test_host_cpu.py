@@ -177,6 +177,19 @@ allr, allc = gather_episode_block(rows, cnt, dist)
 wr, wc = rows_of(0, E)
 assert allr.shape == (E, 6) and torch.equal(allr, wr) and torch.equal(allc, wc.to(torch.int64))
 assert summarize_episode_block(allr, allc) == summarize_episode_block(wr, wc.to(torch.int64))
+# the episode-list payload: [E/R, 6] sums over ALL finished episodes + counts (BatchedShipIceEnv.episode_history) -> means over every episode of the job
+from benchpush_amd.parallel import gather_episode_sums, summarize_episode_sums
+def sums_of(lo, hi):
+    g = torch.arange(lo, hi, dtype=torch.float64)
+    cnt = (1 + g %% 4).to(torch.int32)       # 1..4 finished episodes per env
+    per = torch.stack([0.5 + g / 100, 0.9 - g / 100, -3.0 * g, (g %% 2), 30 + g, 0.25 * g], dim=1)
+    return per * cnt.to(torch.float64).reshape(-1, 1), cnt
+sums, cnt = sums_of(lo, hi)
+alls, allc = gather_episode_sums(sums, cnt, dist)
+ws, wc = sums_of(0, E)
+assert alls.shape == (E, 6) and torch.equal(alls, ws) and torch.equal(allc, wc.to(torch.int64))
+s = summarize_episode_sums(alls, allc)
+assert s["episodes"] == int(wc.sum()) and abs(s["reward"] - float(ws[:, 2].sum() / wc.sum())) < 1e-12
 dist.barrier(); dist.destroy_process_group()
 print("ok", rank)
 '''
