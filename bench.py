@@ -231,6 +231,7 @@ def main():
     for t in range(W):
         one_step(t)
     torch.cuda.synchronize()
+    clk0 = env.clock_stamps() if hasattr(env, "clock_stamps") and args.env in ("ship-ice", "maze") else None
     env.enable_timing(True)
     if dist is not None:
         dist.barrier()
@@ -246,6 +247,9 @@ def main():
     phys_ms, rast_ms, nlaunch = env.kernel_time_ms()
     env.enable_timing(False)
     env.check_errors()
+    # clock the chip held over the timed region: shader-clock counter against the 100 MHz reference, both stamped on the device after every step
+    clk1 = env.clock_stamps() if clk0 is not None else None
+    clock_hz = ((clk1[0] - clk0[0]) / max(clk1[1] - clk0[1], 1) * 1e8) if clk1 is not None and clk1[1] > clk0[1] else None
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
     if dist is not None:
@@ -305,10 +309,12 @@ def main():
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
         # (profiles/r02_final/pmc.json, written by tools/profile_gpu.sh for the build named inside), never measured in this run
-        pmc = profile_sourced(os.path.join("r02_final", "pmc.json")) if args.env == "ship-ice" else None
-        clock_hz = 2.4e9
+        pmc = profile_sourced(os.path.join("r03_final", "pmc.json")) if args.env == "ship-ice" else None
         roof = {
-            "bound": "hbm",
+            "bound": "issue",
+            "accounting": "achieved / peak / frac are the HBM accounting of SURVEY 8d (algorithmic bytes per launch / kernel time against 8 TB/s); what binds "
+                          "the kernel is named in 'bound' / 'binds', and 'issue' gives its share of the chip's wave-instruction issue slots",
+            "clock_mhz": (clock_hz / 1e6) if clock_hz else None,
             "kernel": ("k_physics_step_sched" if sched_chunk > 0 else "k_physics_step"),
             "scheduler": ({"chunk_substeps": sched_chunk, "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
                            "least-advanced waiting env first (DESIGN.md 4a); BP_SCHED=0 selects one wavefront per env for the whole step"}
@@ -332,13 +338,17 @@ def main():
             insts = sum(per.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
             scale = E / float(pmc.get("envs", E))
             roof["traffic"] = pmc.get("hbm_bytes_per_launch")
-            roof["traffic_source"] = "profiles/r02_final/pmc.json (rocprofv3 --pmc passes of build %s, %s envs; not measured in this run)" % (
+            roof["wasted_traffic"] = (roof["traffic"] / (a_phys * E)) if roof["traffic"] else None
+            roof["traffic_source"] = "profiles/r03_final/pmc.json (rocprofv3 --pmc passes of build %s, %s envs; not measured in this run)" % (
                 pmc.get("build", "?"), pmc.get("envs", "?"))
+            ck = clock_hz if clock_hz else 2.1e9
+            insts += per.get("SQ_INSTS_BRANCH", 0.0)
             roof["issue"] = {
                 "wave_instructions_per_launch": insts * scale,
-                "frac": insts * scale / (1024 * clock_hz * phys_ms * 1e-3),
-                "unit": "wave-instructions per SIMD-cycle (1024 SIMDs x 2.4 GHz x kernel time; VALU+SALU+LDS+VMEM)",
-                "valu_frac": per.get("SQ_INSTS_VALU", 0.0) * scale * 4 / (1024 * clock_hz * phys_ms * 1e-3),
+                "wave_instructions_per_env_substep": insts * scale / (E * env.params["steps"]),
+                "frac": insts * scale / (1024 * ck * phys_ms * 1e-3),
+                "unit": "wave-instructions per SIMD-cycle (1024 SIMDs x the measured clock x kernel time; VALU+SALU+branch+LDS+VMEM)",
+                "valu_frac": per.get("SQ_INSTS_VALU", 0.0) * scale * 4 / (1024 * ck * phys_ms * 1e-3),
                 "lanes_active": pmc.get("lanes_active"),
                 "source": roof["traffic_source"],
             }

@@ -286,6 +286,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     if ((rc = dalloc(h, &D.m_sum, E * BP_EPM_COUNT))) return rc;
     if ((rc = dalloc(h, &D.m_count, E))) return rc;
     if ((rc = dalloc(h, &D.m_open, E))) return rc;
+    if ((rc = dalloc(h, &D.clk, (size_t)2))) return rc;
     D.dbg = nullptr; D.dbg_env = -1; D.prof = nullptr;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(256) void k_debug_round2(const double *__restrict__
 __global__ __launch_bounds__(256) void k_episode_metrics(const DevParams P, const DevPtrs D, const int mode, const unsigned char *__restrict__ mask)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env == 0) { D.clk[0] = __builtin_amdgcn_s_memtime(); D.clk[1] = __builtin_amdgcn_s_memrealtime(); }   // bp_get_clock_stamps
     if (env >= P.num_envs) return;
     double *a = D.m_acc + (size_t)env * 8;
     const d2 p = D.pxy[(size_t)env * P.nbcap];
@@ -1151,6 +1153,16 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 }
 
 int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
+
+int bp_get_clock_stamps(bp_handle *h, uint64_t *out2_host)
+{
+    if (!h || !out2_host) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    BP_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out2_host, h->D.clk, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return BP_OK;
+}
 
 int bp_sched_warnings(bp_handle *h, int32_t *out2_host)
 {

@@ -93,6 +93,7 @@ struct DevPtrs {
     double *m_sum;           // [E][BP_EPM_COUNT] row fields summed over all finished episodes
     unsigned *m_count;       // [E] finished episodes
     unsigned char *m_open;   // [E] an episode is running (reset seen, not yet terminated)
+    unsigned long long *clk; // [2] shader-clock counter (s_memtime) and 100 MHz reference (s_memrealtime) stamped after the last physics launch
     // debug
     double *dbg;             // optional [substeps][nbcap][3] pose trace of env dbg_env
     int dbg_env;

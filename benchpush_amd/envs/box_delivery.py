@@ -37,7 +37,7 @@ def _bd_cfg(cfg):
 class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
     """E independent box-delivery environments on one GPU: reset(mask) / step(actions) with device tensors."""
 
-    def __init__(self, num_envs, cfg=None, trials=None, device="cuda:0", env_id_offset=0, num_trials=32, seed=None):
+    def __init__(self, num_envs, cfg=None, trials=None, device="cuda:0", env_id_offset=0, num_trials=32, seed=None, bd_overrides=None):
         if not torch.cuda.is_available():
             raise _lib.BpError("BatchedBoxDeliveryEnv needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
         self.L = _lib.load()
@@ -46,6 +46,8 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
         self.device = torch.device(device)
         self.params = box_delivery_physics_params(self.cfg)
         self.bd_params = box_delivery_params(self.cfg)
+        if bd_overrides:   # constants of the reference that are not in its config (e.g. STEP_LIMIT, box_delivery_env.py:62): tests shorten them
+            self.bd_params.update(bd_overrides)
         if trials is None:
             trials = generate_trials(self.cfg, num_trials, seed)
         self.trials = trials

@@ -246,6 +246,12 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_get_step_cycles(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_step_cycles")
         return out.astype(np.uint64) << 8
 
+    def clock_stamps(self):
+        """(shader-clock counter, 100 MHz reference counter) stamped after the last physics launch: the clock held between two calls is d0 / d1 x 100 MHz."""
+        out = np.zeros(2, np.uint64)
+        _lib.check(self.L, self.h, self.L.bp_get_clock_stamps(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_clock_stamps")
+        return int(out[0]), int(out[1])
+
     def sched_warnings(self):
         """(watchdog events, envs finished by the completion launch) of the step scheduler since load: (0, 0) unless a scheduler fault occurred."""
         out = np.zeros(2, np.int32)

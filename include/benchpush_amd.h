@@ -223,6 +223,10 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
  * behind, and resumed by another workgroup; results are identical), 0 = one wavefront per env for the whole step.  Default 40 for ship-ice and
  * maze handles of up to 8192 envs; environment variable BP_SCHED=<chunk> (0 = off) overrides it at load time. */
 int32_t bp_sched_chunk(bp_handle *h);
+/* Clock calibration for bench.py: the shader-clock counter (s_memtime) and the 100 MHz reference counter (s_memrealtime) stamped on the device right
+ * after the last physics launch of bp_step / bp_reset (ship-ice and maze handles): the clock the chip held between two calls is
+ * (d out[0]) / (d out[1]) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).  Host uint64 [2] (synchronises). */
+int bp_get_clock_stamps(bp_handle *h, uint64_t *out2_host);
 /* Scheduler robustness counters since bp_load_*: out2_host[0] = launches in which the watchdog of the step scheduler fired (a workgroup gave up
  * waiting for a parked env -- a scheduler fault, never seen in practice), out2_host[1] = envs whose step the completion launch that follows every
  * scheduled launch had to finish.  Results are complete and identical either way; non-zero values are a warning, not an error (synchronises). */

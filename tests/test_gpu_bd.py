@@ -95,6 +95,88 @@ def test_delivery_removes_the_box_like_the_oracle():
     env.close()
 
 
+def _deep_run(env, cfg, trials, steps, first_actions, seed, **over):
+    """Steps env and one oracle per env side by side with auto-reset on terminated | truncated (the next episode of env e plays trial
+    (e + episode) % T, like bp_reset); returns what happened."""
+    E, T = env.num_envs, len(trials)
+    oracles = [_oracle(cfg, trials[e % T], **over) for e in range(E)]
+    episode = np.zeros(E, int)
+    seen = dict(delivered=0, truncated=0, terminated=0, resets=0, max_substeps=0.0, hits=0)
+    obs, _ = env.reset()
+    rng = np.random.RandomState(seed)
+    for t in range(steps):
+        acts = rng.uniform(-1, 1, E)
+        if t < len(first_actions):
+            acts[: len(first_actions[t])] = first_actions[t]
+        res = _compare_step(env, oracles, acts, "deep %d" % t)
+        for e, r in enumerate(res):
+            seen["max_substeps"] = max(seen["max_substeps"], r[4]["substeps"])
+            seen["hits"] += int(r[4]["robot_hit_obstacle"])
+        done = np.array([r[2] or r[3] for r in res])
+        seen["terminated"] += int(sum(r[2] and not r[3] for r in res)); seen["truncated"] += int(sum(r[3] for r in res))
+        seen["delivered"] = max(seen["delivered"], int(max(r[4]["cumulative_boxes"] for r in res)))
+        if done.any():
+            obs, _ = env.reset(torch.from_numpy(done.astype(np.uint8)))
+            torch.cuda.synchronize()
+            for e in np.nonzero(done)[0]:
+                episode[e] += 1
+                oo = oracles[e].reset(trials[(e + episode[e]) % T])
+                assert np.array_equal(obs[e].cpu().numpy(), oo), ("reset obs", t, e)
+                seen["resets"] += 1
+    env.check_errors()
+    return seen
+
+
+def test_deep_episodes_through_delivery_removal_and_inactivity_truncation():
+    """32 env steps of 4 envs against the oracle (every step: bodies, info, reward, flags, observation; every reset: first observation): a hand-placed
+    delivery with the removal of the box (box_delivery_env.py:746-777), inactivity truncation (cutoff lowered to 6 steps through the config,
+    box_delivery_env.py:797-804, config.yaml:130-132) with terminated and truncated both set, and the episodes that follow on the next trials."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    cfg.misc.inactivity_cutoff = 6
+    gen = S.generate_trials(cfg, 3)
+    tr = dict(gen[0])
+    tr["start"] = np.array([1.5, 1.75, 0.0])
+    tr["boxes"] = np.array(gen[0]["boxes"])
+    tr["boxes"][0] = [2.6, 1.75, 0.3]                      # a box straight ahead, in front of the receptacle
+    trials = [tr, gen[1], gen[2]]
+    env = BatchedBoxDeliveryEnv(4, cfg={"misc": {"inactivity_cutoff": 6}}, trials=trials)
+    seen = _deep_run(env, cfg, trials, 32, [[1.0], [1.0], [1.0], [1.0]], seed=5)
+    env.close()
+    assert seen["delivered"] >= 1 and seen["truncated"] >= 2 and seen["resets"] >= 2, seen
+
+
+def test_forced_step_limit_steps_match_oracle():
+    """STEP_LIMIT (box_delivery_env.py:62: both execute_robot_path and step_simulation_until_still give up after that many sim steps) lowered from
+    10 000 to 500 on both sides, so that every env step runs into it: the straggler path of k_bd_physics, compared with the oracle bit for bit."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    trials = S.generate_trials(cfg, 3)
+    env = BatchedBoxDeliveryEnv(3, trials=trials, bd_overrides={"step_limit": 500})
+    seen = _deep_run(env, cfg, trials, 8, [], seed=9, step_limit=500)
+    env.close()
+    assert seen["max_substeps"] >= 500, seen
+
+
+def test_large_divider_20_boxes_soak_at_full_size():
+    """4096 envs x the 10 x 10 m room with 20 boxes and the divider: the in-kernel capacities of the box-delivery step (pre_solve events BP_EVCAP,
+    manifold mailbox BP_MBOX, arbiter and velocity slots, query buffers) are never hit -- check_errors() after every step."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    E = 4096
+    env = BatchedBoxDeliveryEnv(E, cfg={"env": {"obstacle_config": "large_divider"}}, num_trials=16)
+    assert env.nbox == 20
+    env.reset()
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(13)
+    for t in range(6):
+        a = torch.rand(E, generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1
+        obs, rew, term, trunc, info = env.step(a)
+        env.check_errors()
+        assert torch.isfinite(info).all() and torch.isfinite(rew).all()
+        env.reset(term | trunc)
+    env.close()
+
+
 def test_masked_reset_and_gym_adapter():
     import benchpush_amd
     from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv

@@ -205,12 +205,13 @@ def test_random_start_matches_oracle_and_redraws_every_episode():
     env.close()
 
 
-@pytest.mark.parametrize("E,conc,steps", [(4096, 0.3, 300), (2048, 0.5, 150)])
-def test_whole_episode_soak_no_capacity_flags(E, conc, steps):
+@pytest.mark.parametrize("E,conc,steps,ntrials", [(4096, 0.3, 300, 50), (4096, 0.5, 300, 100)])
+def test_whole_episode_soak_no_capacity_flags(E, conc, steps, ntrials):
     """Episodes run to their 300-step limit (environments/__init__.py:6) with auto-reset; the in-kernel capacities (arbiter slots,
-    velocity slots, neighbour lists, colours) must never be hit deep in an episode -- check_errors() every 25 steps."""
+    velocity slots, neighbour lists, colours, query buffers) must never be hit deep in an episode -- check_errors() every 25 steps.  The second case is
+    the per-GPU shard of BASELINE.json configs[4] (C5: 32 768 envs at 50 % over 8 GPUs = 4096 envs x 50 % per GPU, 100 trials), whole episodes."""
     from benchpush_amd.envs.ship_ice import default_trials
-    trials = default_trials(conc, 50, base_seed=0)
+    trials = default_trials(conc, ntrials, base_seed=0)
     env = _mk(E, conc, trials)
     env.reset()
     g = torch.Generator(device=env.device)
