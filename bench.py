@@ -231,7 +231,7 @@ def main():
     for t in range(W):
         one_step(t)
     torch.cuda.synchronize()
-    clk0 = env.clock_stamps() if hasattr(env, "clock_stamps") and args.env in ("ship-ice", "maze") else None
+    clk0 = env.clock_stamps() if hasattr(env, "clock_stamps") and hasattr(env.L, "bp_get_clock_stamps") and args.env in ("ship-ice", "maze") else None
     env.enable_timing(True)
     if dist is not None:
         dist.barrier()

@@ -706,7 +706,7 @@ __global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const D
                 // make sure the body is re-cached by the next sub-step
                 bool present = false;
                 for (int k0 = 0; k0 < S.nmv; k0 += 64) present = present || (ballot(k0 + lane < S.nmv && L.mv[k0 + lane] == (unsigned short)body) != 0);
-                if (!present && S.nmv < P.mvcap) { if (lane == 0) L.mv[S.nmv] = (unsigned short)body; S.nmv++; }
+                if (!present && S.nmv < P.mvcap) { if (lane == 0) L.mv[S.nmv] = (unsigned short)body; S.nmv++; S.cc_ok = 0; }
                 __syncthreads();
             }
             d2 cur = mk2(0.0, 0.0);

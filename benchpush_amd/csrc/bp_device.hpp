@@ -132,7 +132,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // the true sequence is unimodal and the computed dot products are within ~1e-13 of the true ones (coordinates below 64 m), so every other vertex
 // is then larger too and j is the unique first minimum.
 #define BP_SUPPORT_MARGIN 1e-10
-#define BP_QCAP 128         // support queries per batch (LDS)
+#define BP_QCAP 96          // support queries per batch (LDS)
 
 #define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step
 #define BP_MBOX 16          // manifold mailbox entries per hand-over batch
@@ -142,7 +142,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the
 // host (launch size), so the two cannot drift apart.
 struct LdsMap {
-    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, mv,
+    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, cc, cc_hw, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, mv,
         slot_of, rf, ev_d, ev_key, prof, total;
 };
 __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
@@ -165,6 +165,8 @@ __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, c
     m.r_idx = p; p += 4u * BP_QCAP;
     m.pt_a = p; p += 16u * 64;
     m.pt_thr = p; p += 16u * 64;
+    m.cc = p; p += 8u * 64;                   // candidate cache of the first candidate round (persists across sub-steps)
+    m.cc_hw = p; p += 8u * 64;
     m.res_smA = p; p += 8u * 64;              // res_smA .. res_jB are contiguous: the AABB keys of the transform phase ([64][4] u64) alias them
     m.res_smB = p; p += 8u * 64;
     m.res_iA = p; p += 4u * 64;

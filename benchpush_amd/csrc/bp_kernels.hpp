@@ -46,6 +46,7 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
     L.q_dir = (d2 *)(b + m.q_dir); L.q_c = (double *)(b + m.q_c); L.r_val = (double *)(b + m.r_val);
     L.q_meta = (unsigned *)(b + m.q_meta); L.q_aux = (unsigned *)(b + m.q_aux); L.r_idx = (unsigned *)(b + m.r_idx);
     L.pt_a = (uint4 *)(b + m.pt_a); L.pt_thr = (d2 *)(b + m.pt_thr);
+    L.cc = (unsigned long long *)(b + m.cc); L.cc_hw = (unsigned long long *)(b + m.cc_hw);
     L.mbox = (d2 *)(b + m.q_dir);   // BP_MBOX * 96 B = 1536 B = the q_dir array
     L.res_smA = (unsigned long long *)(b + m.res_smA); L.res_smB = (unsigned long long *)(b + m.res_smB);
     L.res_iA = (unsigned *)(b + m.res_iA); L.res_iB = (unsigned *)(b + m.res_iB);
@@ -80,6 +81,7 @@ __device__ __forceinline__ void env_ctx(const DevParams &P, const DevPtrs &D, in
 __device__ __forceinline__ void init_regs(ArbReg &A, SubState &S)
 {
     S.costp = 0u;
+    S.cc_ok = 0; S.cc_kmax = 0;
     S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.wall_flag = 0; S.nev = 0; S.robot_hit = 0; S.evmask = 0ull;
     A.e = 0.0; A.u = 0.0;
     S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;

@@ -83,6 +83,9 @@ struct LdsCtx {
     // pair table of a candidate round: what the plane-bound rounds need of each surviving pair
     uint4 *pt_a;               // [64] sa | sb << 16, nA | nB << 8 | hA << 16 | hB << 24, evaluated sides | jA << 8 | jB << 16, -
     d2 *pt_thr;                // [64] separation of the cached plane of side A / B (-inf: none)
+    // candidate cache: what the lanes of the FIRST candidate round found out about their (moving body, neighbour slot) -- body indices, slot, vertex
+    // counts, the static part of the pair filter -- and the slot's hint word, valid while the moving list and the neighbour lists stay as they are
+    unsigned long long *cc, *cc_hw; // [64]
     d2 *mbox;                  // [BP_MBOX][6] manifold mailbox (aliases the query buffers)
     // box-delivery only (substep<BP_ENV_BOX>): (1,3)/(2,3) pre_solve calls of the current sub-step
     unsigned *ev_key;          // [BP_EVCAP] shapeA << 16 | shapeB
@@ -105,6 +108,7 @@ struct SubState {
     unsigned costp;            // work proxy of the env step: sum over sub-steps of 16 + 2 * active arbiters + 4 * warm arbiters * colours
     int yaw_violated, boundary_violated;
     int wall_flag;             // maze: robot body touched a wall (pre_solve of the (1,3) handler)
+    int cc_ok, cc_kmax;        // candidate cache valid (wave-uniform), neighbour stride it was built with
     int quiescent;             // set by substep(): nothing moves and no arbiter is warm -> later sub-steps are no-ops
     unsigned ship_post, ship_contacts; // per-sub-step bookkeeping increments of the (cold) ship arbiters
     int nev;                   // box-delivery: recorded pre_solve events of this sub-step
@@ -352,7 +356,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         PROF_ACC(0)
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
         unsigned long long rm = ballot(leftfat);
-        if (BP_UNLIKELY(rm != 0)) __syncthreads(); // refresh_body reads the AABBs other lanes have just stored
+        if (BP_UNLIKELY(rm != 0)) { S.cc_ok = 0; __syncthreads(); } // refresh_body reads the AABBs other lanes have just stored; the lists change
         while (BP_UNLIKELY(rm != 0)) {
             const int kk = __ffsll((long long)rm) - 1;
             rm &= rm - 1;
@@ -365,36 +369,73 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     PROF_ACC(35)
 
     // ---- 3./4. candidate pairs of moving bodies ----------------------------------------------------------------
-    int kmax = 0; // largest neighbour count among the moving bodies (wave-uniform, found with 5 ballots per chunk)
-    for (int k0 = 0; k0 < S.nmv; k0 += 64) {
-        const int k = k0 + lane;
-        const int cnt = (k < S.nmv) ? (int)E.adjn[L.mv[k]] : 0;
-        int m = 0;
-        for (int bit = 16; bit >= 1; bit >>= 1) { if (ballot(cnt >= (m | bit))) m |= bit; }
-        kmax = max(kmax, m);
+    int kmax = S.cc_kmax; // largest neighbour count among the moving bodies (wave-uniform, found with 5 ballots per chunk)
+    if (!S.cc_ok) {
+        kmax = 0;
+        for (int k0 = 0; k0 < S.nmv; k0 += 64) {
+            const int k = k0 + lane;
+            const int cnt = (k < S.nmv) ? (int)E.adjn[L.mv[k]] : 0;
+            int m = 0;
+            for (int bit = 16; bit >= 1; bit >>= 1) { if (ballot(cnt >= (m | bit))) m |= bit; }
+            kmax = max(kmax, m);
+        }
+        S.cc_kmax = kmax;
     }
     const int ncand_slots = S.nmv * kmax;
     for (int base = 0; base < ncand_slots; base += 64) {
-        const int idx = base + lane;
-        const int k = idx / kmax, s = idx - k * kmax;
-        // Loads are issued unconditionally on clamped (always valid) addresses so that independent ones travel together:
-        // round trip 1: neighbour id / count / hint word / own AABB; 2: partner AABB, kinds, masses, radii, vertex counts.
-        const bool inlist = k < S.nmv;
-        const int i = inlist ? (int)L.mv[k] : 0;
+        // What a lane knows about its (moving body, neighbour slot) before any geometry: which pair it is, the vertex counts, and whether the pair
+        // is evaluated at all (list bounds, "evaluated from the other body's list", shapes of one body, two infinite masses).  None of it changes
+        // while the moving list and the neighbour lists stay the same, so the first round keeps it in LDS (with the slot's hint word, which this
+        // lane alone rewrites) and the next sub-step starts from there: one LDS read and ONE global round trip instead of two dependent ones.
+        int i, j, s, nA_h, nB_h;
+        bool valid, flagonly;
+        unsigned long long hw;
+        const bool cached = S.cc_ok && base == 0;
+        if (cached) {
+            const unsigned long long c = L.cc[lane];
+            hw = L.cc_hw[lane];
+            i = (int)(c & 0x3FFFu); j = (int)((c >> 14) & 0x3FFFu); s = (int)((c >> 28) & 31u);
+            nA_h = (int)((c >> 33) & 31u); nB_h = (int)((c >> 38) & 31u);
+            valid = ((c >> 43) & 1u) != 0; flagonly = ((c >> 44) & 1u) != 0;
+        } else {
+            const int idx = base + lane;
+            const int k = idx / kmax;
+            s = idx - k * kmax;
+            // round trip 1: neighbour id / count / hint word; 2 (below): kinds, masses, vertex counts
+            const bool inlist = k < S.nmv;
+            i = inlist ? (int)L.mv[k] : 0;
+            const int sc = min(s, BP_KADJ - 1);
+            const int adjn_i = E.adjn[i];
+            j = E.adj[i * BP_KADJ + sc] < E.nb ? (int)E.adj[i * BP_KADJ + sc] : 0;
+            hw = E.hint[i * BP_KADJ + sc];
+            valid = inlist && (s < adjn_i);
+            if (valid && L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
+            const int ki = E.kind[i], kj = E.kind[j];
+            const double mi = E.mass[i].x, mj = E.mass[j].x;
+            nA_h = E.nv[min(i, j)]; nB_h = E.nv[max(i, j)];
+            flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
+            if (valid) {
+                if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
+                else if (mi == 0.0 && mj == 0.0) {
+                    const int ci = kind_ctype(ki), cj = kind_ctype(kj);
+                    flagonly = (ci == 1 && cj == 3) || (ci == 3 && cj == 1);
+                    valid = flagonly;
+                }
+            }
+            s = min(s, 31);
+            if (base == 0) {
+                L.cc[lane] = (unsigned long long)(unsigned)i | ((unsigned long long)(unsigned)j << 14) | ((unsigned long long)(unsigned)s << 28) |
+                             ((unsigned long long)(unsigned)nA_h << 33) | ((unsigned long long)(unsigned)nB_h << 38) |
+                             ((unsigned long long)(valid ? 1u : 0u) << 43) | ((unsigned long long)(flagonly ? 1u : 0u) << 44);
+                L.cc_hw[lane] = hw;
+            }
+        }
         const int sc = min(s, BP_KADJ - 1);
-        const int adjn_i = E.adjn[i];
-        const int j = E.adj[i * BP_KADJ + sc] < E.nb ? (int)E.adj[i * BP_KADJ + sc] : 0;
-        const unsigned long long hw = E.hint[i * BP_KADJ + sc];
-        const double4 bbi = E.bb[i];
-        bool valid = inlist && (s < adjn_i);
-        if (valid && L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
-        const double4 bbj = E.bb[j];
-        const int ki = E.kind[i], kj = E.kind[j];
-        const double mi = E.mass[i].x, mj = E.mass[j].x;
         const int sa = min(i, j), sb = max(i, j);
+        const double4 bbi = E.bb[i];
+        const double4 bbj = E.bb[j];
         const double radA = E.prop[sa].x, radB = E.prop[sb].x;
         const double rsum = radA + radB;
-        const int nA_h = E.nv[sa], nB_h = E.nv[sb];
         // the cached planes (hint word) of both sides travel with this round trip too, and so do the cached support vertex of each with its two
         // cyclic neighbours: plane and vertex indices only need to be valid addresses here
         const int hA = HW_PLANE_A(hw) < BP_MAXV ? HW_PLANE_A(hw) : 0, hB = HW_PLANE_B(hw) < BP_MAXV ? HW_PLANE_B(hw) : 0;
@@ -406,15 +447,6 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const d2 fnB = E.wn[sb * BP_MAXV + hB], fpB = E.wv[sb * BP_MAXV + hB];
         const d2 vAm = E.wv[sb * BP_MAXV + jAm], vA0 = E.wv[sb * BP_MAXV + jA0], vAp = E.wv[sb * BP_MAXV + jAp];
         const d2 vBm = E.wv[sa * BP_MAXV + jBm], vB0 = E.wv[sa * BP_MAXV + jB0], vBp = E.wv[sa * BP_MAXV + jBp];
-        bool flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
-        if (valid) {
-            if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
-            else if (mi == 0.0 && mj == 0.0) {
-                const int ci = kind_ctype(ki), cj = kind_ctype(kj);
-                flagonly = (ci == 1 && cj == 3) || (ci == 3 && cj == 1);
-                valid = flagonly;
-            }
-        }
         if (valid) valid = bb_overlap(bbi, bbj);
         PROF_ACC(27)
         PROF_CNT(24, 1)
@@ -459,7 +491,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         if (valid && (sepAc > rsum || sepBc > rsum)) {
             valid = false;
-            if (hw & HW_BOTH) E.hint[i * BP_KADJ + s] = (hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0ull : HW_PRIM_B);
+            if (hw & HW_BOTH) {
+                const unsigned long long nh = (hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0ull : HW_PRIM_B);
+                E.hint[i * BP_KADJ + s] = nh;
+                if (base == 0) L.cc_hw[lane] = nh;
+            }
         }
         const unsigned long long cm = ballot(valid);
         PROF_ACC(28)
@@ -700,9 +736,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (nB == 2 || cm >= om + BP_SUPPORT_MARGIN) { i1B = (c0 > c1) ? iB0 : (c1 > c0) ? iB : min(iB0, iB); needB = false; }
             }
             // the winners of both sides are the next sub-step's cached planes
-            E.hint[i * BP_KADJ + s] = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
-                                                           ((unsigned)nA << 20) | ((unsigned)nB << 25)) |
-                                      HW_HAS_A | HW_HAS_B | (useA ? 0ull : HW_PRIM_B) | ((smax > rsum) ? 0ull : HW_BOTH);
+            const unsigned long long nh = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
+                                                               ((unsigned)nA << 20) | ((unsigned)nB << 25)) |
+                                          HW_HAS_A | HW_HAS_B | (useA ? 0ull : HW_PRIM_B) | ((smax > rsum) ? 0ull : HW_BOTH);
+            E.hint[i * BP_KADJ + s] = nh;
+            if (base == 0) L.cc_hw[lane] = nh;
         }
         PROF_ACC(31)
         // support queries for the support vertices that could not be certified: direction -n over A (n over B); the first minimum is the first maximum wanted
@@ -849,6 +887,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             lds_sync();
         }
     }
+    S.cc_ok = 1;   // the first candidate round has (re)built its cache; the moving-list rebuild and the neighbour-list refresh invalidate it
     PROF_ACC(4)
     // arbiters whose bodies did not move keep last sub-step's contacts
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
@@ -1198,10 +1237,14 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const int shipmv = (KIND == BP_ENV_BOX || v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? P.nkin : 0;
         const unsigned long long mA = ballot(gotA), mB = ballot(gotB);
         const int nA_ = __popcll(mA);
-        if (lane < shipmv) L.mv[lane] = (unsigned short)lane;
-        if (gotA) L.mv[shipmv + popc_below(mA, lane)] = (unsigned short)ba;
-        if (gotB) L.mv[shipmv + nA_ + popc_below(mB, lane)] = (unsigned short)bbi;
-        S.nmv = shipmv + nA_ + __popcll(mB);
+        // the list is rewritten in place; if it comes out as it was, the candidate cache of the first candidate round stays valid
+        bool differs = false;
+        if (lane < shipmv) { differs = L.mv[lane] != (unsigned short)lane; L.mv[lane] = (unsigned short)lane; }
+        if (gotA) { const int pos = shipmv + popc_below(mA, lane); differs = differs || L.mv[pos] != (unsigned short)ba; L.mv[pos] = (unsigned short)ba; }
+        if (gotB) { const int pos = shipmv + nA_ + popc_below(mB, lane); differs = differs || L.mv[pos] != (unsigned short)bbi; L.mv[pos] = (unsigned short)bbi; }
+        const int newn = shipmv + nA_ + __popcll(mB);
+        if (newn != S.nmv || ballot(differs)) S.cc_ok = 0;
+        S.nmv = newn;
     }
     S.quiescent = (S.nmv == 0) && (wmask == 0);
     lds_sync();

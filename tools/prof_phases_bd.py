@@ -32,6 +32,11 @@ for t in range(STEPS):
     r = p[w]
     print("   worst env %d: substeps %.0f cycles/substep %.0f: " % (w, r[22], r[23] / r[22]) + " ".join("%s=%.1f%%" % (n, 100 * r[i] / r[23]) for i, n in enumerate(names)) + " control=%.1f%%" % (100 * r[15] / r[23]))
     print("      per-substep: nmv=%.2f refresh=%.4f fullpairs=%.2f nact=%.2f levels=%.2f nwarm=%.2f" % tuple(r[k] / r[22] for k in (16, 17, 18, 19, 20, 21)))
+    print("      worst env, cycles per sub-step: " + " ".join("%s=%.0f" % (n, r[i] / r[22]) for i, n in enumerate(names)) + " control=%.0f" % (r[15] / r[22]))
+    print("      worst env, stages: " + " ".join("%s=%.0f" % (n, r[k] / r[22]) for n, k in (("pose", 33), ("transform", 34), ("aabb", 0), ("drain", 35), ("candidates", 27),
+          ("cached_planes", 28), ("bound_rounds", 29), ("plane_search", 30), ("normal", 31), ("support", 32))))
+    print("      worst env per-substep: cand_rounds=%.2f aabb_pairs=%.2f cached_plane_queries=%.2f searched_planes=%.2f support_queries=%.2f solver_iterations=%.2f colour_passes=%.2f" %
+          tuple(r[k] / r[22] for k in (24, 36, 37, 38, 39, 42, 43)))
     cps = tot / sub
     print("   cycles/substep percentiles 50/90/99/max: %.0f %.0f %.0f %.0f; total cycles percentiles: %.3g %.3g %.3g %.3g" % (
         np.percentile(cps, 50), np.percentile(cps, 90), np.percentile(cps, 99), cps.max(), np.percentile(tot, 50), np.percentile(tot, 90), np.percentile(tot, 99), tot.max()))
