@@ -9,9 +9,11 @@ import collections
 import re
 import sys
 
-PH = [(232, 239, '0head'), (240, 306, '1integrate'), (307, 318, '2refresh'), (320, 378, '3cand+hint'), (379, 452, '4a_faceseps'),
-      (453, 555, '4b_manifold'), (556, 643, '4c_deliver'), (644, 696, '5filter'), (697, 729, '6a_prestep'), (730, 754, '6a_warmset'),
-      (755, 794, '6a_colour'), (795, 805, '6b_velint'), (806, 829, '6c_warmstart'), (830, 907, '6d_solver'), (908, 944, '7post'), (945, 994, '7mvlist')]
+# phases of substep() as line ranges of csrc/bp_physics.hpp (update when the file moves; `grep -n "// ---- " csrc/bp_physics.hpp`)
+PH = [(267, 282, '0head'), (283, 356, '1integrate'), (357, 370, '2refresh'), (371, 454, '3candidates'), (455, 504, '4a_cached_planes'),
+      (505, 663, '4a_bound_rounds+search'), (664, 802, '4b_manifold'), (803, 891, '4c_deliver'), (892, 944, '5events+filter'),
+      (945, 990, '6a_prestep'), (991, 1014, '6a_warmset'), (1015, 1046, '6a_colour'), (1047, 1059, '6b_velint'), (1060, 1083, '6c_warmstart'),
+      (1084, 1164, '6d_solver'), (1165, 1206, '7post'), (1207, 1252, '7mvlist'), (192, 222, 'support_queries')]
 
 
 def phase_of(chain):

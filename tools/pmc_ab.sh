@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box counter A/B of library builds (run on the GPU box): tools/pmc_ab.sh lib1.so lib2.so ...  -> SQ instruction mix and wave-time split of the step kernel
-# per launch (mean of the last four profiled launches, 4096 envs, steps 8..11 of fresh episodes).  Two rocprofv3 passes per library (8 SQ counters each).
+# per launch (mean of the last four profiled launches, 4096 envs, steps 26..29 of fresh episodes).  Two rocprofv3 passes per library (8 SQ counters each).
 export PMC_KERNELS=${PMC_KERNELS:-k_physics_step_sched}
 for lib in "$@"; do
   echo "== $(basename $lib)"

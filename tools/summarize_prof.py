@@ -11,10 +11,22 @@ build = sys.argv[2] if len(sys.argv) > 2 else "unknown"
 
 
 def rows(pattern):
+    """csv rows; of a kernel that is launched with several grid sizes (k_physics_step_sched: the scheduled launch and the completion launch that
+    follows it, a few hundred workgroups that leave at once) only the dispatches with the largest grid are kept."""
+    allr = []
     for f in glob.glob(os.path.join(out, pattern), recursive=True):
         with open(f) as fh:
-            for r in csv.DictReader(fh):
-                yield r
+            allr.extend(csv.DictReader(fh))
+    big = {}
+    for r in allr:
+        g = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+        k = r.get("Kernel_Name", "")
+        big[k] = max(big.get(k, 0), g)
+    for r in allr:
+        g = int(r.get("Grid_Size") or r.get("Grid_Size_X") or 0)
+        if "Kernel_Name" in r and g and g < big[r["Kernel_Name"]] and r["Kernel_Name"].startswith("k_physics_step_sched"):
+            continue
+        yield r
 
 
 print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
@@ -68,7 +80,7 @@ for sub in ("pmc_sq", "pmc_sq2"):
         sq[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sq.items():
     print("SQ %-40s " % k[:40] + " ".join("%s=%.4g" % (c, sum(v[-6:]) / len(v[-6:])) for c, v in sorted(d.items())))
-pmc = {"build": build, "envs": 4096, "kernel": "k_physics_step",
+pmc = {"build": build, "envs": 4096, "kernel": "k_physics_step", "substeps_per_step": 400,
        "how": "rocprofv3 --kernel-trace --pmc, separate passes, python3 bench.py --steps 6 --warmup 24 (means of the last 6 launches: "
               "episodes 24-30 steps old, close to the steady-state mix)"}
 for k, d in res.items():
@@ -83,6 +95,9 @@ for k, d in sq.items():
         per = {c: sum(v[-6:]) / len(v[-6:]) for c, v in d.items()}
         pmc["per_launch"] = per
         pmc["kernel"] = k
+        tot = sum(per.get(c, 0.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
+        pmc["wave_instructions_per_env_substep"] = tot / (4096 * 400.0)
+        pmc["per_env_substep"] = {c: per.get(c, 0.0) / (4096 * 400.0) for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_BRANCH", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR")}
         if per.get("SQ_ACTIVE_INST_VALU") and per.get("SQ_THREAD_CYCLES_VALU"):
             pmc["lanes_active"] = per["SQ_THREAD_CYCLES_VALU"] / (64.0 * per["SQ_ACTIVE_INST_VALU"])
         if per.get("SQ_WAVE_CYCLES"):
