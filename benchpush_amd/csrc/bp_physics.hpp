@@ -959,7 +959,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const double rct1 = vcross(A.r1_0, t), rct2 = vcross(A.r2_0, t);
             tMass0 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
             const double dist = vdot(vadd(vsub(A.r2_0, A.r1_0), body_delta), n);
-            bias0 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
+            bias0 = -P.bias_coef * fmin(0.0, dist + P.slop);   // divided by dt below when it is not a zero (a signed zero / dt is that zero)
             jBias0 = 0.0;
             const d2 v1 = vadd(va, vmul(vperp(A.r1_0), wa));
             const d2 v2 = vadd(vb, vmul(vperp(A.r2_0), wb));
@@ -971,13 +971,15 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const double rct1 = vcross(A.r1_1, t), rct2 = vcross(A.r2_1, t);
             tMass1 = 1.0 / ((A.ma + A.ia * rct1 * rct1) + (A.mb + A.ib * rct2 * rct2));
             const double dist = vdot(vadd(vsub(A.r2_1, A.r1_1), body_delta), n);
-            bias1 = -P.bias_coef * fmin(0.0, dist + P.slop) / dt;
+            bias1 = -P.bias_coef * fmin(0.0, dist + P.slop);
             jBias1 = 0.0;
             const d2 v1 = vadd(va, vmul(vperp(A.r1_1), wa));
             const d2 v2 = vadd(vb, vmul(vperp(A.r2_1), wb));
             bounce1 = vdot(vsub(v2, v1), n) * A.e;
         }
     }
+    // the bias velocity -bias_coef * min(0, dist + slop) / dt is a signed zero unless a contact is deeper than the slop: the two divisions run only then
+    if (ballot(active && (bias0 != 0.0 || bias1 != 0.0))) { bias0 = bias0 / dt; bias1 = bias1 / dt; }
     // ---- warm set: arbiters that can produce a non-zero impulse this sub-step ------------------------------------
     // Seeds: a kinematic body that moves, a cached impulse, a bias or a bounce term; closed under "shares a dynamic
     // body".  Every other arbiter provably keeps all its impulses at exactly 0 and is skipped.
