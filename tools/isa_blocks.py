@@ -11,9 +11,10 @@ import sys
 
 # phases of substep() as line ranges of csrc/bp_physics.hpp (update when the file moves; `grep -n "// ---- " csrc/bp_physics.hpp`)
 PH = [(267, 282, '0head'), (283, 356, '1integrate'), (357, 370, '2refresh'), (371, 454, '3candidates'), (455, 504, '4a_cached_planes'),
-      (505, 663, '4a_bound_rounds+search'), (664, 802, '4b_manifold'), (803, 891, '4c_deliver'), (892, 944, '5events+filter'),
-      (945, 990, '6a_prestep'), (991, 1014, '6a_warmset'), (1015, 1046, '6a_colour'), (1047, 1059, '6b_velint'), (1060, 1083, '6c_warmstart'),
-      (1084, 1164, '6d_solver'), (1165, 1206, '7post'), (1207, 1252, '7mvlist'), (192, 222, 'support_queries')]
+      (505, 663, '4a_bound_rounds+search'), (664, 819, '4b_manifold'), (820, 927, '4c_deliver'), (928, 944, '5events+filter'),
+      (945, 982, '6a_prestep'), (983, 1008, '6a_warmset'), (1009, 1048, '6a_colour'), (1049, 1061, '6b_velint'), (1062, 1085, '6c_warmstart'),
+      (1086, 1166, '6d_solver'), (1167, 1215, '7post'), (1216, 1262, '7mvlist'), (237, 265, 'support_queries'), (198, 221, 'world_from_pose'),
+      (145, 197, 'refresh_body')]
 
 
 def phase_of(chain):
