@@ -308,8 +308,8 @@ def main():
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
-        # (profiles/r02_final/pmc.json, written by tools/profile_gpu.sh for the build named inside), never measured in this run
-        pmc = profile_sourced(os.path.join("r03_final", "pmc.json")) if args.env == "ship-ice" else None
+        # (profiles/r03_final/pmc.json, written by tools/profile_gpu.sh for the build named inside; config c2 only), never measured in this run
+        pmc = profile_sourced(os.path.join("r03_final", "pmc.json")) if (args.env == "ship-ice" and args.config == "c2") else None
         roof = {
             "bound": "issue",
             "accounting": "achieved / peak / frac are the HBM accounting of SURVEY 8d (algorithmic bytes per launch / kernel time against 8 TB/s); what binds "
