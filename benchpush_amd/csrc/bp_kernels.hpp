@@ -82,7 +82,7 @@ __device__ __forceinline__ void init_regs(ArbReg &A, SubState &S)
 {
     S.costp = 0u;
     S.cc_ok = 0; S.cc_kmax = 0;
-    S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.wall_flag = 0; S.nev = 0; S.robot_hit = 0; S.evmask = 0ull;
+    S.ecoef_e = -1.0; S.ecoef = 0.0; S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.wall_flag = 0; S.nev = 0; S.robot_hit = 0; S.evmask = 0ull;
     A.e = 0.0; A.u = 0.0;
     S.err = 0; S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0; S.nlevels = 0;
     A.level = 0; A.rank = 0;

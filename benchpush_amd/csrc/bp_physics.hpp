@@ -109,6 +109,7 @@ struct SubState {
     int yaw_violated, boundary_violated;
     int wall_flag;             // maze: robot body touched a wall (pre_solve of the (1,3) handler)
     int cc_ok, cc_kmax;        // candidate cache valid (wave-uniform), neighbour stride it was built with
+    double ecoef_e, ecoef;     // last elasticity product seen by the post-solve bookkeeping and its (1 - e) / (1 + e)
     int quiescent;             // set by substep(): nothing moves and no arbiter is warm -> later sub-steps are no-ops
     unsigned ship_post, ship_contacts; // per-sub-step bookkeeping increments of the (cold) ship arbiters
     int nev;                   // box-delivery: recorded pre_solve events of this sub-step
@@ -1060,7 +1061,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     lds_sync();
     PROF_ACC(6)
     // ---- 6c. warm start (cpArbiterApplyCachedImpulse) -----------------------------------------------------------
-    const double dt_coef = (prev_dt == 0.0) ? 0.0 : dt / prev_dt;
+    const double dt_coef = (prev_dt == 0.0) ? 0.0 : (prev_dt == dt) ? 1.0 : dt / prev_dt; // x / x == 1 exactly: no division in the steady case
     const int nlevels = wmask ? S.nlevels : 0;
     unsigned lvlmask = 0; // colours that hold at least one warm arbiter
     for (int lvl = 1; lvl <= nlevels; lvl++) if (ballot(warm && A.level == lvl)) lvlmask |= 1u << lvl;
@@ -1178,7 +1179,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const bool ws = shiparb && warm;
             const unsigned long long wsm = ballot(ws);
             if (wsm) {
-                const double eCoef = (1 - A.e) / (1 + A.e);
+                // (1 - e) / (1 + e): one division per distinct elasticity product instead of one per sub-step (all ship x floe arbiters share it)
+                const double e_first = readlane_f64(A.e, __ffsll((long long)wsm) - 1);
+                double eCoef;
+                if (!ballot(ws && A.e != e_first)) {
+                    if (e_first != S.ecoef_e) { S.ecoef_e = e_first; S.ecoef = (1 - e_first) / (1 + e_first); }
+                    eCoef = S.ecoef;
+                } else eCoef = (1 - A.e) / (1 + A.e);
                 double ke = 0.0;
                 d2 js = mk2(0.0, 0.0);
                 if (ws) {
