@@ -846,7 +846,6 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BP_ENODEVICE;
     if (cfg->damping_pow != 0.0 || cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
-    if (cfg->invert_receptacle_map) return BP_EINVAL;        // env.invert_receptacle_map: false only
     if (cfg->num_boxes <= 0 || cfg->num_boxes > BD_MAXBOX || cfg->local_px <= 0 || (cfg->local_px & 1)) return BP_EINVAL;
     bp_handle *h = new bp_handle();
     memset(&h->cfg, 0, sizeof(h->cfg));
@@ -884,7 +883,8 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     B.yaw_rate_step = cfg->yaw_rate_step; B.t_max = cfg->t_max;
     B.boundary_penalty = cfg->boundary_penalty; B.box_cleared_reward = cfg->box_cleared_reward; B.box_putback_penalty = cfg->box_putback_penalty;
     B.truncation_penalty = cfg->truncation_penalty; B.terminal_reward = cfg->terminal_reward; B.pushing_mult = cfg->pushing_mult;
-    B.recept_outside = 0.0f;
+    // outside the small-map window every cell is padding obstacle: spfa leaves 0 there, the inverted map (box_delivery_env.py:1126-1128) 0 + 1
+    B.recept_outside = (cfg->task == 0 && cfg->invert_receptacle_map) ? 1.0f : 0.0f;
     if (cfg->task == 1) {
         if (cfg->num_boundary_verts < 3 || cfg->num_boundary_verts > 8 || cfg->num_outer_verts < 3 || cfg->num_outer_verts > 8 ||
             cfg->num_goal_points < 1 || cfg->num_goal_points > 128) { delete h; return BP_EINVAL; }
@@ -972,7 +972,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
             G.nbd = cf.num_boundary_verts; G.nob = cf.num_outer_verts; G.ngoal = cf.num_goal_points;
             G.bd = cf.boundary; G.ob = cf.outer_boundary; G.goals = cf.goal_points; G.scale_max = cf.distance_scale_max;
             if (!bd_build_maps(obstacles, cf.room_length, cf.room_width, cf.ppm, cf.local_px, cf.local_w, cf.robot_radius, cf.robot_half_width,
-                               cf.recept_x, cf.recept_y, cf.sp_channel_scale, M, cf.task, &G))
+                               cf.recept_x, cf.recept_y, cf.sp_channel_scale, M, cf.task, &G, cf.task == 0 && cf.invert_receptacle_map != 0))
                 return fail(h, BP_EINVAL, "free space does not fit the small-map window");
             h->bd_maps.push_back(M);
             map_keys.push_back(obstacles);

@@ -263,7 +263,7 @@ static bool ac_contains_point(const double (*p)[2], int n, double x, double y) /
 
 static bool bd_build_maps(const std::vector<std::vector<P2>> &obstacles, double room_length, double room_width, double ppm, int local_px,
                           double local_w, double robot_radius, double robot_half_width, double recept_x, double recept_y,
-                          double sp_channel_scale, BdMaps &M, int task = 0, const AcGeom *G = nullptr)
+                          double sp_channel_scale, BdMaps &M, int task = 0, const AcGeom *G = nullptr, bool invert_recept = false)
 {
     const double pad = (double)local_px * std::sqrt(2.0);
     M.H = (int)(2 * std::ceil((room_width * ppm + pad) / 2));
@@ -373,6 +373,11 @@ static bool bd_build_maps(const std::vector<std::vector<P2>> &obstacles, double 
             float v = dist[(size_t)(M.si0 + i) * W + (M.sj0 + j)] / ppm32;
             v = (float)((double)v / div2);
             v = v * scale32;
+            if (invert_recept) { // cfg.env.invert_receptacle_map (box_delivery_env.py:1126-1128): + (1 - cspace), and cells equal to (1 - cspace) become 1
+                const float inv = 1.0f - (freec[(size_t)(M.si0 + i) * W + (M.sj0 + j)] ? 1.0f : 0.0f);
+                v = v + inv;
+                if (v == inv) v = 1.0f;
+            }
             M.recept[(size_t)i * SW + j] = v;
         }
     return true;

@@ -338,3 +338,21 @@ def test_boxes_stay_in_room_and_state_is_finite():
         boxes = st[6:16, :2]
         assert np.all(np.abs(boxes[:, 0]) < 5.05) and np.all(np.abs(boxes[:, 1]) < 2.55)
         assert 2 <= info["substeps"] <= 10002 + 10002
+
+
+def test_inverted_receptacle_map_equals_the_numpy_statement_of_the_reference():
+    """box_delivery_env.py:1126-1128 on float32 arrays: global_map += 1 - cspace; global_map[global_map == (1 - cspace)] = 1."""
+    cfg = default_cfg("box_delivery")
+    cfg.env.obstacle_config = "small_columns"
+    trial = S.generate_trials(cfg, 1)[0]
+    _, plain = _env(cfg)
+    plain.reset(trial, observe=False)
+    cfg.env.invert_receptacle_map = True
+    _, inv = _env(cfg)
+    inv.reset(trial, observe=False)
+    pm, im = plain.maps(), inv.maps()
+    g = pm["recept"].copy()
+    g += 1 - pm["cspace"]
+    g[g == (1 - pm["cspace"])] = 1
+    assert g.dtype == np.float32 and np.array_equal(g, im["recept"])
+    assert (im["recept"][pm["cspace"] == 0] == 1).all() and not np.array_equal(pm["recept"], im["recept"])

@@ -76,6 +76,37 @@ def test_maps_reset_and_steps_match_oracle(oc):
     env.close()
 
 
+def test_inverted_receptacle_map_matches_oracle():
+    """cfg.env.invert_receptacle_map (box_delivery_env.py:1126-1128, config.yaml:127): obstacle cells and the receptacle's own cell read 1 in the
+    shortest-path-to-receptacle channel; the padding outside the small-map window (all obstacle) therefore reads 1 as well."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    cfg.env.obstacle_config = "small_columns"
+    cfg.env.invert_receptacle_map = True
+    E = 3
+    trials = S.generate_trials(cfg, E)
+    env = BatchedBoxDeliveryEnv(E, cfg={"env": {"obstacle_config": "small_columns", "invert_receptacle_map": True}}, trials=trials)
+    oracles = [_oracle(cfg, trials[e]) for e in range(E)]
+    m, om = env.maps(0), oracles[0].maps()
+    d = m["dims"]
+    si, sj, SH, SW = int(d[4]), int(d[5]), int(d[2]), int(d[3])
+    win = (slice(si, si + SH), slice(sj, sj + SW))
+    assert np.array_equal(m["recept"], om["recept"][win])
+    outside = np.ones_like(om["recept"], bool); outside[win] = False
+    assert (om["recept"][outside] == 1.0).all() and (m["recept"][m["cspace"] == 0] == 1.0).all() and (m["recept"] == 1.0).sum() > (m["cspace"] == 0).sum()
+    plain = BatchedBoxDeliveryEnv(E, cfg={"env": {"obstacle_config": "small_columns"}}, trials=trials)
+    assert not np.array_equal(plain.maps(0)["recept"], m["recept"])
+    plain.close()
+    obs, info = env.reset()
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
+    rng = np.random.RandomState(11)
+    for t in range(3):
+        _compare_step(env, oracles, rng.uniform(-1, 1, E), "inverted %d" % t)
+    env.check_errors()
+    env.close()
+
+
 def test_delivery_removes_the_box_like_the_oracle():
     from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
     cfg = default_cfg("box_delivery")
