@@ -337,7 +337,7 @@ def main():
             per = pmc.get("per_launch", {})
             insts = sum(per.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
             scale = E / float(pmc.get("envs", E))
-            roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+            roof["traffic"] = (pmc.get("hbm_bytes_per_launch") * scale) if pmc.get("hbm_bytes_per_launch") else None   # per launch of E envs
             roof["wasted_traffic"] = (roof["traffic"] / (a_phys * E)) if roof["traffic"] else None
             roof["traffic_source"] = "profiles/r03_final/pmc.json (rocprofv3 --pmc passes of build %s, %s envs; not measured in this run)" % (
                 pmc.get("build", "?"), pmc.get("envs", "?"))

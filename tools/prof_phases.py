@@ -1,4 +1,4 @@
-"""Phase breakdown of k_physics from the BP_PROF diagnostic build: BP_PROF=1 python tools/prof_phases.py [E] [steps]"""
+"""Phase breakdown of k_physics from the BP_PROF diagnostic build: BP_PROF=1 python tools/prof_phases.py [E] [steps] [ship-ice|maze]"""
 import os
 import sys
 
@@ -11,8 +11,13 @@ from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 STEPS = int(sys.argv[2]) if len(sys.argv) > 2 else 14
-trials = default_trials(0.3, 100, base_seed=0)
-env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
+KIND = sys.argv[3] if len(sys.argv) > 3 else "ship-ice"   # ship-ice | maze
+if KIND == "maze":
+    from benchpush_amd.envs.maze_namo import BatchedMazeEnv
+    env = BatchedMazeEnv(E, cfg={"num_obstacles": 20}, num_layouts=100, base_seed=0)
+else:
+    trials = default_trials(0.3, 100, base_seed=0)
+    env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials)
 env.reset()
 prof = torch.zeros((E, 64), dtype=torch.int64, device=env.device)
 env.L.bp_debug_prof(env.h, prof.data_ptr())
