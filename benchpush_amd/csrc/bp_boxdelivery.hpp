@@ -549,7 +549,10 @@ __device__ __forceinline__ d2 bd_local_to_world(const EnvCtx &E, int i, int q)
     return mk2((r.x * lv.x + (-r.y) * lv.y) + tx, (r.y * lv.x + r.x * lv.y) + ty);
 }
 
-__global__ __launch_bounds__(64, 2) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
+#ifndef BP_BD_WAVES
+#define BP_BD_WAVES 2
+#endif
+__global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
 {
     const int env = (D.order != nullptr) ? D.order[blockIdx.x] : (int)blockIdx.x;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
