@@ -1095,7 +1095,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     constexpr bool AB = decltype(bias_tag)::value;
     for (int it = 0; it < P.iterations; it++) {
         PROF_CNT(42, 1)
-        bool changed = false;
+        // "did any accumulated impulse change in this iteration": the differences jnAcc - jnOld, jtAcc - jtOld (and of the bias impulse) exist anyway;
+        // a difference of finite doubles is zero exactly when they are equal, so the bit patterns (sign aside) are OR-ed into one per-lane word --
+        // no compare-and-merge of lane masks across the divergent contact blocks of every colour pass
+        int chg = 0;
         for (unsigned lm = lvlmask; lm; lm &= lm - 1u) { // colours that hold a warm arbiter, ascending
             const int lvl = __ffs((int)lm) - 1;
             PROF_CNT(43, 1)
@@ -1133,18 +1136,21 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         const double jt = -vrt * tMass;
                         const double jtOld = c ? A.jt1 : A.jt0;
                         const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
-                        changed = changed || (jnAcc != jnOld) || (jtAcc != jtOld) || (jBias != jbnOld);
                         if (c) { jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
                         else   { jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
                         if (AB) {
-                            const d2 jb = vmul(n, jBias - jbnOld);
+                            const double djb = jBias - jbnOld;
+                            chg |= __double2loint(djb) | (__double2hiint(djb) & 0x7FFFFFFF);
+                            const d2 jb = vmul(n, djb);
                             const d2 jbneg = vneg(jb);
                             vba = vadd(vba, vmul(jbneg, A.ma));
                             wa2.y += A.ia * vcross(r1, jbneg);
                             vbb = vadd(vbb, vmul(jb, A.mb));
                             wb2.y += A.ib * vcross(r2, jb);
                         }
-                        const d2 j = vrotate(n, mk2(jnAcc - jnOld, jtAcc - jtOld));
+                        const double djn = jnAcc - jnOld, djt = jtAcc - jtOld;
+                        chg |= __double2loint(djn) | __double2loint(djt) | ((__double2hiint(djn) | __double2hiint(djt)) & 0x7FFFFFFF);
+                        const d2 j = vrotate(n, mk2(djn, djt));
                         apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
                     }
                 }
@@ -1160,7 +1166,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         // an iteration that changed no accumulated impulse applied only zero impulses: the state is a fixed point and
         // the remaining iterations would repeat it exactly
-        if (BP_UNLIKELY2(!ballot(changed))) break;
+        if (BP_UNLIKELY2(!ballot(warm && chg != 0))) break;
     }
     };
     if (any_bias) iterate(std::true_type{}); else iterate(std::false_type{});
