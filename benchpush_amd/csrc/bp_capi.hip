@@ -787,6 +787,41 @@ int bp_get_episode_history(bp_handle *h, double *ring, double *sums, uint32_t *c
     return BP_OK;
 }
 
+// test hook: every written hint word of the live envs gets random VALID contents -- plane and support-vertex indices below the vertex counts the word
+// records, a random subset of the HW_* flags.  The sub-step evaluates cached planes exactly and searches whatever they do not certify, so the results
+// of the following steps must not change (tests/test_gpu_parity.py); only the amount of work does.
+__global__ __launch_bounds__(256) void k_debug_scramble_hints(unsigned long long *hint, size_t n, unsigned long long seed, int *count)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const unsigned long long hw = hint[i];
+    const unsigned nA = (unsigned)HW_NV_A(hw), nB = (unsigned)HW_NV_B(hw);
+    if (nA == 0 || nB == 0) return; // never written (or cleared by a neighbour-list refresh)
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1); // splitmix64
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    const unsigned iA = (unsigned)(z & 0xFF) % nA, iB = (unsigned)((z >> 8) & 0xFF) % nB, jA = (unsigned)((z >> 16) & 0xFF) % nB, jB = (unsigned)((z >> 24) & 0xFF) % nA;
+    hint[i] = (unsigned long long)(iA | (iB << 5) | (jA << 10) | (jB << 15) | (nA << 20) | (nB << 25)) |
+              (((z >> 32) & 1ull) ? HW_HAS_A : 0ull) | (((z >> 33) & 1ull) ? HW_HAS_B : 0ull) | (((z >> 34) & 1ull) ? HW_PRIM_B : 0ull) |
+              (((z >> 35) & 1ull) ? HW_BOTH : 0ull);
+    atomicAdd(count, 1);
+}
+
+int bp_debug_scramble_hints(bp_handle *h, uint64_t seed, void *stream)
+{
+    if (!h) return BP_EINVAL;
+    if (!h->loaded || !h->was_reset) return fail(h, BP_ESTATE, "not reset");
+    DevGuard _dg(h->device);
+    const size_t n = (size_t)h->num_envs * (size_t)h->nbcap * BP_KADJ;
+    int *cnt = nullptr, host = 0;
+    HIPCHK(h, hipMalloc(&cnt, sizeof(int)));
+    HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(int), (hipStream_t)stream));
+    hipLaunchKernelGGL(k_debug_scramble_hints, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->D.hint, n, (unsigned long long)seed, cnt);
+    HIPCHK(h, hipMemcpyAsync(&host, cnt, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
+    HIPCHK(h, hipFree(cnt));
+    return host; // number of hint words rewritten (>= 0)
+}
+
 int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream)
 {
     if (!in_dev || !out_dev || n < 0) return BP_EINVAL;

@@ -205,6 +205,10 @@ int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *s
 int bp_get_episode_history(bp_handle *h, double *ring, double *sums, uint32_t *counts, void *stream);
 /* test hook: out[i] = the device's restatement of python's round(in[i], 2) (device doubles [n]) */
 int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream);
+/* test hook: overwrite every cached-plane hint word of the live envs with random valid contents (indices below the recorded vertex counts, random
+ * flags); the following steps must produce bit-identical results -- the hints only steer how much of the plane search is skipped.
+ * Returns the number of words rewritten (>= 0) or a negative BP_E*; synchronises the stream. */
+int bp_debug_scramble_hints(bp_handle *h, uint64_t seed, void *stream);
 
 int32_t bp_nb_cap(const bp_handle *h);       /* body slots per env (ship + max floes, padded) */
 int32_t bp_obs_height(const bp_handle *h);

@@ -80,6 +80,47 @@ def test_parity_preemptive_scheduler(monkeypatch):
     assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
 
 
+@pytest.mark.parametrize("kind,conc", [("ship", 0.3), ("ship", 0.5), ("maze", None)])
+def test_cached_plane_hints_never_change_results(kind, conc):
+    """The hint word of a neighbour slot (winning plane and support vertex of both shapes, flags) only decides how much of the plane search is
+    skipped: cached planes are evaluated exactly, every other plane is pruned by an upper bound or searched.  bp_debug_scramble_hints overwrites
+    every written hint with random valid indices and random flags before every step; states, rewards, observations and info must stay bit-identical."""
+    import ctypes as C
+    if kind == "ship":
+        from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+        trials = default_trials(conc, 5, base_seed=23)
+        mk = lambda: BatchedShipIceEnv(E, cfg={"concentration": conc}, trials=trials, device="cuda:0")
+    else:
+        from benchpush_amd.envs.maze_namo import BatchedMazeEnv
+        mk = lambda: BatchedMazeEnv(E, cfg={"num_obstacles": 20}, num_layouts=5, base_seed=3, device="cuda:0")
+    E, steps = 64, 20
+    g = torch.Generator(device="cuda:0")
+    g.manual_seed(17)
+    acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
+
+    def run(scramble):
+        env = mk()
+        env.reset()
+        rsum = torch.zeros(E, dtype=torch.float64, device="cuda:0")
+        for t in range(steps):
+            if scramble:
+                n = env.L.bp_debug_scramble_hints(env.h, C.c_uint64(1000 * scramble + t), None)
+                assert n >= 0 and (t < 3 or n > E), n      # after a few steps every env has pairs with cached planes to overwrite
+            _, rew, term, _, _ = env.step(acts[t])
+            rsum += rew
+            env.reset(term)
+        env.check_errors()
+        out = (env.body_state().clone(), rsum, env.obs.clone(), env.info.clone())
+        env.close()
+        return out
+
+    ref = run(0)
+    for sc in (1, 2):
+        got = run(sc)
+        for a, b in zip(ref, got):
+            assert torch.equal(a, b), (kind, conc, sc)
+
+
 def test_dispatch_order_hint_never_changes_results():
     """bp_set_step_cost_hint (the dispatch order of the step kernel) with random and with reversed hints: same states, rewards and observations."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
