@@ -80,7 +80,7 @@ def test_parity_preemptive_scheduler(monkeypatch):
     assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
 
 
-@pytest.mark.parametrize("kind,conc", [("ship", 0.3), ("ship", 0.5), ("maze", None)])
+@pytest.mark.parametrize("kind,conc", [("ship", 0.3), ("ship", 0.5), ("maze", None), ("box", None)])
 def test_cached_plane_hints_never_change_results(kind, conc):
     """The hint word of a neighbour slot (winning plane and support vertex of both shapes, flags) only decides how much of the plane search is
     skipped: cached planes are evaluated exactly, every other plane is pruned by an upper bound or searched.  bp_debug_scramble_hints overwrites
@@ -90,10 +90,13 @@ def test_cached_plane_hints_never_change_results(kind, conc):
         from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
         trials = default_trials(conc, 5, base_seed=23)
         mk = lambda: BatchedShipIceEnv(E, cfg={"concentration": conc}, trials=trials, device="cuda:0")
-    else:
+    elif kind == "maze":
         from benchpush_amd.envs.maze_namo import BatchedMazeEnv
         mk = lambda: BatchedMazeEnv(E, cfg={"num_obstacles": 20}, num_layouts=5, base_seed=3, device="cuda:0")
-    E, steps = 64, 20
+    else:   # box-delivery: ~1000 sim steps of the same sub-step per env step
+        from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+        mk = lambda: BatchedBoxDeliveryEnv(E, cfg={"env": {"obstacle_config": "small_columns"}}, num_trials=4, seed=5, device="cuda:0")
+    E, steps = (64, 20) if kind != "box" else (16, 6)
     g = torch.Generator(device="cuda:0")
     g.manual_seed(17)
     acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
