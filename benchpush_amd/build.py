@@ -41,5 +41,26 @@ def build_hip(force=False, verbose=False):
     return LIB_PATH
 
 
+DBG_LIB_PATH = os.path.join(_HERE, "libbenchpush_hip_dbgpaths.so")
+
+
+def build_debug_paths(force=False, verbose=False):
+    """Diagnostic twin of the library (-DBP_DEBUG_PATHS): BP_DEBUG_PATHS=<mask> forces the narrow phase's fallback paths.  Only tests load it
+    (tests/test_gpu_parity.py::test_rarely_taken_narrow_phase_paths_match_oracle); the product library compiles those tests away."""
+    if not force and os.path.exists(DBG_LIB_PATH):
+        t = os.path.getmtime(DBG_LIB_PATH)
+        if all(os.path.getmtime(p) <= t for p in [os.path.join(CSRC, f) for f in SOURCES] + _headers() if os.path.exists(p)):
+            return DBG_LIB_PATH
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + ["-DBP_DEBUG_PATHS=1", "-o", DBG_LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=CSRC)
+    return DBG_LIB_PATH
+
+
 if __name__ == "__main__":
     print(build_hip(force=True, verbose=True))
+    print(build_debug_paths(force=True, verbose=True))

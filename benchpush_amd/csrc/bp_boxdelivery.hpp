@@ -724,7 +724,7 @@ __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams 
         }
         // ---------------- the sim step ----------------
         substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
-        if (BP_UNLIKELY2(D.dbg != nullptr && env == D.dbg_env && total_sub < 10100u)) { // bp_debug_trace: (x, y, angle) of every body after each sim step
+        if (BP_UNLIKELY2(BP_TRACE_ON(D) && env == D.dbg_env && total_sub < 10100u)) { // bp_debug_trace: (x, y, angle) of every body after each sim step
             for (int i = lane; i < E.nb; i += 64) {
                 double *o = D.dbg + ((size_t)total_sub * P.nbcap + i) * 3;
                 o[0] = E.pxy[i].x; o[1] = E.pxy[i].y; o[2] = E.ang[i];

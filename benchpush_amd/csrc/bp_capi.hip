@@ -125,6 +125,7 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     memset(&P, 0, sizeof(P));
     P.dt_sub = cfg->dt / cfg->steps;
     P.steps = cfg->steps; P.iterations = cfg->iterations; P.persistence = cfg->persistence; P.settle_steps = cfg->settle_steps;
+    if (const char *evp = getenv("BP_DEBUG_PATHS")) P.dbg_paths = atoi(evp); // test hook: force the rarely taken paths of the narrow phase (bp_device.hpp)
     P.damping_pow = cfg->damping_pow; P.bias_coef = cfg->bias_coef; P.slop = cfg->slop;
     P.target_speed = cfg->target_speed; P.max_yaw_rate = cfg->max_yaw_rate;
     P.map_w = cfg->map_w; P.map_h = cfg->map_h; P.goal_y = cfg->goal_y; P.m_to_pix = cfg->m_to_pix;
@@ -894,6 +895,7 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     memset(&P, 0, sizeof(P));
     P.dt_sub = cfg->ctrl_dt / cfg->steps;
     P.steps = cfg->steps; P.iterations = cfg->iterations; P.persistence = cfg->persistence; P.settle_steps = cfg->settle_steps;
+    if (const char *evp = getenv("BP_DEBUG_PATHS")) P.dbg_paths = atoi(evp); // test hook: force the rarely taken paths of the narrow phase (bp_device.hpp)
     P.damping_pow = cfg->damping_pow; P.bias_coef = cfg->bias_coef; P.slop = cfg->slop;
     P.target_speed = cfg->target_speed;
     P.skin = 0.25;
@@ -1257,11 +1259,15 @@ int bp_set_resettle(bp_handle *h, int32_t on)
     return BP_OK;
 }
 
-// debug hook used by the parity tests: trace (x, y, angle) of every body of one env after each sub-step of the next
+// debug hook of the diagnostic twin (-DBP_DEBUG_PATHS): trace (x, y, angle) of every body of one env after each sub-step of the next
 // launches into a device buffer [substeps][nb_cap][3]; pass NULL to disable.
 int bp_debug_trace(bp_handle *h, double *dev_buf, int32_t env)
 {
     if (!h) return BP_EINVAL;
+#ifndef BP_DEBUG_PATHS
+    // the product kernels do not test the trace pointer every sub-step; the diagnostic twin does (benchpush_amd/build.py: build_debug_paths)
+    if (dev_buf) return fail(h, BP_ESTATE, "bp_debug_trace needs the -DBP_DEBUG_PATHS build (BP_PROF=1 BP_PROF_LIB=.../libbenchpush_hip_dbgpaths.so)");
+#endif
     h->D.dbg = dev_buf;
     h->D.dbg_env = env;
     return BP_OK;

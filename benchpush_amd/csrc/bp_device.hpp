@@ -35,6 +35,8 @@ struct DevParams {
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
     int sq_mode;                               // 0 = scheduled launch, 1 = completion launch: workgroup b finishes env b if the scheduled launch left it unfinished
     int sq_debug;                              // test hook (BP_SCHED_DEBUG_DROP=1): env 1 is parked after its first chunk and never queued, the watchdog is short
+    int dbg_paths;                             // test hook (BP_DEBUG_PATHS bit mask): 1 no candidate cache, 2 bound rounds through the sequential (flushing) loop,
+                                               // 4 cached planes always through the support query, 8 manifold support vertices always through the support query
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
     double start_x_range, ship_mass;
     unsigned long long start_seed;

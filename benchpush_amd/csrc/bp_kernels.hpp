@@ -432,7 +432,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (it == nsub - 10) pr_c10 = S.costp;
 #endif
         substep<KIND>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
-        if (BP_UNLIKELY2(S.quiescent && D.dbg == nullptr)) {
+        if (BP_UNLIKELY2(S.quiescent && !BP_TRACE_ON(D))) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active
             // arbiters are re-stamped (FIRST -> NORMAL), cached ones age out after `persistence` sub-steps, and the
@@ -451,7 +451,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             step_done = true;
             break;
         }
-        if (BP_UNLIKELY2(D.dbg != nullptr && env == D.dbg_env)) {
+        if (BP_UNLIKELY2(BP_TRACE_ON(D) && env == D.dbg_env)) {
             for (int base = 0; base < E.nb; base += 64) {
                 const int i = base + lane;
                 if (i < E.nb) {

@@ -34,6 +34,16 @@
 // pass *likely* costs 8 %, marking these unlikely gains 1.5 % (same-box A/B, tools/experiments/README.md).
 #define BP_UNLIKELY(x) __builtin_expect(!!(x), 0)
 #define BP_UNLIKELY2(x) __builtin_expect(!!(x), 0)
+// Diagnostic build (-DBP_DEBUG_PATHS, libbenchpush_hip_dbgpaths.so): BP_DEBUG_PATHS=<mask> in the environment forces the fallbacks that the fast paths of the
+// narrow phase normally shadow (DevParams::dbg_paths).  In the product build the tests cost nothing: a run-time test of the mask measured -2 %.
+// bp_debug_trace (per-sub-step poses of one env) lives in the same twin: the product kernels do not test the trace pointer every sub-step.
+#ifdef BP_DEBUG_PATHS
+#define BP_DBGP(bit) ((P.dbg_paths & (bit)) != 0)
+#define BP_TRACE_ON(D) ((D).dbg != nullptr)
+#else
+#define BP_DBGP(bit) false
+#define BP_TRACE_ON(D) false
+#endif
 struct ArbReg {
     unsigned key, stamp, h0, h1;
     int state, count, level, rank;
@@ -391,7 +401,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         int i, j, s, nA_h, nB_h;
         bool valid, flagonly;
         unsigned long long hw;
-        const bool cached = S.cc_ok && base == 0;
+        const bool cached = S.cc_ok && base == 0 && !BP_DBGP(1);
         if (cached) {
             const unsigned long long c = L.cc[lane];
             hw = L.cc_hw[lane];
@@ -465,11 +475,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         bool qryA = evA, qryB = evB; // sides whose cached support vertex does not pass the local test: searched by support_queries
         {   // the cached support vertex against its two neighbours (BP_SUPPORT_MARGIN): exact minimum and first index without a search
             const double dm = vdot(fnA, vAm), d0 = vdot(fnA, vA0), dp = vdot(fnA, vAp);
-            if (evA && cnB == nB_h && cnB >= 2 && d0 + BP_SUPPORT_MARGIN <= dm && d0 + BP_SUPPORT_MARGIN <= dp) { sepAc = (d0 - cA) + 0.0; qryA = false; }
+            if (evA && cnB == nB_h && cnB >= 2 && d0 + BP_SUPPORT_MARGIN <= dm && d0 + BP_SUPPORT_MARGIN <= dp && !BP_DBGP(4)) { sepAc = (d0 - cA) + 0.0; qryA = false; }
         }
         {
             const double dm = vdot(fnB, vBm), d0 = vdot(fnB, vB0), dp = vdot(fnB, vBp);
-            if (evB && cnA == nA_h && cnA >= 2 && d0 + BP_SUPPORT_MARGIN <= dm && d0 + BP_SUPPORT_MARGIN <= dp) { sepBc = (d0 - cB) + 0.0; qryB = false; }
+            if (evB && cnA == nA_h && cnA >= 2 && d0 + BP_SUPPORT_MARGIN <= dm && d0 + BP_SUPPORT_MARGIN <= dp && !BP_DBGP(4)) { sepBc = (d0 - cB) + 0.0; qryB = false; }
         }
         {
             const unsigned long long mqA = ballot(qryA), mqB = ballot(qryB);
@@ -539,7 +549,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             // buffer.  If they do not all fit (rare: pairs without cached planes), the sequential loop below redoes the rounds group by group.
             int rr_start = nc;
             {
-                bool fits = true;
+                bool fits = !BP_DBGP(2);
                 for (int r0 = 0; r0 < nc && fits; r0 += 2) {
                     const bool two = r0 + 1 < nc;
                     const uint4 pa0 = L.pt_a[r0], pa1 = L.pt_a[two ? r0 + 1 : r0];
@@ -728,13 +738,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             if (touching && src == 0) {
                 const double c0 = vdot(aA, n), c1 = vdot(bA, n), o0 = vdot(oA0, n), o1 = vdot(oA1, n);
                 const double cm = (c0 > c1) ? c0 : c1, om = (o0 > o1) ? o0 : o1;
-                if (nA == 2 || cm >= om + BP_SUPPORT_MARGIN) { i1A = (c0 > c1) ? iA0 : (c1 > c0) ? iA : min(iA0, iA); needA = false; }
+                if ((nA == 2 || cm >= om + BP_SUPPORT_MARGIN) && !BP_DBGP(8)) { i1A = (c0 > c1) ? iA0 : (c1 > c0) ? iA : min(iA0, iA); needA = false; }
             }
             if (touching && src == 1) {
                 const d2 nn = vneg(n);
                 const double c0 = vdot(aB, nn), c1 = vdot(bB, nn), o0 = vdot(oB0, nn), o1 = vdot(oB1, nn);
                 const double cm = (c0 > c1) ? c0 : c1, om = (o0 > o1) ? o0 : o1;
-                if (nB == 2 || cm >= om + BP_SUPPORT_MARGIN) { i1B = (c0 > c1) ? iB0 : (c1 > c0) ? iB : min(iB0, iB); needB = false; }
+                if ((nB == 2 || cm >= om + BP_SUPPORT_MARGIN) && !BP_DBGP(8)) { i1B = (c0 > c1) ? iB0 : (c1 > c0) ? iB : min(iB0, iB); needB = false; }
             }
             // the winners of both sides are the next sub-step's cached planes
             const unsigned long long nh = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
@@ -1219,7 +1229,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     if (ship_rules) {
         const double a0 = L.ag[0].x;
         const double x0 = L.sp[0].x;
-        if (P.env_kind == BP_ENV_SHIP_ICE && (a0 <= 0.0 || a0 >= BP_PI)) {
+        if (KIND == BP_ENV_SHIP_ICE && (a0 <= 0.0 || a0 >= BP_PI)) {
             if (lane < P.nkin) L.sw[lane] = mk2(0.0, L.sw[lane].y);
             S.yaw_violated = 1;
         }

@@ -124,6 +124,23 @@ def test_cached_plane_hints_never_change_results(kind, conc):
             assert torch.equal(a, b), (kind, conc, sc)
 
 
+@pytest.mark.parametrize("mask", [1, 2, 4, 8, 15])
+def test_rarely_taken_narrow_phase_paths_match_oracle(monkeypatch, mask):
+    """BP_DEBUG_PATHS forces the fallbacks of the narrow phase that the fast paths normally shadow: 1 = no candidate cache, 2 = bound rounds through the
+    sequential loop that flushes the query buffer, 4 = cached planes through the eight-lane support query instead of the three-dot certificate,
+    8 = manifold support vertices through the support query instead of the certificate of the winning edge.  Each is bit-identical to the oracle."""
+    from benchpush_amd import _lib
+    from benchpush_amd.build import DBG_LIB_PATH, build_debug_paths
+    build_debug_paths()                                   # -DBP_DEBUG_PATHS twin of the library (built by __graft_entry__.build(); up to date -> no-op)
+    monkeypatch.setattr(_lib, "_lib", None)               # load the twin for this test only; monkeypatch restores the product library afterwards
+    monkeypatch.setenv("BP_PROF", "1")
+    monkeypatch.setenv("BP_PROF_LIB", DBG_LIB_PATH)
+    monkeypatch.setenv("BP_DEBUG_PATHS", str(mask))
+    assert _run_parity(E=6, conc=0.3, T=3, steps=24, seed=9) > 300
+    if mask in (2, 15):
+        assert _run_parity(E=4, conc=0.5, T=2, steps=10, seed=4) > 100
+
+
 def test_dispatch_order_hint_never_changes_results():
     """bp_set_step_cost_hint (the dispatch order of the step kernel) with random and with reversed hints: same states, rewards and observations."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials

@@ -6,6 +6,10 @@ import ctypes as C
 import os
 import sys
 
+# bp_debug_trace lives in the diagnostic twin of the library (python -c "from benchpush_amd.build import build_debug_paths; build_debug_paths()")
+os.environ.setdefault("BP_PROF", "1")
+os.environ.setdefault("BP_PROF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchpush_amd", "libbenchpush_hip_dbgpaths.so"))
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import torch

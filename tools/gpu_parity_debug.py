@@ -1,6 +1,10 @@
 """GPU-vs-oracle parity probe (run on the GPU box): python tools/gpu_parity_debug.py [E] [steps] [conc]"""
 import os
 import sys
+
+# bp_debug_trace lives in the diagnostic twin of the library (python -c "from benchpush_amd.build import build_debug_paths; build_debug_paths()")
+os.environ.setdefault("BP_PROF", "1")
+os.environ.setdefault("BP_PROF_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "benchpush_amd", "libbenchpush_hip_dbgpaths.so"))
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
