@@ -134,11 +134,15 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // the true sequence is unimodal and the computed dot products are within ~1e-13 of the true ones (coordinates below 64 m), so every other vertex
 // is then larger too and j is the unique first minimum.
 #define BP_SUPPORT_MARGIN 1e-10
+#ifndef BP_QCAP
 #define BP_QCAP 96          // support queries per batch (LDS)
+#endif
 
 #define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step
 #define BP_MBOX 16          // manifold mailbox entries per hand-over batch
+#ifndef BP_NSLOT
 #define BP_NSLOT 96         // velocity slots per env (bodies with a non-zero velocity or an arbiter)
+#endif
 #define BP_PROFN 64         // diagnostic build: phase timers / trip counters per env
 
 // LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the

@@ -738,7 +738,10 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         }
     }
 }
-__global__ __launch_bounds__(64, 2) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+#ifndef BP_SCHED_WAVES
+#define BP_SCHED_WAVES 2
+#endif
+__global__ __launch_bounds__(64, BP_SCHED_WAVES) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
 {

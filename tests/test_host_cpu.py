@@ -204,3 +204,32 @@ def test_episode_metric_allgather_world_size_2_gloo(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+def test_bench_gpus_2_really_starts_two_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself: the line's n_gpus is the number
+    of ranks that joined the process group.  Here: gloo, no environment (--plumbing-only), the real [E/R, 6] episode-block all-gather."""
+    import json
+    env = dict(os.environ, BP_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only", "--envs-per-gpu", "4096"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["plumbing_only"] is True and d["gathered_shape"] == [8192, 6]
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Fewer devices than ranks: rc != 0 and no JSON line, instead of N copies of a 1-GPU number."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BP_BENCH_BACKEND"):
+        env.pop(k, None)
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and not p.stdout.decode().strip()
+    assert "refusing" in p.stderr.decode()

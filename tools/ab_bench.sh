@@ -6,6 +6,6 @@ if [ "$1" = "--env" ]; then ENV=$2; shift 2; fi
 for rep in 1 2; do
   for lib in "$@"; do
     echo -n "$(basename $lib): "
-    BP_PROF=1 BP_PROF_LIB=$lib python bench.py --env $ENV --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['physics_ms'],3))"
+    BP_PROF=1 BP_PROF_LIB=$lib python bench.py ${AB_ARGS} --env $ENV --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['physics_ms'],3))"
   done
 done

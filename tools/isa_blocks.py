@@ -10,11 +10,11 @@ import re
 import sys
 
 # phases of substep() as line ranges of csrc/bp_physics.hpp (update when the file moves; `grep -n "// ---- " csrc/bp_physics.hpp`)
-PH = [(267, 282, '0head'), (283, 356, '1integrate'), (357, 370, '2refresh'), (371, 454, '3candidates'), (455, 504, '4a_cached_planes'),
-      (505, 663, '4a_bound_rounds+search'), (664, 819, '4b_manifold'), (820, 927, '4c_deliver'), (928, 944, '5events+filter'),
-      (945, 982, '6a_prestep'), (983, 1008, '6a_warmset'), (1009, 1048, '6a_colour'), (1049, 1061, '6b_velint'), (1062, 1085, '6c_warmstart'),
-      (1086, 1166, '6d_solver'), (1167, 1215, '7post'), (1216, 1262, '7mvlist'), (237, 265, 'support_queries'), (198, 221, 'world_from_pose'),
-      (145, 197, 'refresh_body')]
+PH = [(278, 293, '0head'), (294, 367, '1integrate'), (368, 381, '2refresh'), (382, 465, '3candidates'), (466, 515, '4a_cached_planes'),
+      (516, 674, '4a_bound_rounds+search'), (675, 830, '4b_manifold'), (831, 938, '4c_deliver'), (939, 955, '5events+filter'),
+      (956, 993, '6a_prestep'), (994, 1019, '6a_warmset'), (1020, 1059, '6a_colour'), (1060, 1072, '6b_velint'), (1073, 1096, '6c_warmstart'),
+      (1097, 1183, '6d_solver'), (1184, 1226, '7post'), (1227, 1277, '7mvlist'), (248, 273, 'support_queries'), (209, 231, 'world_from_pose'),
+      (156, 206, 'refresh_body')]
 
 
 def phase_of(chain):
