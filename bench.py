@@ -326,7 +326,8 @@ def main():
     _check_errors(env)
     # clock the chip held over the timed region: shader-clock counter against the 100 MHz reference, both stamped on the device after every step
     clk1 = env.clock_stamps() if clk0 is not None else None
-    clock_hz = ((clk1[0] - clk0[0]) / max(clk1[1] - clk0[1], 1) * 1e8) if clk1 is not None and clk1[1] > clk0[1] else None
+    # both stamps of the pair come from ONE XCD (the shader-clock counters of different XCDs are not synchronised): the XCD with the longest span
+    clock_hz, clock_xcd = env.clock_hz_between(clk0, clk1) if clk1 is not None else (None, None)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
     if dist is not None:
@@ -392,6 +393,8 @@ def main():
             "accounting": "achieved / peak / frac are the HBM accounting of SURVEY 8d (algorithmic bytes per launch / kernel time against 8 TB/s); what binds "
                           "the kernel is named in 'bound' / 'binds', and 'issue' gives its share of the chip's wave-instruction issue slots",
             "clock_mhz": (clock_hz / 1e6) if clock_hz else None,
+            "clock_source": ("s_memtime / s_memrealtime stamps of XCD %d around the timed launches" % clock_xcd) if clock_hz else
+                            "no stamp pair from one XCD: issue.frac uses the nominal 2.1 GHz",
             "kernel": ("k_physics_step_sched" if sched_chunk > 0 else "k_physics_step"),
             "scheduler": ({"chunk_substeps": sched_chunk, "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
                            "least-advanced waiting env first (DESIGN.md 4a); BP_SCHED=0 selects one wavefront per env for the whole step"}
@@ -424,6 +427,7 @@ def main():
                 "wave_instructions_per_launch": insts * scale,
                 "wave_instructions_per_env_substep": insts * scale / (E * env.params["steps"]),
                 "frac": insts * scale / (1024 * ck * phys_ms * 1e-3),
+                "clock_used_mhz": ck / 1e6,
                 "unit": "wave-instructions per SIMD-cycle (1024 SIMDs x the measured clock x kernel time; VALU+SALU+branch+LDS+VMEM)",
                 "valu_frac": per.get("SQ_INSTS_VALU", 0.0) * scale * 4 / (1024 * ck * phys_ms * 1e-3),
                 "lanes_active": pmc.get("lanes_active"),

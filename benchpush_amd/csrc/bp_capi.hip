@@ -24,6 +24,7 @@ struct bp_handle {
     bool steps_done = false;
     bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
+    bool damp = false;     // bp_config.damping_pow != 0: k_physics_step_damp / k_physics_reset_damp (generic vertex loops, no scheduler)
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
     hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -106,7 +107,7 @@ int bp_create(const bp_config *cfg, int32_t num_envs, int64_t env_id_offset, int
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BP_ENODEVICE;
-    if (cfg->damping_pow != 0.0) return BP_EINVAL;          // only the reference's damping: 0 is supported
+    if (!(cfg->damping_pow >= 0.0) || cfg->damping_pow > 1.0) return BP_EINVAL;   // pow(space.damping, dt) of a damping in [0, 1]; != 0 selects the generic kernels (k_physics_*_damp)
     if (cfg->num_ship_verts < 3 || cfg->num_ship_verts > BP_MAX_SHIP_VERTS) return BP_EINVAL;
     if (cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
     if (cfg->env_kind != BP_ENV_SHIP_ICE && cfg->env_kind != BP_ENV_MAZE) return BP_EINVAL;
@@ -194,6 +195,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     h->P.num_trials = T;
     h->lds_bytes = lds_bytes_for(nbcap, h->P.env_kind == BP_ENV_BOX);
     if (h->lds_bytes > 160 * 1024) return fail(h, BP_EINVAL, "nb_cap too large for LDS");
+    // the candidate cache (LdsCtx::cc, bp_physics.hpp step 3) packs both body indices of a pair into BP_CC_IDX_BITS bits each
+    if (nbcap >= (1 << BP_CC_IDX_BITS)) return fail(h, BP_EINVAL, "nb_cap exceeds the candidate cache's body-index field (16384 bodies per env)");
 
     std::vector<int> h_nb(T), h_nv((size_t)T * nbcap, 0), h_kind((size_t)T * nbcap, 0);
     std::vector<d2> h_lv((size_t)T * nbcap * BP_MAXV), h_ln((size_t)T * nbcap * BP_MAXV);
@@ -287,11 +290,24 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     if ((rc = dalloc(h, &D.m_sum, E * BP_EPM_COUNT))) return rc;
     if ((rc = dalloc(h, &D.m_count, E))) return rc;
     if ((rc = dalloc(h, &D.m_open, E))) return rc;
-    if ((rc = dalloc(h, &D.clk, (size_t)2))) return rc;
+    if ((rc = dalloc(h, &D.clk, (size_t)16))) return rc;
+    HIPCHK(h, hipMemset(D.clk, 0, 16 * sizeof(unsigned long long)));
     D.dbg = nullptr; D.dbg_env = -1; D.prof = nullptr;
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    h->damp = h->P.damping_pow != 0.0;
+    if (h->damp) {
+        // space.damping != 0: one generic pair of kernels for ship-ice and maze handles; settle every trial once with it
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_damp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset_damp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+        if (!settle) return BP_OK;
+        hipLaunchKernelGGL(k_physics_reset_damp, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
+        HIPCHK(h, hipGetLastError());
+        HIPCHK(h, hipDeviceSynchronize());
+        h->loaded = true;
+        return BP_OK;
+    }
     if (h->P.env_kind == BP_ENV_SHIP_ICE && h->P.nkin == 1 && nbcap < 16384) {
         bool plain = true; // one kinematic shape (index 0), dynamic shapes without groups otherwise
         for (int t = 0; t < T && plain; t++)
@@ -323,7 +339,9 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
               h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn; }
+#ifdef BP_DEBUG_PATHS   // fault injection lives in the diagnostic twin only: a stray variable in a job environment cannot disturb the product library
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
+#endif
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         }
     }
@@ -350,7 +368,9 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
               h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn; }
+#ifdef BP_DEBUG_PATHS
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
+#endif
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         }
         HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -492,7 +512,8 @@ __global__ __launch_bounds__(256) void k_debug_round2(const double *__restrict__
 __global__ __launch_bounds__(256) void k_episode_metrics(const DevParams P, const DevPtrs D, const int mode, const unsigned char *__restrict__ mask)
 {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
-    if (env == 0) { D.clk[0] = __builtin_amdgcn_s_memtime(); D.clk[1] = __builtin_amdgcn_s_memrealtime(); }   // bp_get_clock_stamps
+    // bp_get_clock_stamps: the shader-clock counters of the XCDs are not synchronised with each other, so the pair is filed under the XCD that took it
+    if (env == 0) { const int x = sq_xcc_id(); D.clk[2 * x] = __builtin_amdgcn_s_memtime(); D.clk[2 * x + 1] = __builtin_amdgcn_s_memrealtime(); }
     if (env >= P.num_envs) return;
     double *a = D.m_acc + (size_t)env * 8;
     const d2 p = D.pxy[(size_t)env * P.nbcap];
@@ -609,7 +630,11 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             HIPCHK(h, hipGetLastError());
             // completion launch: workgroup b finishes the b-th env that the scheduled launch left unfinished (scheduler watchdog); normally all leave at once
-            static const bool completion = !(getenv("BP_SCHED_COMPLETION") && atoi(getenv("BP_SCHED_COMPLETION")) == 0);   // diagnostic switch
+#ifdef BP_DEBUG_PATHS
+            static const bool completion = !(getenv("BP_SCHED_COMPLETION") && atoi(getenv("BP_SCHED_COMPLETION")) == 0);   // diagnostic switch (twin library only)
+#else
+            constexpr bool completion = true;
+#endif
             if (completion) {
                 hipLaunchKernelGGL(k_sched_scan, dim3(1), dim3(256), 0, st, h->P, h->D);
                 HIPCHK(h, hipGetLastError());
@@ -621,6 +646,10 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                     hipLaunchKernelGGL(k_physics_step_sched, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
             }
         }
+        else if (mode == MODE_STEP && h->damp)
+            hipLaunchKernelGGL(k_physics_step_damp, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (h->resettle && h->damp)
+            hipLaunchKernelGGL(k_physics_reset_damp, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, mask, info, 0);
         else if (mode == MODE_STEP && h->maze8)
             hipLaunchKernelGGL(k_physics_step_maze, dim3(h->num_envs), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
         else if (mode == MODE_STEP)
@@ -815,12 +844,16 @@ int bp_debug_scramble_hints(bp_handle *h, uint64_t seed, void *stream)
     const size_t n = (size_t)h->num_envs * (size_t)h->nbcap * BP_KADJ;
     int *cnt = nullptr, host = 0;
     HIPCHK(h, hipMalloc(&cnt, sizeof(int)));
-    HIPCHK(h, hipMemsetAsync(cnt, 0, sizeof(int), (hipStream_t)stream));
-    hipLaunchKernelGGL(k_debug_scramble_hints, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->D.hint, n, (unsigned long long)seed, cnt);
-    HIPCHK(h, hipMemcpyAsync(&host, cnt, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
-    HIPCHK(h, hipStreamSynchronize((hipStream_t)stream));
-    HIPCHK(h, hipFree(cnt));
-    return host; // number of hint words rewritten (>= 0)
+    hipError_t e = hipMemsetAsync(cnt, 0, sizeof(int), (hipStream_t)stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_scramble_hints, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, h->D.hint, n, (unsigned long long)seed, cnt);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, cnt, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(cnt);   // also on the error paths
+    HIPCHK(h, e);
+    return host; // number of hint words rewritten (>= 0; negative = BP_E*)
 }
 
 int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream)
@@ -1191,13 +1224,14 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 
 int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
 
-int bp_get_clock_stamps(bp_handle *h, uint64_t *out2_host)
+int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
 {
+    uint64_t *out2_host = out16_host;
     if (!h || !out2_host) return BP_EINVAL;
     if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
     BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
-    HIPCHK(h, hipMemcpy(out2_host, h->D.clk, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(out2_host, h->D.clk, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return BP_OK;
 }
 

@@ -95,7 +95,7 @@ struct DevPtrs {
     double *m_sum;           // [E][BP_EPM_COUNT] row fields summed over all finished episodes
     unsigned *m_count;       // [E] finished episodes
     unsigned char *m_open;   // [E] an episode is running (reset seen, not yet terminated)
-    unsigned long long *clk; // [2] shader-clock counter (s_memtime) and 100 MHz reference (s_memrealtime) stamped after the last physics launch
+    unsigned long long *clk; // [8][2] per XCD: shader-clock counter (s_memtime) and 100 MHz reference (s_memrealtime) stamped after a physics launch by a thread of that XCD
     // debug
     double *dbg;             // optional [substeps][nbcap][3] pose trace of env dbg_env
     int dbg_env;
@@ -138,6 +138,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 #define BP_QCAP 96          // support queries per batch (LDS)
 #endif
 
+#define BP_CC_IDX_BITS 14   // candidate cache word (LdsCtx::cc): bits per body index; bp_load_* refuse nb_cap >= 1 << BP_CC_IDX_BITS
 #define BP_EVCAP 32         // box-delivery: pre_solve events per sub-step
 #define BP_MBOX 16          // manifold mailbox entries per hand-over batch
 #ifndef BP_NSLOT
@@ -148,7 +149,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the
 // host (launch size), so the two cannot drift apart.
 struct LdsMap {
-    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, cc, cc_hw, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, mv,
+    unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, cc, cc_hw, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, sbody, mv,
         slot_of, rf, ev_d, ev_key, prof, total;
 };
 __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
@@ -183,6 +184,7 @@ __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, c
     m.owner = p; p += 2u * (BP_NSLOT + 2);    // per velocity slot
     m.colmask = p; p += 2u * (BP_NSLOT + 2);
     m.mvo = p; p += 4u * (BP_NSLOT + 2);      // per velocity slot: stamp of the sub-step whose moving list the body has joined
+    m.sbody = p; p += 2u * (BP_NSLOT + 2);    // per velocity slot: the body that holds it (read by the damping != 0 instantiation only)
     m.mv = p; p += 2u * (unsigned)mvcap;
     m.slot_of = p; p += (unsigned)nbcap;
     m.rf = p; p += 64u;

@@ -53,7 +53,7 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
     L.res_jA = (unsigned *)(b + m.res_jA); L.res_jB = (unsigned *)(b + m.res_jB);
     L.mvs = (unsigned *)(b + m.mvs);
     L.owner = (unsigned short *)(b + m.owner); L.colmask = (unsigned short *)(b + m.colmask);
-    L.mv = (unsigned short *)(b + m.mv); L.mvo = (unsigned *)(b + m.mvo);
+    L.mv = (unsigned short *)(b + m.mv); L.mvo = (unsigned *)(b + m.mvo); L.sbody = (unsigned short *)(b + m.sbody);
     L.slot_of = (unsigned char *)(b + m.slot_of); L.rf = (unsigned char *)(b + m.rf);
     L.ev_key = nullptr; L.ev_d = nullptr;
     if (KIND == BP_ENV_BOX) { L.ev_d = (d2 *)(b + m.ev_d); L.ev_key = (unsigned *)(b + m.ev_key); }
@@ -103,7 +103,7 @@ __device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &
         const int i = base + lane;
         if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     }
-    for (int i = lane; i < BP_NSLOT + 2; i += 64) L.mvo[i] = 0u;
+    for (int i = lane; i < BP_NSLOT + 2; i += 64) { L.mvo[i] = 0u; L.sbody[i] = (unsigned short)i; }   // slots [0, nkin) belong to bodies [0, nkin)
     if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; L.sp[lane] = E.pxy[lane]; }
     if (lane == 0) { L.ag[0] = mk2(E.ang[0], 0.0); L.ag[1] = E.rot[0]; }
     S.nslots = P.nkin;
@@ -153,7 +153,7 @@ __device__ __forceinline__ void load_state_b(const DevParams &P, const DevPtrs &
         if (mvg && i >= P.nkin) {
             int sl = S.nslots + popc_below(ms, lane);
             if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
-            L.slot_of[i] = (unsigned char)sl;
+            L.slot_of[i] = (unsigned char)sl; L.sbody[sl] = (unsigned short)i;
             L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb; L.sp[sl] = E.pxy[i];
         }
         n += __popcll(m);
@@ -261,7 +261,7 @@ __device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevP
 // (returns true) or, at a chunk boundary, an env that has completed fewer chunks is waiting in XCD c_x's queues (returns false, *c_lev_out = chunks
 // completed): an env that is behind everybody else -- a heavy one -- is never parked.  Parking goes through the same store / load as a step boundary,
 // the step-local flags through D.sq_carry.
-template <int mode, int KIND, bool CHUNKED = false>
+template <int mode, int KIND, bool CHUNKED = false, bool DAMP = false>
 __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
@@ -317,7 +317,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             const int i = base + lane;
             if (i < nbcap) {
                 L.mvs[i] = 0u;
-                if (i < BP_NSLOT + 2) L.mvo[i] = 0u;
+                if (i < BP_NSLOT + 2) { L.mvo[i] = 0u; L.sbody[i] = (unsigned short)i; }
                 L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255;
                 if (i < P.nkin) { L.sv[i] = mk2(0.0, 0.0); L.sw[i] = mk2(0.0, 0.0); L.sb[i] = mk2(0.0, 0.0); }
                 if (i < E.nb) {
@@ -431,7 +431,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (it == nsub - 50) pr_c50 = S.costp;
         if (it == nsub - 10) pr_c10 = S.costp;
 #endif
-        substep<KIND>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
+        substep<KIND, DAMP>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
         if (BP_UNLIKELY2(S.quiescent && !BP_TRACE_ON(D))) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active
@@ -758,6 +758,19 @@ __global__ __launch_bounds__(64, 2) void k_physics_reset(const DevParams P, cons
                                                       double *__restrict__ info, const int tmpl)
 {
     physics_body<MODE_RESET, 0>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+}
+// space.damping != 0 (bp_config.damping_pow != 0; no shipped config): the generic instantiation (vertex loops of BP_MAXV, so it serves ship-ice and maze
+// handles alike) with substep<0, DAMP = true>; one wavefront per env for the whole step, no scheduler
+__global__ __launch_bounds__(64, 2) void k_physics_step_damp(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                          double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                          unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    physics_body<MODE_STEP, 0, false, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
+}
+__global__ __launch_bounds__(64, 2) void k_physics_reset_damp(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                           double *__restrict__ info, const int tmpl)
+{
+    physics_body<MODE_RESET, 0, false, true>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
 }
 // maze-NAMO-v0 instantiations (vertex loops of 8)
 __global__ __launch_bounds__(64, 2) void k_physics_step_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,

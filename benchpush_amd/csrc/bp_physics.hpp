@@ -80,6 +80,7 @@ struct LdsCtx {
     d2 *tf;                    // [64][2] (cos, sin) (tx, ty) of the moving bodies of the current chunk
     unsigned short *mv;        // [P.mvcap] moving-body list
     unsigned *mvo;             // [BP_NSLOT] stamp of the sub-step whose (next) moving list the slot's body has joined
+    unsigned short *sbody;     // [BP_NSLOT] body that holds the slot (substep<KIND, DAMP = true> rebuilds the moving list from the slots)
     unsigned char *rf;         // [64] refresh flags of the current chunk
     // narrow phase (per candidate round, indexed by survivor rank): best plane separation of side A / B as order-preserving keys, its plane
     // index and support vertex
@@ -136,7 +137,7 @@ __device__ __forceinline__ int slot_get(const LdsCtx &L, SubState &S, const d2 *
         if (s >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; s = BP_NSLOT - 1; }
         else S.nslots = s + 1;
         if (lane_id() == 0) {
-            L.slot_of[body] = (unsigned char)s;
+            L.slot_of[body] = (unsigned char)s; L.sbody[s] = (unsigned short)body;
             L.sv[s] = mk2(0.0, 0.0); L.sw[s] = mk2(0.0, 0.0); L.sb[s] = mk2(0.0, 0.0);
             L.sp[s] = pxy[body];
         }
@@ -274,7 +275,12 @@ __device__ __forceinline__ void support_queries(const EnvCtx &E, const LdsCtx &L
 
 // One sub-step.  ship_rules: apply the yaw / boundary rules of ShipIceEnv.step after the sub-step.
 // KIND == BP_ENV_BOX adds box-delivery's collision handlers (box_delivery_env.py:208-229,294-311); other values compile them out.
-template <int KIND>
+// DAMP: space.damping != 0 (ship_ice_env.py:120, maze_NAMO_env.py:148: `space.damping = cfg.sim.damping`; every shipped config sets 0).  cpBodyUpdateVelocity
+// then multiplies the velocities of the dynamic bodies by damping^dt instead of clearing them, so a body keeps moving after its contacts are gone: the
+// velocity integrate scales every velocity slot, an arbiter is warm as soon as one of its bodies has a velocity, and the next moving list is rebuilt from the
+// velocity slots (L.sbody) instead of the active arbiters' bodies.  Everything else -- carried-over contacts of unmoved bodies, cold arbiters, the quiescent
+// shortcut -- holds as stated, because each rests on "did not move" / "zero velocity", not on how a velocity came to be zero.
+template <int KIND, bool DAMP = false>
 __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, const LdsCtx &L, ArbReg &A, SubState &S,
                                         const double dt, const bool ship_rules)
 {
@@ -405,7 +411,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         if (cached) {
             const unsigned long long c = L.cc[lane];
             hw = L.cc_hw[lane];
-            i = (int)(c & 0x3FFFu); j = (int)((c >> 14) & 0x3FFFu); s = (int)((c >> 28) & 31u);
+            static_assert(2 * BP_CC_IDX_BITS == 28, "cc word layout: i | j << BP_CC_IDX_BITS | slot << 28 ...");
+            i = (int)(c & ((1u << BP_CC_IDX_BITS) - 1u)); j = (int)((c >> BP_CC_IDX_BITS) & ((1u << BP_CC_IDX_BITS) - 1u)); s = (int)((c >> 28) & 31u);
             nA_h = (int)((c >> 33) & 31u); nB_h = (int)((c >> 38) & 31u);
             valid = ((c >> 43) & 1u) != 0; flagonly = ((c >> 44) & 1u) != 0;
         } else {
@@ -435,7 +442,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             }
             s = min(s, 31);
             if (base == 0) {
-                L.cc[lane] = (unsigned long long)(unsigned)i | ((unsigned long long)(unsigned)j << 14) | ((unsigned long long)(unsigned)s << 28) |
+                L.cc[lane] = (unsigned long long)(unsigned)i | ((unsigned long long)(unsigned)j << BP_CC_IDX_BITS) | ((unsigned long long)(unsigned)s << 28) |
                              ((unsigned long long)(unsigned)nA_h << 33) | ((unsigned long long)(unsigned)nB_h << 38) |
                              ((unsigned long long)(valid ? 1u : 0u) << 43) | ((unsigned long long)(flagonly ? 1u : 0u) << 44);
                 L.cc_hw[lane] = hw;
@@ -998,8 +1005,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     if (active) {
         warm = (A.jn0 != 0.0) || (A.jt0 != 0.0) || (bias0 != 0.0) || (bounce0 != 0.0);
         if (A.count > 1) warm = warm || (A.jn1 != 0.0) || (A.jt1 != 0.0) || (bias1 != 0.0) || (bounce1 != 0.0);
-        if (A.ma == 0.0) { const d2 v = L.sv[A.slotA]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotA].x != 0.0); }
-        if (A.mb == 0.0) { const d2 v = L.sv[A.slotB]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotB].x != 0.0); }
+        // a velocity that survives the velocity integrate: a kinematic body's always does, a dynamic body's only with damping != 0 (a product that
+        // underflows to zero there makes the arbiter warm for nothing, which is exact: warm arbiters run the full arithmetic)
+        if (DAMP || A.ma == 0.0) { const d2 v = L.sv[A.slotA]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotA].x != 0.0); }
+        if (DAMP || A.mb == 0.0) { const d2 v = L.sv[A.slotB]; warm = warm || (v.x != 0.0) || (v.y != 0.0) || (L.sw[A.slotB].x != 0.0); }
         if (A.ma != 0.0) L.owner[A.slotA] = 0;
         if (A.mb != 0.0) L.owner[A.slotB] = 0;
     }
@@ -1058,6 +1067,19 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     S.costp += 16u + 2u * (unsigned)__popcll(amask) + 4u * (unsigned)(__popcll(wmask) * S.nlevels);
     lds_sync();
     // ---- 6b. velocity integrate: damping^dt == 0, no gravity/forces -> dynamic bodies' v, w := +0 ---------------
+    if (DAMP) {
+        // cpBodyUpdateVelocity with damping != 0: v = v * damping^dt + (g + f / m) * dt, w = w * damping^dt + t / I * dt with g = f = t = 0, i.e. "+ 0.0"
+        // (a negative zero becomes +0, like the oracle's).  Every dynamic body with a non-zero velocity holds a velocity slot; bodies of slots at or above
+        // nkin are dynamic or static (zero velocity: unchanged by the arithmetic).
+        for (int s0 = 0; s0 < S.nslots; s0 += 64) {
+            const int sl = s0 + lane;
+            if (sl >= P.nkin && sl < S.nslots) {
+                const d2 v = L.sv[sl], w2 = L.sw[sl];
+                L.sv[sl] = mk2(v.x * P.damping_pow + 0.0, v.y * P.damping_pow + 0.0);
+                L.sw[sl] = mk2(w2.x * P.damping_pow + 0.0, w2.y);
+            }
+        }
+    } else
     for (int k0 = 0; k0 < S.nmv; k0 += 64) {
         const int k = k0 + lane;
         if (k < S.nmv) {
@@ -1253,20 +1275,47 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (A.mb != 0.0 && ((S.evmask >> bbi) & 1ull)) wantB = true;
             }
         }
-        // a body that several arbiters want joins the list once: the first claim of this sub-step's stamp wins (one LDS atomic per side)
-        const bool gotA = wantA && atomicMax(&L.mvo[A.slotA], now) < now;
-        const bool gotB = wantB && atomicMax(&L.mvo[A.slotB], now) < now;
         const d2 v0 = L.sv[0], w0 = L.sw[0];
         // every part of the kinematic agent; the box-delivery robot is re-cached every sub-step (its controller rewrites the
         // velocity between sub-steps; re-evaluating an unmoved body reproduces the carried-over result exactly)
         const int shipmv = (KIND == BP_ENV_BOX || v0.x != 0.0 || v0.y != 0.0 || w0.x != 0.0) ? P.nkin : 0;
-        const unsigned long long mA = ballot(gotA), mB = ballot(gotB);
-        const int nA_ = __popcll(mA);
         // the list is rewritten in place; if it comes out as it was, the candidate cache of the first candidate round stays valid
         bool differs = false;
         if (lane < shipmv) { differs = L.mv[lane] != (unsigned short)lane; L.mv[lane] = (unsigned short)lane; }
+        int nA_ = 0;
+        unsigned long long mB = 0ull;
+        if (DAMP) {
+            // damping != 0: a body keeps its velocity without any arbiter -- every velocity slot whose body still moves joins the list, in slot order
+            // (the order of the list only permutes independent work: pairs are keyed by body, arbiters are solved in (colour, key) order)
+            int pos0 = shipmv;
+            for (int s0 = 0; s0 < S.nslots; s0 += 64) {
+                const int sl = s0 + lane;
+                bool want = false;
+                unsigned short body = 0;
+                if (sl >= P.nkin && sl < S.nslots) {
+                    body = L.sbody[sl];
+                    const d2 v = L.sv[sl], w2 = L.sw[sl], vb = L.sb[sl];
+                    want = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
+                }
+                const unsigned long long m = ballot(want);
+                if (want) {
+                    const int pos = pos0 + popc_below(m, lane);
+                    if (pos < P.mvcap) { differs = differs || L.mv[pos] != body; L.mv[pos] = body; }
+                }
+                pos0 += __popcll(m);
+            }
+            if (pos0 > P.mvcap) { S.err |= BP_ERR_ARB_OVERFLOW; pos0 = P.mvcap; }
+            nA_ = pos0 - shipmv;
+        } else {
+        // a body that several arbiters want joins the list once: the first claim of this sub-step's stamp wins (one LDS atomic per side)
+        const bool gotA = wantA && atomicMax(&L.mvo[A.slotA], now) < now;
+        const bool gotB = wantB && atomicMax(&L.mvo[A.slotB], now) < now;
+        const unsigned long long mA = ballot(gotA);
+        mB = ballot(gotB);
+        nA_ = __popcll(mA);
         if (gotA) { const int pos = shipmv + popc_below(mA, lane); differs = differs || L.mv[pos] != (unsigned short)ba; L.mv[pos] = (unsigned short)ba; }
         if (gotB) { const int pos = shipmv + nA_ + popc_below(mB, lane); differs = differs || L.mv[pos] != (unsigned short)bbi; L.mv[pos] = (unsigned short)bbi; }
+        }
         const int newn = shipmv + nA_ + __popcll(mB);
         if (newn != S.nmv || ballot(differs)) S.cc_ok = 0;
         S.nmv = newn;

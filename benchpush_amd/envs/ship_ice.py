@@ -247,10 +247,24 @@ class BatchedShipIceEnv(_BatchedBase):
         return out.astype(np.uint64) << 8
 
     def clock_stamps(self):
-        """(shader-clock counter, 100 MHz reference counter) stamped after the last physics launch: the clock held between two calls is d0 / d1 x 100 MHz."""
-        out = np.zeros(2, np.uint64)
+        """uint64 [8, 2]: per XCD the latest (shader-clock counter, 100 MHz reference counter) pair stamped after a physics launch by a thread of that
+        XCD (zeros: none yet).  `clock_hz_between` turns two readings into the clock the chip held in between."""
+        out = np.zeros((8, 2), np.uint64)
         _lib.check(self.L, self.h, self.L.bp_get_clock_stamps(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_clock_stamps")
-        return int(out[0]), int(out[1])
+        return out
+
+    @staticmethod
+    def clock_hz_between(c0, c1):
+        """Shader clock between two `clock_stamps()` readings: both counters of ONE XCD (the counters of different XCDs are not synchronised), the XCD
+        with the longest span of reference time between its two stamps.  Returns (hz, xcd) or (None, None) if no XCD was stamped before both readings."""
+        best = (None, None, 0)
+        for x in range(8):
+            if c0[x, 1] == 0 or c1[x, 1] <= c0[x, 1]:
+                continue
+            span = int(c1[x, 1]) - int(c0[x, 1])
+            if span > best[2]:
+                best = ((int(c1[x, 0]) - int(c0[x, 0])) / span * 1e8, x, span)
+        return best[0], best[1]
 
     def sched_warnings(self):
         """(watchdog events, envs finished by the completion launch) of the step scheduler since load: (0, 0) unless a scheduler fault occurred."""
@@ -277,8 +291,10 @@ class BatchedShipIceEnv(_BatchedBase):
         return p.value, r.value, n.value
 
     def debug_trace(self, buf, env=0):
+        """Per-sub-step pose trace of one env into `buf`; only the -DBP_DEBUG_PATHS twin of the library records it (the product library returns BP_ESTATE
+        for a non-null buffer, which surfaces here instead of leaving an all-zero trace behind)."""
         self._dbg = buf
-        self.L.bp_debug_trace(self.h, _ptr(buf), int(env))
+        _lib.check(self.L, self.h, self.L.bp_debug_trace(self.h, _ptr(buf) if buf is not None else None, int(env)), "bp_debug_trace")
 
 
 class ShipIceEnv(Env):

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 7
+#define BP_ABI_VERSION 8
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -62,7 +62,11 @@ typedef struct bp_config {
     int32_t iterations;      /* solver iterations */
     int32_t persistence;     /* Chipmunk collision_persistence */
     int32_t settle_steps;    /* sub-steps run by reset */
-    double damping_pow;      /* pow(space.damping, dt/steps); only 0 is supported on the GPU */
+    double damping_pow;      /* pow(space.damping, dt/steps), in [0, 1] (ship_ice_env.py:120, maze_NAMO_env.py:148: space.damping = cfg.sim.damping).
+                              * 0 (every shipped config) runs the specialised kernels; any other value selects a generic instantiation of the same
+                              * sub-step (k_physics_step_damp: velocities scaled instead of cleared, moving list rebuilt from the velocity slots,
+                              * no step scheduler) -- slower, and bodies once pushed keep moving, so the in-kernel capacities (BP_ECAPACITY) are
+                              * reached sooner.  box-delivery / area-clearing handles (bp_bd_create) accept 0 only and return BP_EINVAL otherwise. */
     double bias_coef;        /* 1 - pow(collision_bias, dt/steps) */
     double slop;
     double target_speed;
@@ -228,9 +232,11 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
  * maze handles of up to 8192 envs; environment variable BP_SCHED=<chunk> (0 = off) overrides it at load time. */
 int32_t bp_sched_chunk(bp_handle *h);
 /* Clock calibration for bench.py: the shader-clock counter (s_memtime) and the 100 MHz reference counter (s_memrealtime) stamped on the device right
- * after the last physics launch of bp_step / bp_reset (ship-ice and maze handles): the clock the chip held between two calls is
- * (d out[0]) / (d out[1]) x 100 MHz (MI355X_MICROARCH.md, DVFS item 6).  Host uint64 [2] (synchronises). */
-int bp_get_clock_stamps(bp_handle *h, uint64_t *out2_host);
+ * after every physics launch of bp_step / bp_reset (ship-ice and maze handles) by one thread, filed under the XCD it ran on (the shader-clock counters
+ * of different XCDs are not synchronised): out[x][0..1] = the latest pair taken on XCD x, zeros if none yet.  The clock the chip held between two
+ * calls is (d out[x][0]) / (d out[x][1]) x 100 MHz for any x stamped before the first and before the second call (MI355X_MICROARCH.md, DVFS item 6).
+ * Host uint64 [8][2] (synchronises).  ABI 8 (ABI 7: one pair, whatever the XCD). */
+int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host);
 /* Scheduler robustness counters since bp_load_*: out2_host[0] = launches in which the watchdog of the step scheduler fired (a workgroup gave up
  * waiting for a parked env -- a scheduler fault, never seen in practice), out2_host[1] = envs whose step the completion launch that follows every
  * scheduled launch had to finish.  Results are complete and identical either way; non-zero values are a warning, not an error (synchronises). */

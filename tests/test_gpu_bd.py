@@ -260,6 +260,28 @@ def test_other_action_types_match_oracle(atype):
     env.close()
 
 
+def test_config_c4_size_12_boxes_matches_oracle():
+    """BASELINE.json configs[3]'s own size -- `num_boxes_small: 12` (the shipped default is 10): 3 envs x 5 steps against the oracle, the same
+    constructor arguments as bench.py --env box and the full-size property test below."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    cfg.boxes.num_boxes_small = 12
+    E = 3
+    trials = S.generate_trials(cfg, E)
+    assert all(len(t["boxes"]) == 12 for t in trials)
+    env = BatchedBoxDeliveryEnv(E, cfg={"boxes": {"num_boxes_small": 12}}, trials=trials)
+    assert env.nbox == 12
+    oracles = [_oracle(cfg, trials[e]) for e in range(E)]
+    obs, info = env.reset()
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
+    rng = np.random.RandomState(12)
+    for t in range(5):
+        _compare_step(env, oracles, rng.uniform(-1, 1, E), "12 boxes, step %d" % t)
+    env.check_errors()
+    env.close()
+
+
 def test_full_size_properties_4096_envs():
     """BASELINE.json configs[3] size (box-delivery-v0, 4096 envs, 12 boxes): oracle-free properties.  Envs that play the same trial with
     the same actions must produce the same bits (env e plays trial e % T), counters are monotone, everything stays finite and in range."""

@@ -237,6 +237,53 @@ def test_whole_episode_soak_no_capacity_flags(E, conc, steps, ntrials):
     env.close()
 
 
+def test_last_rank_shard_of_c5_matches_oracle_on_sampled_envs():
+    """BASELINE.json configs[4] (C5) as its LAST rank sees it: 4096 envs at 50 %, `env_id_offset = 7 * 4096` (the other soaks run rank 0's shard).
+    Env e of the shard plays trial (7 * 4096 + e + episode) % T; 8 envs spread over the shard are compared bit for bit with the oracle for 20 steps
+    (body state, reward, termination, an observation every 5 steps, resets included), the whole shard is soaked for 60 steps with check_errors()."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    from oracle.oracle import OracleShipIce
+    E, T, OFF = 4096, 100, 7 * 4096
+    trials = default_trials(0.5, T, base_seed=0)
+    env = BatchedShipIceEnv(E, cfg={"concentration": 0.5}, trials=trials, device="cuda:0", env_id_offset=OFF)
+    c = env.cfg
+    sample = [0, 1, 511, 1024, 2049, 3000, 4094, 4095]
+    orcs = {e: OracleShipIce(env.params, c.ship.vertices, c.ship.head, c.ship.tail) for e in sample}
+    eps = {e: 0 for e in sample}
+    obs, _ = env.reset()
+    for e in sample:
+        oo, _ = orcs[e].reset(trials[(OFF + e) % T])
+        assert np.array_equal(obs[e].cpu().numpy(), oo), e
+    g = torch.Generator(device=env.device)
+    g.manual_seed(77)
+    for t in range(60):
+        a = (torch.rand(E, generator=g, device=env.device, dtype=torch.float64) * 2 - 1) * 0.6
+        obs, rew, term, _, info = env.step(a)
+        if t < 20:
+            bs = env.body_state()
+            ah = a.cpu().numpy()
+            for e in sample:
+                oo, orr, ot, _ = orcs[e].step(float(ah[e]), observe=(t % 5 == 0))
+                nb = len(orcs[e].bodies())
+                assert np.array_equal(bs[e, :nb].cpu().numpy(), orcs[e].bodies()), (t, e)
+                assert float(rew[e]) == orr and bool(term[e]) == ot, (t, e)
+                if t % 5 == 0:
+                    assert np.array_equal(obs[e].cpu().numpy(), oo), (t, e)
+        obs2, _ = env.reset(term)
+        if t < 20:
+            tm = term.cpu().numpy().astype(bool)
+            for e in sample:
+                if tm[e]:
+                    eps[e] += 1
+                    oo, _ = orcs[e].reset(trials[(OFF + e + eps[e]) % T])
+                    assert np.array_equal(obs2[e].cpu().numpy(), oo), (t, e)
+        if t % 20 == 19:
+            env.check_errors()
+            assert bool(torch.isfinite(rew).all()) and bool(torch.isfinite(info).all())
+    env.check_errors()
+    env.close()
+
+
 @pytest.mark.parametrize("E,conc,steps", [(8, 0.3, 300), (4, 0.5, 120)])
 def test_sampled_envs_bit_exact_over_300_steps(E, conc, steps):
     """8 envs x 300 steps at 30 % (and 4 x 120 at 50 %, the concentration of config C5) against the oracle -- the parity suite's other

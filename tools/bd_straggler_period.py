@@ -32,7 +32,9 @@ def run(trace=None):
         buf = None
         if trace is not None and trace[0] == t:
             buf = torch.full((CAP, nbcap, 3), float("nan"), dtype=torch.float64, device=env.device)
-            env.L.bp_debug_trace(env.h, C.c_void_p(buf.data_ptr()), int(trace[1]))
+            rc = env.L.bp_debug_trace(env.h, C.c_void_p(buf.data_ptr()), int(trace[1]))
+            if rc != 0:
+                raise SystemExit("bp_debug_trace: rc %d -- this tool needs the -DBP_DEBUG_PATHS twin of the library (benchpush_amd.build.build_debug_paths)" % rc)
         _, _, term, _, _ = env.step(a)
         torch.cuda.synchronize()
         if buf is not None:
