@@ -643,13 +643,15 @@ __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams 
             // ideal_control (dp.py:217-248)
             const double theta_d = bd_atan2(spy - prevy, spx - prevx);
             double theta_e = theta_d - prevh;
-            double se, ce;
-            bp_sincos(theta_e, se, ce);
+            // the two sincos of the controller (theta_e here, the heading for the goal velocity below) are independent: lane 1 evaluates the second one
+            // while the other lanes evaluate the first -- one pass of the polynomial instead of two
+            double sn2, cs2;
+            bp_sincos(lane == 1 ? prevh : theta_e, sn2, cs2);
+            const double se = __shfl(sn2, 0), ce = __shfl(cs2, 0);
+            const double sy_ = __shfl(sn2, 1), cy_ = __shfl(cs2, 1);
             theta_e = bd_atan2(se, ce);
             double omega = 1.0 * theta_e;
             omega = omega / B.ctrl_dt;
-            double sy_, cy_;
-            bp_sincos(prevh, sy_, cy_);
             const double gvx = cy_ * B.target_speed + -sy_ * 0.0, gvy = sy_ * B.target_speed + cy_ * 0.0;
             al += B.target_speed * B.ctrl_dt;  // TargetCourse.advance
             sp_one = plen < al;
@@ -658,7 +660,7 @@ __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams 
                 L.sw[lane] = mk2(omega * B.omega_scale, L.sw[lane].y);
                 L.sv[lane] = done_turning ? mk2(gvx * B.v_scale, gvy * B.v_scale) : mk2((gvx * 0) * B.v_scale, (gvy * 0) * B.v_scale);
             }
-            __syncthreads();
+            lds_sync();   // velocity slots live in LDS and the workgroup is one wavefront: no drain of the global stores of the last sim step
 #ifdef BP_PROF
             _t_ctrl += __builtin_amdgcn_s_memtime() - _tc0;
 #endif
@@ -673,23 +675,60 @@ __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams 
             }
             __syncthreads();
         } else if (phase == PH_STILL) {
-            // boxes with a vertex strictly inside an obstacle shape are moved to the nearest free cell
+            // boxes with a vertex strictly inside an obstacle shape are moved to the nearest free cell (box_delivery_env.py:995-1004).  The test is a pure
+            // function of the box's pose (the obstacle shapes never move), and a box that failed it was relocated, i.e. it moved: a box that did not move in
+            // the last sim step (L.mvs, the stamp of the sub-step that last integrated it) would repeat the answer "free" of the previous iteration and is
+            // skipped; the first iteration tests every box.  Of the (box vertex, obstacle shape) items of the boxes that are left, those whose vertex lies
+            // outside the shape's AABB -- nearly all -- are dropped by a first pass that costs a comparison; the point query runs on the compacted rest.
             unsigned long long stuck = 0ull;
-            const int items = nalive * 4 * nstat;
+            const bool cand = lane < nalive && (!have_prev || L.mvs[B.first_box + order[lane]] == S.stamp);
+            const unsigned long long candm = ballot(cand);
+            if (cand) L.rf[popc_below(candm, lane)] = (unsigned char)lane;   // L.rf: scratch of the integrate phase, free between sim steps
+            lds_sync();
+            const int items = __popcll(candm) * 4 * nstat;
+            unsigned *surv = L.q_meta;   // [BP_QCAP] item ids that passed the AABB test (narrow-phase scratch, free between sim steps)
+            int nsurv = 0;
+            auto run_queries = [&]() {   // full point query on the compacted items
+                for (int b2 = 0; b2 < nsurv; b2 += 64) {
+                    const int k = b2 + lane;
+                    bool hit = false;
+                    int q = 0;
+                    if (k < nsurv) {
+                        const int it = (int)surv[k];
+                        const int c = it / (4 * nstat);
+                        q = L.rf[c];
+                        const int rem = it - c * 4 * nstat, vi = rem / nstat, s2 = first_static + (rem - vi * nstat);
+                        const int body = B.first_box + order[q];
+                        hit = bd_point_in_shape(E.wv + s2 * BP_MAXV, E.wn + s2 * BP_MAXV, E.nv[s2], E.prop[s2].x, E.bb[s2], bd_local_to_world(E, body, vi));
+                    }
+                    unsigned long long hm = ballot(hit);
+                    while (hm) { const int l = __ffsll((long long)hm) - 1; hm &= hm - 1; stuck |= 1ull << __shfl(q, l); }
+                }
+                nsurv = 0;
+            };
             for (int base = 0; base < items; base += 64) {
                 const int it = base + lane;
-                bool hit = false;
-                int q = 0;
+                bool pre = false;
                 if (it < items) {
-                    q = it / (4 * nstat);
-                    const int rem = it - q * 4 * nstat, vi = rem / nstat, s2 = first_static + (rem - vi * nstat);
+                    const int c = it / (4 * nstat);
+                    const int q = L.rf[c];
+                    const int rem = it - c * 4 * nstat, vi = rem / nstat, s2 = first_static + (rem - vi * nstat);
                     const int body = B.first_box + order[q];
-                    if (vi < E.nv[body])
-                        hit = bd_point_in_shape(E.wv + s2 * BP_MAXV, E.wn + s2 * BP_MAXV, E.nv[s2], E.prop[s2].x, E.bb[s2], bd_local_to_world(E, body, vi));
+                    if (vi < E.nv[body]) {
+                        const d2 p = bd_local_to_world(E, body, vi);
+                        const double4 bb = E.bb[s2];
+                        pre = bb.x <= p.x && p.x <= bb.z && bb.y <= p.y && p.y <= bb.w;   // the first test of bd_point_in_shape
+                    }
                 }
-                unsigned long long hm = ballot(hit);
-                while (hm) { const int l = __ffsll((long long)hm) - 1; hm &= hm - 1; stuck |= 1ull << __shfl(q, l); }
+                const unsigned long long pm = ballot(pre);
+                if (pm) {
+                    if (nsurv + __popcll(pm) > BP_QCAP) { lds_sync(); run_queries(); lds_sync(); }
+                    if (pre) surv[nsurv + popc_below(pm, lane)] = (unsigned)it;
+                    nsurv += __popcll(pm);
+                }
             }
+            lds_sync();
+            if (nsurv) run_queries();
             while (stuck) {
                 const int q = __ffsll((long long)stuck) - 1;
                 stuck &= stuck - 1;

@@ -907,6 +907,20 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     }
     S.cc_ok = 1;   // the first candidate round has (re)built its cache; the moving-list rebuild and the neighbour-list refresh invalidate it
     PROF_ACC(4)
+    if (KIND == BP_ENV_BOX) {
+        // box-delivery: most sim steps of a robot that drives through free space have nothing to solve -- no arbiter exists (none was delivered in this sub-step,
+        // none is still cached from an earlier one), no pre_solve event was recorded and only the robot's own slots are in the moving list.  Steps 5-7 then
+        // reduce to what is written here: an empty active set (the colouring cache follows it), the work proxy, no ship bookkeeping, and a moving list
+        // that comes out as it is (the robot's slots lead the list and are re-listed every sub-step) -- about a quarter of such a sim step's instructions.
+        if (S.nev == 0 && S.nmv == P.nkin && ballot(A.key != ARB_FREE_KEY) == 0) {
+            if (S.prev_amask != 0ull) { S.prev_amask = 0ull; S.nlevels = 0; }
+            S.costp += 16u;
+            S.ship_post = 0u; S.ship_contacts = 0u;
+            S.quiescent = 0;
+            PROF_ACC(9)
+            return;
+        }
+    }
     // arbiters whose bodies did not move keep last sub-step's contacts
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
         const int a = (int)(A.key >> 16), b = (int)(A.key & 0xFFFFu);
