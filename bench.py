@@ -386,8 +386,9 @@ def main():
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
-        # (profiles/r03_final/pmc.json, written by tools/profile_gpu.sh for the build named inside; config c2 only), never measured in this run
-        pmc = profile_sourced(os.path.join("r03_final", "pmc.json")) if (args.env == "ship-ice" and args.config == "c2") else None
+        # (profiles/r04_final/pmc.json -- r03_final until the round's profile exists --, written by tools/profile_gpu.sh for the build named inside; config c2 only), never measured in this run
+        pmc_dir = "r04_final" if os.path.exists(os.path.join(ROOT, "profiles", "r04_final", "pmc.json")) else "r03_final"
+        pmc = profile_sourced(os.path.join(pmc_dir, "pmc.json")) if (args.env == "ship-ice" and args.config == "c2") else None
         roof = {
             "bound": "issue",
             "accounting": "achieved / peak / frac are the HBM accounting of SURVEY 8d (algorithmic bytes per launch / kernel time against 8 TB/s); what binds "
@@ -419,8 +420,13 @@ def main():
             scale = E / float(pmc.get("envs", E))
             roof["traffic"] = (pmc.get("hbm_bytes_per_launch") * scale) if pmc.get("hbm_bytes_per_launch") else None   # per launch of E envs
             roof["wasted_traffic"] = (roof["traffic"] / (a_phys * E)) if roof["traffic"] else None
-            roof["traffic_source"] = "profiles/r03_final/pmc.json (rocprofv3 --pmc passes of build %s, %s envs; not measured in this run)" % (
-                pmc.get("build", "?"), pmc.get("envs", "?"))
+            roof["traffic_source"] = "profiles/%s/pmc.json (rocprofv3 --pmc passes of build %s, %s envs; not measured in this run)" % (
+                pmc_dir, pmc.get("build", "?"), pmc.get("envs", "?"))
+            if pmc.get("lds"):   # LDS bank conflicts beside occupancy and VALU utilisation (same profile-sourced passes)
+                roof["lds_bank_conflict_frac"] = pmc["lds"].get("bank_conflict_frac")
+                roof["lds"] = dict(pmc["lds"], source=roof["traffic_source"],
+                                   what="bank_conflict_frac = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE (extra LDS-array cycles over all LDS-array cycles); "
+                                        "issue_stall_share_of_wave_time = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES; array_busy_frac = LDS-array cycles / (256 CUs x kernel cycles)")
             ck = clock_hz if clock_hz else 2.1e9
             insts += per.get("SQ_INSTS_BRANCH", 0.0)
             roof["issue"] = {

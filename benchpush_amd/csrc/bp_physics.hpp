@@ -1142,9 +1142,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     for (int it = 0; it < P.iterations; it++) {
         PROF_CNT(42, 1)
         // "did any accumulated impulse change in this iteration": the differences jnAcc - jnOld, jtAcc - jtOld (and of the bias impulse) exist anyway;
-        // a difference of finite doubles is zero exactly when they are equal, so the bit patterns (sign aside) are OR-ed into one per-lane word --
-        // no compare-and-merge of lane masks across the divergent contact blocks of every colour pass
-        int chg = 0;
+        // a difference of finite doubles is zero exactly when they are equal, and a sum of magnitudes is zero exactly when every term is (no
+        // cancellation, no underflow: binary64 keeps subnormals; a NaN stays non-zero), so their absolute values are accumulated into one per-lane
+        // double -- two additions per contact instead of the four integer operations of the bit-pattern form, and no compare-and-merge of lane masks
+        double chg = 0.0;
         for (unsigned lm = lvlmask; lm; lm &= lm - 1u) { // colours that hold a warm arbiter, ascending
             const int lvl = __ffs((int)lm) - 1;
             PROF_CNT(43, 1)
@@ -1186,7 +1187,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                         else   { jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
                         if (AB) {
                             const double djb = jBias - jbnOld;
-                            chg |= __double2loint(djb) | (__double2hiint(djb) & 0x7FFFFFFF);
+                            chg += __builtin_fabs(djb);
                             const d2 jb = vmul(n, djb);
                             const d2 jbneg = vneg(jb);
                             vba = vadd(vba, vmul(jbneg, A.ma));
@@ -1195,7 +1196,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                             wb2.y += A.ib * vcross(r2, jb);
                         }
                         const double djn = jnAcc - jnOld, djt = jtAcc - jtOld;
-                        chg |= __double2loint(djn) | __double2loint(djt) | ((__double2hiint(djn) | __double2hiint(djt)) & 0x7FFFFFFF);
+                        chg += __builtin_fabs(djn); chg += __builtin_fabs(djt);   // two adds with |.| as a source modifier; off the pass's dependency chain
                         const d2 j = vrotate(n, mk2(djn, djt));
                         apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
                     }
@@ -1212,7 +1213,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         // an iteration that changed no accumulated impulse applied only zero impulses: the state is a fixed point and
         // the remaining iterations would repeat it exactly
-        if (BP_UNLIKELY2(!ballot(warm && chg != 0))) break;
+        if (BP_UNLIKELY2(!ballot(warm && chg != 0.0))) break;
     }
     };
     if (any_bias) iterate(std::true_type{}); else iterate(std::false_type{});

@@ -356,3 +356,50 @@ def test_inverted_receptacle_map_equals_the_numpy_statement_of_the_reference():
     g[g == (1 - pm["cspace"])] = 1
     assert g.dtype == np.float32 and np.array_equal(g, im["recept"])
     assert (im["recept"][pm["cspace"] == 0] == 1).all() and not np.array_equal(pm["recept"], im["recept"])
+
+
+def test_chokepoint_layout_has_a_diagonal_only_corridor_and_skips_buckets():
+    """The regression layout of tests/chokepoint_layout.py really is what its docstring says (oracle maps + oracle spfa): the pocket and the room are
+    8-connected but not 4-connected, and the search from the robot leaves distance buckets empty between non-empty ones."""
+    from collections import deque
+    from benchpush_amd import box_delivery_scenario as S
+    from benchpush_amd.config import default_cfg
+    from oracle.oracle_bd import OracleBoxDelivery, spfa
+    from chokepoint_layout import make_chokepoint_trial
+    cfg = default_cfg("box_delivery")
+    cfg.boxes.num_boxes_small = 3
+    tr = make_chokepoint_trial(cfg)
+    bp = S.box_delivery_params(cfg)
+    bp["num_boxes"] = len(tr["boxes"])
+    o = OracleBoxDelivery(S.box_delivery_physics_params(cfg), bp, cfg)
+    o.reset(tr, observe=False)
+    m = o.maps()
+    cs = m["cspace"] > 0.5
+    H, W = cs.shape
+
+    def reach(conn8, src):
+        seen = np.zeros_like(cs)
+        seen[src] = True
+        dq = deque([src])
+        while dq:
+            i, j = dq.popleft()
+            for di in (-1, 0, 1):
+                for dj in (-1, 0, 1):
+                    if (di or dj) and (conn8 or di == 0 or dj == 0):
+                        a, b = i + di, j + dj
+                        if 0 <= a < H and 0 <= b < W and cs[a, b] and not seen[a, b]:
+                            seen[a, b] = True
+                            dq.append((a, b))
+        return seen
+
+    ppm = 224 / 10.0
+    pi, pj = int(np.floor(-tr["start"][1] * ppm + H / 2)), int(np.floor(tr["start"][0] * ppm + W / 2))
+    src = (int(m["edt_i"][pi, pj]), int(m["edt_j"][pi, pj]))
+    assert cs[src]
+    r8, r4 = reach(True, src), reach(False, src)
+    assert r8.sum() == cs.sum() and r4.sum() < 0.2 * cs.sum()          # everything is reachable, but only over diagonal steps
+    dist, _, _ = spfa(m["cspace"], src)
+    d = dist[r8]
+    cnt = np.bincount(np.floor(d).astype(int))
+    empties = [k for k in range(len(cnt) - 1) if cnt[k] == 0]
+    assert len(empties) >= 8 and all(cnt[k + 1] > 0 for k in empties)    # single empty buckets between non-empty ones

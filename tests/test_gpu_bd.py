@@ -282,6 +282,35 @@ def test_config_c4_size_12_boxes_matches_oracle():
     env.close()
 
 
+def test_diagonal_chokepoint_layout_matches_oracle():
+    """ADVICE r2 item 1 / VERDICT r3 item 6b: the layout of tests/chokepoint_layout.py (a one-cell-wide diagonal corridor between the robot's pocket
+    and the room; the CPU suite checks that the search from the robot skips distance buckets there) through k_bd_robot_map (channel 2), k_bd_finish
+    (box distances: rewards / info) and the planner, against the oracle: observations at reset and over four steps, bodies, info, rewards."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    from chokepoint_layout import make_chokepoint_trial
+    cfg = default_cfg("box_delivery")
+    cfg.boxes.num_boxes_small = 3
+    tr = make_chokepoint_trial(cfg)
+    E = 2
+    env = BatchedBoxDeliveryEnv(E, cfg={"boxes": {"num_boxes_small": 3}}, trials=[tr])
+    oracles = [_oracle(cfg, tr) for _ in range(E)]
+    m, om = env.maps(0), oracles[0].maps()
+    d = m["dims"]
+    si, sj, SH, SW = int(d[4]), int(d[5]), int(d[2]), int(d[3])
+    win = (slice(si, si + SH), slice(sj, sj + SW))
+    assert np.array_equal(m["cspace"], om["cspace"][win]) and om["cspace"].sum() == om["cspace"][win].sum()
+    obs, info = env.reset()
+    torch.cuda.synchronize()
+    ref = np.stack([o.observe() for o in oracles])
+    assert np.array_equal(obs.cpu().numpy(), ref)
+    assert ref[0, :, :, 2].max() > 0                                   # the robot's distance map reaches through the corridor
+    acts = np.array([[0.5, -0.25], [0.0, 0.75], [-0.5, 0.25], [1.0, -1.0]])   # heading actions of the two envs
+    for t in range(4):
+        _compare_step(env, oracles, acts[t], "chokepoint step %d" % t)
+    env.check_errors()
+    env.close()
+
+
 def test_full_size_properties_4096_envs():
     """BASELINE.json configs[3] size (box-delivery-v0, 4096 envs, 12 boxes): oracle-free properties.  Envs that play the same trial with
     the same actions must produce the same bits (env e plays trial e % T), counters are monotone, everything stays finite and in range."""

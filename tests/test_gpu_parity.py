@@ -415,7 +415,15 @@ def test_scheduler_fault_is_finished_by_the_completion_launch(monkeypatch):
     """Scheduler fault path (bp_kernels.hpp: sched_body): with the test hook BP_SCHED_DEBUG_DROP=1 env 1 is parked after its first chunk and its queue
     item is dropped, so the scheduled launch cannot finish it; the pollers leave on the (short) watchdog and the completion launch that follows every
     scheduled launch resumes the env at its chunk boundary.  Results equal the unscheduled kernel's bit for bit, the fault is reported as a warning."""
+    from benchpush_amd import _lib
+    from benchpush_amd.build import DBG_LIB_PATH, build_debug_paths
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    # the fault-injection hook is compiled into the diagnostic twin of the library only (ADVICE r3): the product library ignores the variable,
+    # which the last run below checks
+    build_debug_paths()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("BP_PROF", "1")
+    monkeypatch.setenv("BP_PROF_LIB", DBG_LIB_PATH)
     trials = default_trials(0.3, 3, base_seed=5)
     E, steps = 9, 12
     g = torch.Generator(device="cuda:0")
@@ -449,6 +457,15 @@ def test_scheduler_fault_is_finished_by_the_completion_launch(monkeypatch):
     assert clean[4] == (0, 0)
     for a, b in zip(ref[:4], clean[:4]):
         assert torch.equal(a, b)
+    # the product library does not act on the test variable
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.delenv("BP_PROF")
+    monkeypatch.delenv("BP_PROF_LIB")
+    prod = run({"BP_SCHED_DEBUG_DROP": "1"})
+    assert prod[4] == (0, 0)
+    for a, b in zip(ref[:4], prod[:4]):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(_lib, "_lib", None)   # whatever was loaded last is dropped: the next test loads the product library afresh
 
 
 def test_gym_adapter_surface_and_metric_plumbing():
@@ -490,9 +507,10 @@ def test_cabi_call_order_errors():
     assert L.bp_step(h, C.c_void_p(a.data_ptr()), None, None, None, None, None, None) == -5   # BP_ESTATE
     assert L.bp_reset(h, None, None, None, None) == -5
     assert b"bp_load_scenarios" in L.bp_last_error(h)
-    bad = _lib.make_config(dict(ship_ice_physics_params(cfg), damping_pow=0.5), cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
-    h2 = C.c_void_p()
-    assert L.bp_create(C.byref(bad), 2, 0, 0, C.byref(h2)) == -1                              # BP_EINVAL
+    for dp in (1.5, -0.1, float("nan")):   # pow(space.damping, dt) of a damping in [0, 1]; anything else is refused (0.5 is served: test_parity_nonzero_damping)
+        bad = _lib.make_config(dict(ship_ice_physics_params(cfg), damping_pow=dp), cfg.ship.vertices, cfg.ship.head, cfg.ship.tail)
+        h2 = C.c_void_p()
+        assert L.bp_create(C.byref(bad), 2, 0, 0, C.byref(h2)) == -1                          # BP_EINVAL
     assert L.bp_destroy(h) == 0
 
 

@@ -15,6 +15,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch 
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $REPO/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_write.log
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM --output-format csv -d $OUT/pmc_sq -- python3 $REPO/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_sq.log
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_sq2 -- python3 $REPO/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_sq2.log
+rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_LDS_ATOMIC_RETURN --output-format csv -d $OUT/pmc_lds -- python3 $REPO/bench.py $PMCARGS > /dev/null 2> $OUT/pmc_lds.log
 cd $REPO
 python3 tools/summarize_prof.py $OUT $BUILD > $OUT/summary.txt 2>&1
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv 2>/dev/null

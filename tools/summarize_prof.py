@@ -75,7 +75,7 @@ for name, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
         print("%s %-40s n=%d mean=%.1f KB per launch" % (name, k[:40], len(v), sum(v) / len(v)))
         res.setdefault(k, {})[name] = sum(v) / len(v)
 sq = defaultdict(lambda: defaultdict(list))
-for sub in ("pmc_sq", "pmc_sq2"):
+for sub in ("pmc_sq", "pmc_sq2", "pmc_lds"):
     for r in rows(sub + "/**/*counter_collection.csv"):
         sq[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in sq.items():
@@ -104,5 +104,22 @@ for k, d in sq.items():
             pmc["wave_time_split"] = {"issuing": per.get("SQ_ACTIVE_INST_ANY", 0) / per["SQ_WAVE_CYCLES"],
                                       "waitcnt": per.get("SQ_WAIT_ANY", 0) / per["SQ_WAVE_CYCLES"],
                                       "issue_stall": per.get("SQ_WAIT_INST_ANY", 0) / per["SQ_WAVE_CYCLES"]}
+per = pmc.get("per_launch", {})
+if per.get("SQ_LDS_IDX_ACTIVE"):
+    # SURVEY 8d's LDS line (MI355X_MICROARCH.md, LDS): SQ_LDS_BANK_CONFLICT = extra LDS-array cycles spent on conflicts, SQ_LDS_IDX_ACTIVE = all LDS-array
+    # cycles; SQ_WAIT_INST_LDS = wave quad-cycles stalled at LDS *issue* (a sub-bucket of WAIT_INST_ANY, not the lgkmcnt drain); the LDS array's
+    # own occupancy = its active cycles / (256 CUs x kernel cycles), from the kernel time of the stats pass
+    pmc["lds"] = {"bank_conflict_frac": per.get("SQ_LDS_BANK_CONFLICT", 0.0) / per["SQ_LDS_IDX_ACTIVE"],
+                  "addr_conflict_cycles": per.get("SQ_LDS_ADDR_CONFLICT"),
+                  "array_cycles_per_env_substep": per["SQ_LDS_IDX_ACTIVE"] / (4096 * 400.0),
+                  "cycles_per_lds_instruction": per["SQ_LDS_IDX_ACTIVE"] / max(per.get("SQ_INSTS_LDS", 1.0), 1.0),
+                  "issue_stall_share_of_wave_time": (per.get("SQ_WAIT_INST_LDS", 0.0) / per["SQ_WAVE_CYCLES"]) if per.get("SQ_WAVE_CYCLES") else None,
+                  "lds_issue_share_of_wave_time": (per.get("SQ_ACTIVE_INST_LDS", 0.0) / per["SQ_WAVE_CYCLES"]) if per.get("SQ_WAVE_CYCLES") else None}
+    try:
+        kms = [d for k, d in dur.items() if k.startswith("k_physics_step")][0]
+        kcyc = (sum(kms) / len(kms)) * 1e-9 * 2.4e9
+        pmc["lds"]["array_busy_frac"] = per["SQ_LDS_IDX_ACTIVE"] / (256.0 * kcyc)
+    except Exception:
+        pass
 json.dump(pmc, open(os.path.join(out, "pmc.json"), "w"), indent=1)
 print(json.dumps(pmc))
