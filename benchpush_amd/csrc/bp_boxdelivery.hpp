@@ -552,7 +552,9 @@ __device__ __forceinline__ d2 bd_local_to_world(const EnvCtx &E, int i, int q)
 #ifndef BP_BD_WAVES
 #define BP_BD_WAVES 2
 #endif
-__global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
+// DAMP: space.damping != 0 (box_delivery_env.py:204, area_clearing.py: `space.damping = cfg.sim.damping`; no shipped config) -> substep<BP_ENV_BOX, true>
+template <bool DAMP>
+__device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtrs &D, const BdParams &B, const BdPtrs &Q)
 {
     const int env = (D.order != nullptr) ? D.order[blockIdx.x] : (int)blockIdx.x;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -762,7 +764,7 @@ __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams 
             prevp = cur; have_prev = true;
         }
         // ---------------- the sim step ----------------
-        substep<BP_ENV_BOX>(P, E, L, A, S, P.dt_sub, false);
+        substep<BP_ENV_BOX, DAMP>(P, E, L, A, S, P.dt_sub, false);
         if (BP_UNLIKELY2(BP_TRACE_ON(D) && env == D.dbg_env && total_sub < 10100u)) { // bp_debug_trace: (x, y, angle) of every body after each sim step
             for (int i = lane; i < E.nb; i += 64) {
                 double *o = D.dbg + ((size_t)total_sub * P.nbcap + i) * 3;
@@ -820,6 +822,14 @@ __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams 
         double *o = Q.stepf + (size_t)env * 8;
         o[0] = robot_distance; o[4] = (double)S.robot_hit; o[5] = (double)total_sub;
     }
+}
+__global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
+{
+    bd_physics_body<false>(P, D, B, Q);
+}
+__global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics_damp(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
+{
+    bd_physics_body<true>(P, D, B, Q);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -579,7 +579,8 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 h->steps_done = true;
                 hipLaunchKernelGGL(k_bd_plan, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, actions);
                 HIPCHK(h, hipGetLastError());
-                hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
+                if (h->damp) hipLaunchKernelGGL(k_bd_physics_damp, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
+                else hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
                 HIPCHK(h, hipGetLastError());
                 // the robot's spfa map needs only the robot pose: it runs beside the finish kernel on a second stream
                 if (!h->st_aux) {
@@ -914,7 +915,7 @@ int bp_bd_create(const bp_bd_config *cfg, int32_t num_envs, int64_t env_id_offse
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BP_ENODEVICE;
-    if (cfg->damping_pow != 0.0 || cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
+    if (!(cfg->damping_pow >= 0.0) || cfg->damping_pow > 1.0 || cfg->steps <= 0 || cfg->iterations <= 0 || cfg->persistence <= 0) return BP_EINVAL;
     if (cfg->num_boxes <= 0 || cfg->num_boxes > BD_MAXBOX || cfg->local_px <= 0 || (cfg->local_px & 1)) return BP_EINVAL;
     bp_handle *h = new bp_handle();
     memset(&h->cfg, 0, sizeof(h->cfg));
@@ -1130,6 +1131,9 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if (h->bd_lds > 160 * 1024 || h->bd_obs_lds > 160 * 1024) return fail(h, BP_EINVAL, "map window too large for LDS");
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_settle, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics_damp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_settle_damp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    h->damp = h->P.damping_pow != 0.0;   // space.damping != 0: the generic instantiations (substep<BP_ENV_BOX, DAMP = true>)
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_plan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_ac_finish, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_lds));
@@ -1140,7 +1144,8 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
         HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_robot_map, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bd_rmap_lds));
     }
     // settle every trial once into its template slot, then the episode-start bookkeeping (box distances, robot map)
-    hipLaunchKernelGGL(k_bd_settle, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
+    if (h->damp) hipLaunchKernelGGL(k_bd_settle_damp, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
+    else hipLaunchKernelGGL(k_bd_settle, dim3(T), dim3(64), h->lds_bytes, 0, h->P, h->D, (const unsigned char *)nullptr, (double *)nullptr, 1);
     HIPCHK(h, hipGetLastError());
     if (cf.task == 1)
         hipLaunchKernelGGL(k_ac_finish, dim3(T), dim3(64), h->bd_lds, 0, h->P, h->D, h->B, h->Q, 1, 1, (double *)nullptr, (unsigned char *)nullptr,

@@ -790,6 +790,11 @@ __global__ __launch_bounds__(64, 2) void k_bd_settle(const DevParams P, const De
 {
     physics_body<MODE_RESET, BP_ENV_BOX>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
 }
+__global__ __launch_bounds__(64, 2) void k_bd_settle_damp(const DevParams P, const DevPtrs D, const unsigned char *__restrict__ mask,
+                                                       double *__restrict__ info, const int tmpl)
+{
+    physics_body<MODE_RESET, BP_ENV_BOX, false, true>(P, D, nullptr, mask, nullptr, nullptr, nullptr, tmpl ? nullptr : info, tmpl);
+}
 
 // Dispatch order for the next step: envs sorted by the cycles their last step took, heaviest first (bucket sort).
 // Workgroups start in index order, so the long-running environments start first and the launch tail shrinks.

@@ -1311,6 +1311,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     body = L.sbody[sl];
                     const d2 v = L.sv[sl], w2 = L.sw[sl], vb = L.sb[sl];
                     want = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
+                    if (KIND == BP_ENV_BOX && ((S.evmask >> body) & 1ull)) want = true;   // moved by a pre_solve push-out: re-cached next sub-step
                 }
                 const unsigned long long m = ballot(want);
                 if (want) {

@@ -66,7 +66,8 @@ typedef struct bp_config {
                               * 0 (every shipped config) runs the specialised kernels; any other value selects a generic instantiation of the same
                               * sub-step (k_physics_step_damp: velocities scaled instead of cleared, moving list rebuilt from the velocity slots,
                               * no step scheduler) -- slower, and bodies once pushed keep moving, so the in-kernel capacities (BP_ECAPACITY) are
-                              * reached sooner.  box-delivery / area-clearing handles (bp_bd_create) accept 0 only and return BP_EINVAL otherwise. */
+                              * reached sooner.  The same holds for box-delivery / area-clearing handles (bp_bd_config.damping_pow, box_delivery_env.py:204: k_bd_settle_damp /
+                              * k_bd_physics_damp). */
     double bias_coef;        /* 1 - pow(collision_bias, dt/steps) */
     double slop;
     double target_speed;

@@ -55,6 +55,40 @@ def test_area_clearing_matches_oracle(layout, atype):
     env.close()
 
 
+def test_area_clearing_nonzero_damping_matches_oracle():
+    """cfg.sim.damping = 0.8 on area-clearing-v0 (the same DAMP instantiation as box-delivery): 3 envs x 4 heading steps against the oracle."""
+    from benchpush_amd.envs.area_clearing import BatchedAreaClearingEnv
+    from oracle.oracle_bd import AC_INFO_KEYS, OracleAreaClearing
+    cfg = default_cfg("area_clearing")
+    cfg.sim.damping = 0.8
+    E = 3
+    trials = A.generate_trials(cfg, E)
+    env = BatchedAreaClearingEnv(E, cfg={"sim": {"damping": 0.8}}, trials=trials)
+    oracles = []
+    for e in range(E):
+        o = OracleAreaClearing(A.area_clearing_physics_params(cfg), A.area_clearing_params(cfg), cfg)
+        o.reset(trials[e], observe=False)
+        oracles.append(o)
+    obs, _ = env.reset()
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
+    rng = np.random.RandomState(5)
+    for t in range(4):
+        a = rng.uniform(-1, 1, E)
+        obs, rew, term, trunc, info = env.step(torch.tensor(a))
+        torch.cuda.synchronize()
+        res = [o.step(a[e]) for e, o in enumerate(oracles)]
+        assert np.array_equal(info.cpu().numpy(), np.array([[r[4][k] for k in AC_INFO_KEYS] for r in res])), t
+        assert np.array_equal(rew.cpu().numpy(), np.array([r[1] for r in res])), t
+        assert np.array_equal(obs.cpu().numpy(), np.stack([r[0] for r in res])), t
+        st = env.body_state().cpu().numpy()
+        for e, o in enumerate(oracles):
+            n = 6 + env.nbox
+            assert np.array_equal(st[e, :n], o.shape_states()[:n]), (t, e)
+    env.check_errors()
+    env.close()
+
+
 def test_deep_episodes_through_clearing_and_time_truncation():
     """30 env steps of 4 envs against the oracle with auto-reset (every step: bodies, info, reward, flags, observation; every reset: first
     observation): a hand-placed box next to the clearance boundary is pushed out (cleared reward, box_count; area_clearing.py:611-780) and the

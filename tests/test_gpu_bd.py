@@ -311,6 +311,27 @@ def test_diagonal_chokepoint_layout_matches_oracle():
     env.close()
 
 
+def test_nonzero_damping_matches_oracle():
+    """`space.damping = cfg.sim.damping` (box_delivery_env.py:204) other than the shipped 0: the handle runs substep<BP_ENV_BOX, DAMP = true> (k_bd_settle_damp /
+    k_bd_physics_damp: pushed boxes coast, the moving list comes from the velocity slots); 3 envs x 5 steps against the oracle with the same damping."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    cfg = default_cfg("box_delivery")
+    cfg.sim.damping = 0.8
+    E = 3
+    trials = S.generate_trials(cfg, E)
+    env = BatchedBoxDeliveryEnv(E, cfg={"sim": {"damping": 0.8}}, trials=trials)
+
+    oracles = [_oracle(cfg, trials[e]) for e in range(E)]
+    obs, info = env.reset()
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
+    rng = np.random.RandomState(31)
+    for t in range(5):
+        _compare_step(env, oracles, rng.uniform(-1, 1, E), "damping 0.8, step %d" % t)
+    env.check_errors()
+    env.close()
+
+
 def test_full_size_properties_4096_envs():
     """BASELINE.json configs[3] size (box-delivery-v0, 4096 envs, 12 boxes): oracle-free properties.  Envs that play the same trial with
     the same actions must produce the same bits (env e plays trial e % T), counters are monotone, everything stays finite and in range."""
