@@ -3,7 +3,8 @@ AreaClearingEnv.init_area_clearing_env / generate_obstacles / generate_walls / g
 (benchpush/environments/area_clearing/area_clearing.py:225-264,361-561).  The reference draws from the unseeded module-level
 ``random``; here trial t uses ``random.Random(base_seed + t)`` with the same draw order (start x, then box centres).
 shapely pieces are restated for the shipped layouts: ``create_polygon_from_line`` = the flat-capped 0.2 m wide rectangle around
-the segment, boundary goal lines = the boundary edges (none of the shipped walls cuts an edge), ``interpolate`` = linear.
+the segment, boundary goal lines = the boundary edges minus the walls' 0.1 m buffers (``cut_edge_by_wall``: exact where a wall crosses an
+edge; none of the shipped walls does), ``interpolate`` = linear.
 """
 import math
 import random as _random
@@ -35,23 +36,85 @@ def line_rectangle(line, width=0.2):
     return [[x0 + nx, y0 + ny], [x1 + nx, y1 + ny], [x1 - nx, y1 - ny], [x0 - nx, y0 - ny]]
 
 
-def goal_points(cfg, interpolated_points=10):
+def _dist_to_segment(px, py, a, b):
+    ax, ay = a
+    bx, by = b
+    dx, dy = bx - ax, by - ay
+    L2 = dx * dx + dy * dy
+    t = 0.0 if L2 == 0.0 else max(0.0, min(1.0, ((px - ax) * dx + (py - ay) * dy) / L2))
+    return math.hypot(px - (ax + t * dx), py - (ay + t * dy))
+
+
+def cut_edge_by_wall(p0, p1, wall, r=0.1):
+    """``LineString([p0, p1]).difference(LineString(wall).buffer(r))`` (area_clearing.py:236-240) for one boundary edge and one wall: the parts of the
+    edge outside the wall's 0.1 m buffer, in the direction of the edge.  The buffer of a segment is convex (a stadium), so it covers one interval of
+    the edge.  Where the interval ends on a *straight side* of the buffer (a wall that crosses the edge) the end point is the exact intersection with
+    the offset line; where it ends on a round cap, shapely's answer depends on its 16-segments-per-quadrant polygon of the cap, which is not restated
+    here: such a layout is refused (NotImplementedError) instead of being answered approximately."""
+    (ax, ay), (bx, by) = wall
+    wx, wy = bx - ax, by - ay
+    wl = math.hypot(wx, wy)
+    ex, ey = p1[0] - p0[0], p1[1] - p0[1]
+    inside0 = _dist_to_segment(p0[0], p0[1], wall[0], wall[1]) <= r
+    inside1 = _dist_to_segment(p1[0], p1[1], wall[0], wall[1]) <= r
+    ts = []       # parameters of the edge where it crosses the buffer's outline, with the kind of outline
+    nx, ny = -wy / wl, wx / wl
+    for sgn in (1.0, -1.0):   # the two straight sides: points a + s * w + sgn * r * n, 0 <= s <= 1
+        ox, oy = ax + sgn * r * nx, ay + sgn * r * ny
+        den = ex * wy - ey * wx
+        if den == 0.0:
+            continue
+        t = ((ox - p0[0]) * wy - (oy - p0[1]) * wx) / den
+        sp = ((p0[0] + t * ex - ox) * wx + (p0[1] + t * ey - oy) * wy) / (wl * wl)
+        if 0.0 <= t <= 1.0 and 0.0 <= sp <= 1.0:
+            # the crossing point from both parametrisations; a coordinate along which one of the two lines does not move is exact there (axis-aligned
+            # edges and walls, the usual case, come out as GEOS computes them: (edge x, wall y +- 0.1))
+            qx = p0[0] if ex == 0.0 else (ox if wx == 0.0 else p0[0] + t * ex)
+            qy = p0[1] if ey == 0.0 else (oy if wy == 0.0 else p0[1] + t * ey)
+            ts.append((t, "side", (qx, qy)))
+    for cx, cy, outward in ((ax, ay, -1.0), (bx, by, 1.0)):   # the two caps: the half circles beyond the wall's ends
+        fx, fy = p0[0] - cx, p0[1] - cy
+        qa, qb, qc = ex * ex + ey * ey, 2 * (fx * ex + fy * ey), fx * fx + fy * fy - r * r
+        disc = qb * qb - 4 * qa * qc
+        if disc <= 0.0:
+            continue
+        for t in ((-qb - math.sqrt(disc)) / (2 * qa), (-qb + math.sqrt(disc)) / (2 * qa)):
+            hx, hy = p0[0] + t * ex - cx, p0[1] + t * ey - cy
+            if 0.0 <= t <= 1.0 and (hx * wx + hy * wy) * outward > 0.0:
+                ts.append((t, "cap", None))
+    if not ts and not inside0:
+        return [(list(p0), list(p1))]                      # the wall's buffer does not reach this edge
+    if any(k == "cap" for _, k, _ in ts) or (inside0 and inside1 and not ts):
+        raise NotImplementedError("a wall whose rounded end (buffer cap) reaches the clearance boundary needs shapely's polygon of the cap")
+    first = None if inside0 else min(ts, key=lambda c: c[0])
+    last = None if inside1 else max(ts, key=lambda c: c[0])
+    out = []
+    if first is not None and first[0] > 0.0:
+        out.append((list(p0), list(first[2])))
+    if last is not None and last[0] < 1.0:
+        out.append((list(last[2]), list(p1)))
+    return out
+
+
+def boundary_goal_lines(cfg):
+    """_compute_boundary_goals (area_clearing.py:225-255): the boundary edges minus every wall's 0.1 m buffer, pieces longer than 0.1 m, in edge order."""
     lay = env_layout(cfg)
     b = lay.boundary
-    walls = lay.walls if "walls" in lay else []
-    for w in walls:   # the restatement covers layouts whose walls (buffered by 0.1) stay clear of the boundary edges
-        rect = line_rectangle(w, 0.2)
-        x0, x1, y0, y1 = _extent(rect)
-        bx0, bx1, by0, by1 = _extent(b)
-        touches = (x0 <= bx1 and x1 >= bx0 and y0 <= by1 and y1 >= by0) and not (x0 > bx0 and x1 < bx1 and y0 > by0 and y1 < by1)
-        if touches:
-            raise NotImplementedError("walls that cut the clearance boundary need shapely's difference()")
+    lines = [([float(b[i][0]), float(b[i][1])], [float(b[(i + 1) % len(b)][0]), float(b[(i + 1) % len(b)][1])]) for i in range(len(b))]
+    for w in (lay.walls if "walls" in lay else []):
+        wall = ((float(w[0][0]), float(w[0][1])), (float(w[1][0]), float(w[1][1])))
+        nxt = []
+        for q0, q1 in lines:      # the reference cuts edge i by every wall in turn; a piece of an edge stays in the edge's place
+            nxt.extend(cut_edge_by_wall(q0, q1, wall))
+        lines = nxt
+    return [(q0, q1) for q0, q1 in lines if math.hypot(q1[0] - q0[0], q1[1] - q0[1]) > 0.1]
+
+
+def goal_points(cfg, interpolated_points=10):
+    """10 points per boundary goal line at ((k + 1/2) / 10) of its length (area_clearing.py:257-262)."""
     pts = []
-    for i in range(len(b)):
-        p0, p1 = b[i], b[(i + 1) % len(b)]
+    for p0, p1 in boundary_goal_lines(cfg):
         length = math.hypot(p1[0] - p0[0], p1[1] - p0[1])
-        if not length > 0.1:
-            continue
         for k in range(int(interpolated_points)):
             d = ((k + 1 / 2) / interpolated_points) * length
             f = d / length

@@ -1,5 +1,6 @@
 """area-clearing-v0 oracle: layouts, shapely-predicate restatements against brute force, goal map rules, env-level known answers."""
 import numpy as np
+import pytest
 
 from benchpush_amd import area_clearing_scenario as A
 from benchpush_amd.config import default_cfg
@@ -89,3 +90,49 @@ def test_task_driven_metric_against_networkx():
     m.update({"total_work": 1.0, "box_completed_statuses": [True, False], "state": (3, 4, 0)}, 1.0, eps_complete=True)
     assert abs(m.efficiency_scores[0] - (np.hypot(6.5, 6.5) + 1.5) / 5.0) < 1e-12 and m.success_rates == [0.5]
     assert abs(m.effort_scores[0] - (5.0 + 1.5 * 1.0) / (5.0 + 1.0)) < 1e-12
+
+
+def _wall_cut_cfg():
+    """walled_env plus a wall that crosses the left edge of the clearance boundary (x = -5) at y = 0: area_clearing.py:236-240 then removes the
+    wall's 0.1 m buffer from that edge (`LineString.difference`) and the boundary has five goal lines instead of four."""
+    cfg = default_cfg("area_clearing")
+    cfg.env = "walled_env"
+    cfg.envs.walled_env.walls = list(cfg.envs.walled_env.walls) + [[[-7.0, 0.0], [-3.0, 0.0]]]
+    return cfg
+
+
+def test_walls_that_cut_the_clearance_boundary():
+    """_compute_boundary_goals with a wall across an edge: the edge is split at the wall's buffer, pieces keep the edge's
+    direction and place, 10 goal points per piece; an oblique wall cuts at the exact intersection with its offset lines; a wall whose rounded
+    end reaches an edge is refused (shapely's cap polygon is not restated); pieces of 0.1 m or less are dropped."""
+    cfg = _wall_cut_cfg()
+    lines = A.boundary_goal_lines(cfg)
+    assert lines[0] == ([-5.0, -5.0], [-5.0, -0.1]) and lines[1] == ([-5.0, 0.1], [-5.0, 5.0]) and len(lines) == 5
+    g = A.goal_points(cfg)
+    assert g.shape == (50, 2) and np.allclose(g[0], [-5.0, -5.0 + 0.05 * 4.9]) and np.allclose(g[10], [-5.0, 0.1 + 0.05 * 4.9]) and np.allclose(g[20], [-4.5, 5.0])
+    # oblique wall through the top edge y = 5: the buffer's straight sides are the lines through (x, 5) at distance 0.1 from the wall's axis
+    a, b = (0.0, 3.0), (2.0, 7.0)
+    (l0, l1), (r0, r1) = A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], (a, b))
+    for q in (l1, r0):
+        assert q[1] == 5.0 and abs(A._dist_to_segment(q[0], q[1], a, b) - 0.1) < 1e-12
+    assert l0 == [-5.0, 5.0] and r1 == [5.0, 5.0] and l1[0] < 1.0 < r0[0]
+    # wall that does not reach the edge: untouched; wall along the edge: the covered part disappears (one end inside the buffer)
+    assert A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], ((0.0, 0.0), (0.0, 4.0))) == [([-5.0, 5.0], [5.0, 5.0])]
+    with pytest.raises(NotImplementedError):
+        A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], ((0.0, 0.0), (0.0, 4.95)))      # the cap, not a straight side, reaches the edge
+    # two walls close together leave a piece of 0.05 m between their buffers: dropped (area_clearing.py:246-250)
+    cfg2 = default_cfg("area_clearing")
+    cfg2.env = "walled_env"
+    cfg2.envs.walled_env.walls = list(cfg2.envs.walled_env.walls) + [[[-7.0, 0.0], [-3.0, 0.0]], [[-7.0, 0.25], [-3.0, 0.25]]]
+    lines2 = A.boundary_goal_lines(cfg2)
+    assert lines2[0] == ([-5.0, -5.0], [-5.0, -0.1]) and lines2[1] == ([-5.0, 0.35], [-5.0, 5.0]) and len(lines2) == 5
+
+
+def test_wall_cut_layout_runs_through_the_oracle():
+    """The oracle accepts the 50 goal points of the wall-cut layout and its goal-distance map sees them (channel 3 of the observation)."""
+    cfg = _wall_cut_cfg()
+    o = _oracle(cfg, A.generate_trial(cfg, 1))
+    m = o.maps()
+    assert np.isfinite(m["recept"]).all() and m["recept"].max() > 0
+    obs, r, term, trunc, info = o.step(0.3)
+    assert obs.shape == (224, 224, 4) and np.isfinite(r)

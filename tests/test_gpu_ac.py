@@ -89,6 +89,45 @@ def test_area_clearing_nonzero_damping_matches_oracle():
     env.close()
 
 
+def test_layout_whose_wall_cuts_the_clearance_boundary_matches_oracle():
+    """VERDICT r3 item 9 (area_clearing.py:225-262,1122-1140): walled_env plus a wall across the left boundary edge -- five boundary goal lines, 50 goal
+    points; maps, first observation and five steps (goal-distance rewards, channel 3) against the oracle."""
+    from benchpush_amd.envs.area_clearing import BatchedAreaClearingEnv
+    from oracle.oracle_bd import AC_INFO_KEYS, OracleAreaClearing
+    walls = [[[-6.0, -6.0], [-6.0, 6.0]], [[6.0, 6.0], [6.0, -6.0]], [[-7.0, 0.0], [-3.0, 0.0]]]
+    cfg = default_cfg("area_clearing")
+    cfg.env = "walled_env"
+    cfg.envs.walled_env.walls = walls
+    assert A.goal_points(cfg).shape == (50, 2)
+    E = 3
+    trials = A.generate_trials(cfg, E)
+    env = BatchedAreaClearingEnv(E, cfg={"env": "walled_env", "envs": {"walled_env": cfg.envs.walled_env}}, trials=trials)   # one-level-deep merge: the layout entry is replaced
+    assert len(env.goal_points) == 50
+    oracles = []
+    for e in range(E):
+        o = OracleAreaClearing(A.area_clearing_physics_params(cfg), A.area_clearing_params(cfg), cfg)
+        o.reset(trials[e], observe=False)
+        oracles.append(o)
+    m, om = env.maps(0), oracles[0].maps()
+    d = m["dims"]
+    win = (slice(int(d[4]), int(d[4]) + int(d[2])), slice(int(d[5]), int(d[5]) + int(d[3])))
+    assert np.array_equal(m["cspace"], om["cspace"][win]) and np.array_equal(m["recept"], om["recept"][win])
+    obs, _ = env.reset()
+    torch.cuda.synchronize()
+    assert np.array_equal(obs.cpu().numpy(), np.stack([o.observe() for o in oracles]))
+    rng = np.random.RandomState(9)
+    for t in range(5):
+        a = rng.uniform(-1, 1, E)
+        obs, rew, term, trunc, info = env.step(torch.tensor(a))
+        torch.cuda.synchronize()
+        res = [o.step(a[e]) for e, o in enumerate(oracles)]
+        assert np.array_equal(info.cpu().numpy(), np.array([[r[4][k] for k in AC_INFO_KEYS] for r in res])), t
+        assert np.array_equal(rew.cpu().numpy(), np.array([r[1] for r in res])), t
+        assert np.array_equal(obs.cpu().numpy(), np.stack([r[0] for r in res])), t
+    env.check_errors()
+    env.close()
+
+
 def test_deep_episodes_through_clearing_and_time_truncation():
     """30 env steps of 4 envs against the oracle with auto-reset (every step: bodies, info, reward, flags, observation; every reset: first
     observation): a hand-placed box next to the clearance boundary is pushed out (cleared reward, box_count; area_clearing.py:611-780) and the
