@@ -322,7 +322,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
             E.pxy[i] = p; E.ang[i] = a2; E.rot[i] = r;
             if (i == 0) { L.ag[0] = mk2(a2, 0.0); L.ag[1] = r; }
-            if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(w2.x, 0.0); L.sp[sl] = p; }
+            if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl].y = 0.0; L.sp[sl] = p; }   // w itself is unchanged: only the bias half is cleared (8-byte store)
             double4 t;
             t.x = r.x; t.y = r.y;
             t.z = p.x - (ms.z * r.x - ms.w * r.y);
@@ -1101,7 +1101,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const int sl = L.slot_of[i];
             // bodies of the moving list are parts of the kinematic agent (indices below nkin) or dynamic; a static shape in the list (first sub-step
             // of a new space) has zero velocity already
-            if (sl != 255 && i >= P.nkin) { L.sv[sl] = mk2(0.0, 0.0); L.sw[sl] = mk2(0.0, L.sw[sl].y); }
+            if (sl != 255 && i >= P.nkin) { L.sv[sl] = mk2(0.0, 0.0); L.sw[sl].x = 0.0; }
         }
     }
     lds_sync();
@@ -1115,17 +1115,17 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const int lvl = __ffs((int)lm) - 1;
         if (warm && A.level == lvl && A.state != ARB_FIRST) {
             d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
-            d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
+            double wa = L.sw[A.slotA].x, wb = L.sw[A.slotB].x;   // the bias halves are not touched by the warm start: 8-byte accesses
             {
                 const d2 j = vmul(vrotate(A.n, mk2(A.jn0, A.jt0)), dt_coef);
-                apply_contact_impulses(A, 0, va, wa2.x, vb, wb2.x, j);
+                apply_contact_impulses(A, 0, va, wa, vb, wb, j);
             }
             if (A.count > 1) {
                 const d2 j = vmul(vrotate(A.n, mk2(A.jn1, A.jt1)), dt_coef);
-                apply_contact_impulses(A, 1, va, wa2.x, vb, wb2.x, j);
+                apply_contact_impulses(A, 1, va, wa, vb, wb, j);
             }
-            if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; }
-            if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; }
+            if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA].x = wa; }
+            if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB].x = wb; }
         }
         lds_sync();
     }
@@ -1152,9 +1152,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             PROF_CNT(44, ballot(warm && A.level == lvl && A.count > 1) ? 1 : 0)
             if (warm && A.level == lvl) {
                 d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
-                d2 wa2 = L.sw[A.slotA], wb2 = L.sw[A.slotB];
+                d2 wa2 = mk2(0.0, 0.0), wb2 = mk2(0.0, 0.0);
                 d2 vba = mk2(0.0, 0.0), vbb = mk2(0.0, 0.0);
-                if (AB) { vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
+                if (AB) { wa2 = L.sw[A.slotA]; wb2 = L.sw[A.slotB]; vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
+                else { wa2.x = L.sw[A.slotA].x; wb2.x = L.sw[A.slotB].x; }   // without bias terms only the angular velocity itself is read and written back: 8-byte LDS accesses
                 const d2 n = A.n;
 #pragma unroll
                 for (int c = 0; c < 2; c++) {
@@ -1202,11 +1203,11 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     }
                 }
                 if (SCRATCH_WB) {
-                    L.sv[wA] = va; L.sw[wA] = wa2; if (AB) L.sb[wA] = vba;
-                    L.sv[wB] = vb; L.sw[wB] = wb2; if (AB) L.sb[wB] = vbb;
+                    L.sv[wA] = va; if (AB) { L.sw[wA] = wa2; L.sb[wA] = vba; } else L.sw[wA].x = wa2.x;
+                    L.sv[wB] = vb; if (AB) { L.sw[wB] = wb2; L.sb[wB] = vbb; } else L.sw[wB].x = wb2.x;
                 } else {
-                    if (A.ma != 0.0) { L.sv[A.slotA] = va; L.sw[A.slotA] = wa2; if (AB) L.sb[A.slotA] = vba; }
-                    if (A.mb != 0.0) { L.sv[A.slotB] = vb; L.sw[A.slotB] = wb2; if (AB) L.sb[A.slotB] = vbb; }
+                    if (A.ma != 0.0) { L.sv[A.slotA] = va; if (AB) { L.sw[A.slotA] = wa2; L.sb[A.slotA] = vba; } else L.sw[A.slotA].x = wa2.x; }
+                    if (A.mb != 0.0) { L.sv[A.slotB] = vb; if (AB) { L.sw[A.slotB] = wb2; L.sb[A.slotB] = vbb; } else L.sw[A.slotB].x = wb2.x; }
                 }
             }
             lds_sync();
