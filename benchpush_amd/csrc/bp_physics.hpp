@@ -1139,76 +1139,113 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     const int wA = (!SCRATCH_WB || A.ma != 0.0) ? A.slotA : BP_NSLOT, wB = (!SCRATCH_WB || A.mb != 0.0) ? A.slotB : BP_NSLOT;
     auto iterate = [&](auto bias_tag) {
     constexpr bool AB = decltype(bias_tag)::value;
+    // the three parts of a colour pass for the lane's arbiter: velocities of its two bodies from their slots, cpArbiterApplyImpulse for its one or two contacts,
+    // velocities back to the slots (an infinite-mass body's to the scratch slot)
+    auto gather = [&](d2 &va, d2 &vb, d2 &wa2, d2 &wb2, d2 &vba, d2 &vbb) {
+        va = L.sv[A.slotA]; vb = L.sv[A.slotB];
+        wa2 = mk2(0.0, 0.0); wb2 = mk2(0.0, 0.0); vba = mk2(0.0, 0.0); vbb = mk2(0.0, 0.0);
+        if (AB) { wa2 = L.sw[A.slotA]; wb2 = L.sw[A.slotB]; vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
+        else { wa2.x = L.sw[A.slotA].x; wb2.x = L.sw[A.slotB].x; }   // without bias terms only the angular velocity itself is read and written back: 8-byte LDS accesses
+    };
+    auto scatter = [&](const d2 va, const d2 vb, const d2 wa2, const d2 wb2, const d2 vba, const d2 vbb) {
+        if (SCRATCH_WB) {
+            L.sv[wA] = va; if (AB) { L.sw[wA] = wa2; L.sb[wA] = vba; } else L.sw[wA].x = wa2.x;
+            L.sv[wB] = vb; if (AB) { L.sw[wB] = wb2; L.sb[wB] = vbb; } else L.sw[wB].x = wb2.x;
+        } else {
+            if (A.ma != 0.0) { L.sv[A.slotA] = va; if (AB) { L.sw[A.slotA] = wa2; L.sb[A.slotA] = vba; } else L.sw[A.slotA].x = wa2.x; }
+            if (A.mb != 0.0) { L.sv[A.slotB] = vb; if (AB) { L.sw[A.slotB] = wb2; L.sb[A.slotB] = vbb; } else L.sw[A.slotB].x = wb2.x; }
+        }
+    };
+    // "did any accumulated impulse change in this iteration": the differences jnAcc - jnOld, jtAcc - jtOld (and of the bias impulse) exist anyway;
+    // a difference of finite doubles is zero exactly when they are equal, and a sum of magnitudes is zero exactly when every term is (no
+    // cancellation, no underflow: binary64 keeps subnormals; a NaN stays non-zero), so their absolute values are accumulated into one per-lane
+    // double -- two additions per contact instead of the four integer operations of the bit-pattern form, and no compare-and-merge of lane masks
+    auto contacts = [&](d2 &va, d2 &vb, d2 &wa2, d2 &wb2, d2 &vba, d2 &vbb, double &chg) {
+        const d2 n = A.n;
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            if (c == 0 || A.count > 1) { // an arbiter always has its first contact
+                const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
+                const double nMass = c ? nMass1 : nMass0, tMass = c ? tMass1 : tMass0;
+                const double bias = c ? bias1 : bias0, bounce = c ? bounce1 : bounce0;
+                const d2 v1 = vadd(va, vmul(vperp(r1), wa2.x));
+                const d2 v2 = vadd(vb, vmul(vperp(r2), wb2.x));
+                const d2 vr = vsub(v2, v1);
+                const double vrn = vdot(vr, n);
+                const double vrt = vdot(vr, vperp(n));
+                const double jbnOld = c ? jBias1 : jBias0;
+                double jBias = jbnOld;
+                if (AB) { // with no bias term anywhere every bias impulse stays exactly 0
+                    const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
+                    const d2 vb2 = vadd(vbb, vmul(vperp(r2), wb2.y));
+                    const double vbn = vdot(vsub(vb2, vb1), n);
+                    const double jbn = (bias - vbn) * nMass;
+                    jBias = fmax(jbnOld + jbn, 0.0);
+                }
+                const double jn = -(bounce + vrn) * nMass;
+                const double jnOld = c ? A.jn1 : A.jn0;
+                const double jnAcc = fmax(jnOld + jn, 0.0);
+                const double jtMax = A.u * jnAcc;
+                const double jt = -vrt * tMass;
+                const double jtOld = c ? A.jt1 : A.jt0;
+                const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
+                if (c) { jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
+                else   { jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
+                if (AB) {
+                    const double djb = jBias - jbnOld;
+                    chg += __builtin_fabs(djb);
+                    const d2 jb = vmul(n, djb);
+                    const d2 jbneg = vneg(jb);
+                    vba = vadd(vba, vmul(jbneg, A.ma));
+                    wa2.y += A.ia * vcross(r1, jbneg);
+                    vbb = vadd(vbb, vmul(jb, A.mb));
+                    wb2.y += A.ib * vcross(r2, jb);
+                }
+                const double djn = jnAcc - jnOld, djt = jtAcc - jtOld;
+                chg += __builtin_fabs(djn); chg += __builtin_fabs(djt);   // two adds with |.| as a source modifier; off the pass's dependency chain
+                const d2 j = vrotate(n, mk2(djn, djt));
+                apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
+            }
+        }
+    };
+    // ---- one warm colour: the warm arbiters share no dynamic body, so nobody else reads or writes the velocities a lane works on between its passes --
+    // they stay in registers for the ten iterations (one gather, one scatter; a third of a pass is its LDS round trip, profiles/r04_floor).  An
+    // infinite-mass body's velocity is re-read unchanged by every pass of the loop below, while here the (zero) impulse is added to the lane's copy:
+    // x + (+-0) == x bit for bit unless a component of x is a negative zero, so lanes check their infinite-mass sides once and the wave takes
+    // the slot loop if any such component exists (a kinematic body commanded with -0.0).
+    // (no-bias copy only, and not in the box-delivery instantiation: the extra live registers of the other copies push those kernels over the 256-VGPR line)
+    if (!AB && KIND != BP_ENV_BOX && (lvlmask & (lvlmask - 1u)) == 0u && lvlmask != 0u) {
+        d2 va = mk2(0.0, 0.0), vb = va, wa2 = va, wb2 = va, vba = va, vbb = va;
+        if (warm) gather(va, vb, wa2, wb2, vba, vbb);
+        auto negzero = [](double x) { return (((unsigned)__double2hiint(x) ^ 0x80000000u) | (unsigned)__double2loint(x)) == 0u; };
+        bool nz = false;
+        if (warm && A.ma == 0.0) nz = negzero(va.x) || negzero(va.y) || negzero(wa2.x) || (AB && (negzero(wa2.y) || negzero(vba.x) || negzero(vba.y)));
+        if (warm && A.mb == 0.0) nz = nz || negzero(vb.x) || negzero(vb.y) || negzero(wb2.x) || (AB && (negzero(wb2.y) || negzero(vbb.x) || negzero(vbb.y)));
+        if (!ballot(nz)) {
+            for (int it = 0; it < P.iterations; it++) {
+                PROF_CNT(42, 1)
+                PROF_CNT(43, 1)
+                double chg = 0.0;
+                if (warm) contacts(va, vb, wa2, wb2, vba, vbb, chg);
+                if (BP_UNLIKELY2(!ballot(warm && chg != 0.0))) break;
+            }
+            if (warm) scatter(va, vb, wa2, wb2, vba, vbb);
+            lds_sync();
+            return;
+        }
+    }
     for (int it = 0; it < P.iterations; it++) {
         PROF_CNT(42, 1)
-        // "did any accumulated impulse change in this iteration": the differences jnAcc - jnOld, jtAcc - jtOld (and of the bias impulse) exist anyway;
-        // a difference of finite doubles is zero exactly when they are equal, and a sum of magnitudes is zero exactly when every term is (no
-        // cancellation, no underflow: binary64 keeps subnormals; a NaN stays non-zero), so their absolute values are accumulated into one per-lane
-        // double -- two additions per contact instead of the four integer operations of the bit-pattern form, and no compare-and-merge of lane masks
         double chg = 0.0;
         for (unsigned lm = lvlmask; lm; lm &= lm - 1u) { // colours that hold a warm arbiter, ascending
             const int lvl = __ffs((int)lm) - 1;
             PROF_CNT(43, 1)
             PROF_CNT(44, ballot(warm && A.level == lvl && A.count > 1) ? 1 : 0)
             if (warm && A.level == lvl) {
-                d2 va = L.sv[A.slotA], vb = L.sv[A.slotB];
-                d2 wa2 = mk2(0.0, 0.0), wb2 = mk2(0.0, 0.0);
-                d2 vba = mk2(0.0, 0.0), vbb = mk2(0.0, 0.0);
-                if (AB) { wa2 = L.sw[A.slotA]; wb2 = L.sw[A.slotB]; vba = L.sb[A.slotA]; vbb = L.sb[A.slotB]; }
-                else { wa2.x = L.sw[A.slotA].x; wb2.x = L.sw[A.slotB].x; }   // without bias terms only the angular velocity itself is read and written back: 8-byte LDS accesses
-                const d2 n = A.n;
-#pragma unroll
-                for (int c = 0; c < 2; c++) {
-                    if (c == 0 || A.count > 1) { // an arbiter always has its first contact
-                        const d2 r1 = c ? A.r1_1 : A.r1_0, r2 = c ? A.r2_1 : A.r2_0;
-                        const double nMass = c ? nMass1 : nMass0, tMass = c ? tMass1 : tMass0;
-                        const double bias = c ? bias1 : bias0, bounce = c ? bounce1 : bounce0;
-                        const d2 v1 = vadd(va, vmul(vperp(r1), wa2.x));
-                        const d2 v2 = vadd(vb, vmul(vperp(r2), wb2.x));
-                        const d2 vr = vsub(v2, v1);
-                        const double vrn = vdot(vr, n);
-                        const double vrt = vdot(vr, vperp(n));
-                        const double jbnOld = c ? jBias1 : jBias0;
-                        double jBias = jbnOld;
-                        if (AB) { // with no bias term anywhere every bias impulse stays exactly 0
-                            const d2 vb1 = vadd(vba, vmul(vperp(r1), wa2.y));
-                            const d2 vb2 = vadd(vbb, vmul(vperp(r2), wb2.y));
-                            const double vbn = vdot(vsub(vb2, vb1), n);
-                            const double jbn = (bias - vbn) * nMass;
-                            jBias = fmax(jbnOld + jbn, 0.0);
-                        }
-                        const double jn = -(bounce + vrn) * nMass;
-                        const double jnOld = c ? A.jn1 : A.jn0;
-                        const double jnAcc = fmax(jnOld + jn, 0.0);
-                        const double jtMax = A.u * jnAcc;
-                        const double jt = -vrt * tMass;
-                        const double jtOld = c ? A.jt1 : A.jt0;
-                        const double jtAcc = fclampd(jtOld + jt, -jtMax, jtMax);
-                        if (c) { jBias1 = jBias; A.jn1 = jnAcc; A.jt1 = jtAcc; }
-                        else   { jBias0 = jBias; A.jn0 = jnAcc; A.jt0 = jtAcc; }
-                        if (AB) {
-                            const double djb = jBias - jbnOld;
-                            chg += __builtin_fabs(djb);
-                            const d2 jb = vmul(n, djb);
-                            const d2 jbneg = vneg(jb);
-                            vba = vadd(vba, vmul(jbneg, A.ma));
-                            wa2.y += A.ia * vcross(r1, jbneg);
-                            vbb = vadd(vbb, vmul(jb, A.mb));
-                            wb2.y += A.ib * vcross(r2, jb);
-                        }
-                        const double djn = jnAcc - jnOld, djt = jtAcc - jtOld;
-                        chg += __builtin_fabs(djn); chg += __builtin_fabs(djt);   // two adds with |.| as a source modifier; off the pass's dependency chain
-                        const d2 j = vrotate(n, mk2(djn, djt));
-                        apply_contact_impulses(A, c, va, wa2.x, vb, wb2.x, j);
-                    }
-                }
-                if (SCRATCH_WB) {
-                    L.sv[wA] = va; if (AB) { L.sw[wA] = wa2; L.sb[wA] = vba; } else L.sw[wA].x = wa2.x;
-                    L.sv[wB] = vb; if (AB) { L.sw[wB] = wb2; L.sb[wB] = vbb; } else L.sw[wB].x = wb2.x;
-                } else {
-                    if (A.ma != 0.0) { L.sv[A.slotA] = va; if (AB) { L.sw[A.slotA] = wa2; L.sb[A.slotA] = vba; } else L.sw[A.slotA].x = wa2.x; }
-                    if (A.mb != 0.0) { L.sv[A.slotB] = vb; if (AB) { L.sw[A.slotB] = wb2; L.sb[A.slotB] = vbb; } else L.sw[A.slotB].x = wb2.x; }
-                }
+                d2 va, vb, wa2, wb2, vba, vbb;
+                gather(va, vb, wa2, wb2, vba, vbb);
+                contacts(va, vb, wa2, wb2, vba, vbb, chg);
+                scatter(va, vb, wa2, wb2, vba, vbb);
             }
             lds_sync();
         }
