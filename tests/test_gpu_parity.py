@@ -202,6 +202,14 @@ def test_damping_is_a_real_knob_and_zero_matches_the_default():
     assert not np.array_equal(outs[0], outs[2])
 
 
+def test_parity_negative_zero_yaw_command():
+    """A ship commanded with -0.0 carries w = -0 (an infinite-mass body with a negative-zero velocity component): the register-resident solve of single-colour
+    sub-steps must not be taken then (x + (+0) != x for x = -0; substep(), step 6d) -- the slot loop runs instead and the results equal the oracle's, as they do
+    for +0.0 where the register path is taken."""
+    n = _run_parity(E=4, conc=0.3, T=2, steps=30, seed=3, action_fn=lambda e, t: -0.0 if (e % 2) else 0.0)
+    assert n > 100
+
+
 def test_parity_50pct_dense_field():
     assert _run_parity(E=4, conc=0.5, T=2, steps=12, seed=21) > 100
 
