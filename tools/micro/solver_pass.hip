@@ -5,6 +5,8 @@
 //   MODE 0 = as in the kernel: body velocities gathered from / scattered to LDS velocity slots around every pass (three round trips: sv, sw, write-back)
 //   MODE 1 = arithmetic only: the two bodies' velocities stay in registers (what a pass would cost if no body were shared between arbiters)
 //   MODE 2 = LDS trips only: gather + scatter, no arithmetic
+//   MODE 3 = side A in registers, side B through LDS (what a pass costs when one of its two bodies is unshared or of infinite mass)
+// Since round 4's product change the no-bias LDS forms move only `w` of the (w, w_bias) slot (8-byte accesses), like the kernel.
 // For every (mode, contacts, active lanes, colours) the program prints, at 1 / 2 / 3 / 4 wavefronts per SIMD (occupancy forced through the dynamic LDS size):
 //   wave cycles per pass (s_memtime around the loop, mean over waves) and SIMD cycles per pass (= wave cycles / waves per SIMD: the throughput view).
 #include <hip/hip_runtime.h>
@@ -65,7 +67,11 @@ __global__ __launch_bounds__(64) void k_pass(double *out, unsigned long long *cy
                 if (warm && A.level == lvl) {
                     d2 va, vb, wa2, wb2, vba = mk2(0.0, 0.0), vbb = mk2(0.0, 0.0);
                     if (MODE == 1) { va = rva; vb = rvb; wa2 = rwa; wb2 = rwb; vba = rba; vbb = rbb; }
-                    else { va = sv[A.slotA]; vb = sv[A.slotB]; wa2 = sw[A.slotA]; wb2 = sw[A.slotB]; if (AB) { vba = sb[A.slotA]; vbb = sb[A.slotB]; } }
+                    else {
+                        if (MODE == 3) { va = rva; wa2 = rwa; vba = rba; }
+                        else { va = sv[A.slotA]; if (AB) { wa2 = sw[A.slotA]; vba = sb[A.slotA]; } else { wa2 = mk2(0.0, 0.0); wa2.x = sw[A.slotA].x; } }
+                        vb = sv[A.slotB]; if (AB) { wb2 = sw[A.slotB]; vbb = sb[A.slotB]; } else { wb2 = mk2(0.0, 0.0); wb2.x = sw[A.slotB].x; }
+                    }
                     const d2 n = A.n;
                     if (MODE != 2) {
 #pragma unroll
@@ -116,8 +122,9 @@ __global__ __launch_bounds__(64) void k_pass(double *out, unsigned long long *cy
                     }
                     if (MODE == 1) { rva = va; rvb = vb; rwa = wa2; rwb = wb2; rba = vba; rbb = vbb; }
                     else {
-                        sv[wA] = va; sw[wA] = wa2; if (AB) sb[wA] = vba;
-                        sv[wB] = vb; sw[wB] = wb2; if (AB) sb[wB] = vbb;
+                        if (MODE == 3) { rva = va; rwa = wa2; rba = vba; }
+                        else { sv[wA] = va; if (AB) { sw[wA] = wa2; sb[wA] = vba; } else sw[wA].x = wa2.x; }
+                        sv[wB] = vb; if (AB) { sw[wB] = wb2; sb[wB] = vbb; } else sw[wB].x = wb2.x;
                     }
                 }
                 lds_sync();
@@ -191,6 +198,8 @@ int main()
         run_cfg<1, false>(out, cyc, 3, 2, two);
         run_cfg<0, true>(out, cyc, 3, 2, two);
         run_cfg<1, true>(out, cyc, 3, 2, two);
+        run_cfg<3, false>(out, cyc, 3, 2, two);
+        run_cfg<3, true>(out, cyc, 3, 2, two);
     }
     run_cfg<2, false>(out, cyc, 3, 2, 0);
     run_cfg<2, true>(out, cyc, 3, 2, 0);
