@@ -217,12 +217,15 @@ __device__ __forceinline__ void bp_sincos(double x, double &sn, double &cs)
     double r = x - fn * pio2_1;
     double w = fn * pio2_1t;
     double y0 = r - w;
-    if (__builtin_fabs(y0) < __builtin_fabs(x) * 7.62939453125e-06) {
-        double t = r;
-        w = fn * pio2_2;
-        r = t - w;
-        w = fn * pio2_2t - ((t - r) - w);
-        y0 = r - w;
+    // second reduction stage (arguments within 2^-17 of a multiple of pi/2: cancellation): rare, so the wave branches around it as a whole instead of
+    // computing it for every call and selecting (the per-lane result is the same either way)
+    const bool deep = __builtin_fabs(y0) < __builtin_fabs(x) * 7.62939453125e-06;
+    if (__builtin_expect(__ballot(deep) != 0ull, 0)) {
+        const double t = r;
+        const double w2 = fn * pio2_2;
+        const double r2 = t - w2;
+        const double w3 = fn * pio2_2t - ((t - r2) - w2);
+        if (deep) { r = r2; w = w3; y0 = r2 - w3; }
     }
     double y1 = (r - y0) - w;
     int q = (int)((long long)fn & 3);
@@ -232,10 +235,12 @@ __device__ __forceinline__ void bp_sincos(double x, double &sn, double &cs)
     double ks = y0 - ((z * (0.5 * y1 - v * rs) - y1) - v * S1);
     double rc = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
     double kc = 1.0 - (0.5 * z - (z * rc - y0 * y1));
-    if (q == 0) { sn = ks; cs = kc; }
-    else if (q == 1) { sn = kc; cs = -ks; }
-    else if (q == 2) { sn = -ks; cs = -kc; }
-    else { sn = -kc; cs = ks; }
+    // quadrant: q = 0 (ks, kc), 1 (kc, -ks), 2 (-ks, -kc), 3 (-kc, ks) -- two selects and two sign-bit flips (a negation is exactly a flip of the sign bit)
+    const bool odd = (q & 1) != 0;
+    const double s0 = odd ? kc : ks, c0 = odd ? ks : kc;
+    const int sflip = (q & 2) ? (int)0x80000000 : 0, cflip = ((q + 1) & 2) ? (int)0x80000000 : 0;
+    sn = __hiloint2double(__double2hiint(s0) ^ sflip, __double2loint(s0));
+    cs = __hiloint2double(__double2hiint(c0) ^ cflip, __double2loint(c0));
 }
 
 // counter RNG of the per-episode start pose (include/benchpush_amd.h: bp_start_uniform)

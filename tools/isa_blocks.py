@@ -10,11 +10,11 @@ import re
 import sys
 
 # phases of substep() as line ranges of csrc/bp_physics.hpp (update when the file moves; `grep -n "// ---- " csrc/bp_physics.hpp`)
-PH = [(278, 293, '0head'), (294, 367, '1integrate'), (368, 381, '2refresh'), (382, 465, '3candidates'), (466, 515, '4a_cached_planes'),
-      (516, 674, '4a_bound_rounds+search'), (675, 830, '4b_manifold'), (831, 938, '4c_deliver'), (939, 955, '5events+filter'),
-      (956, 993, '6a_prestep'), (994, 1019, '6a_warmset'), (1020, 1059, '6a_colour'), (1060, 1072, '6b_velint'), (1073, 1096, '6c_warmstart'),
-      (1097, 1183, '6d_solver'), (1184, 1226, '7post'), (1227, 1277, '7mvlist'), (248, 273, 'support_queries'), (209, 231, 'world_from_pose'),
-      (156, 206, 'refresh_body')]
+PH = [(284, 299, '0head'), (300, 373, '1integrate'), (374, 387, '2refresh'), (388, 472, '3candidates'), (473, 522, '4a_cached_planes'),
+      (523, 681, '4a_bound_rounds+search'), (682, 837, '4b_manifold'), (838, 959, '4c_deliver'), (960, 976, '5events+filter'),
+      (977, 1014, '6a_prestep'), (1015, 1042, '6a_warmset'), (1043, 1082, '6a_colour'), (1083, 1108, '6b_velint'), (1109, 1132, '6c_warmstart'),
+      (1133, 1282, '6d_solver'), (1283, 1325, '7post'), (1326, 1380, '7mvlist'), (254, 279, 'support_queries'), (215, 237, 'world_from_pose'),
+      (162, 212, 'refresh_body')]
 
 
 def phase_of(chain):
