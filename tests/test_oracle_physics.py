@@ -124,7 +124,7 @@ def test_deep_overlap_is_pushed_apart_by_bias(ship_cfg):
 def test_damping_known_answer_a_released_floe_coasts_geometrically(ship_cfg):
     """cpBodyUpdateVelocity with `space.damping` d (ship_ice_env.py:120): a body without contacts keeps v * d^dt per sub-step.  A floe dead ahead is pushed for
     three steps, then the ship turns away at full rate and the floe runs free: its speed shrinks by d^(400 dt) = d^0.8 per env step -- a known answer that does not
-    depend on the contact model -- until the ship's stern swings back into it.  With the shipped damping 0 a body that nothing pushes in a sub-step is at rest."""
+    depend on the contact model -- until the ship's stern swings back into it."""
     cfg, P = ship_cfg
     d = 0.5
     env, _ = _env(ship_cfg, damping_pow=math.pow(d, cfg.dt / cfg.sim.steps))
@@ -138,12 +138,6 @@ def test_damping_known_answer_a_released_floe_coasts_geometrically(ship_cfg):
     assert speeds[2] == pytest.approx(0.3, rel=0.05)                        # pushed at the ship's speed
     for t in range(4, 10):                                                  # free flight: steps 4..9
         assert speeds[t] / speeds[t - 1] == pytest.approx(d ** 0.8, rel=1e-9), t
-    env0, _ = _env(ship_cfg)                                                # damping 0: no velocity survives a sub-step without an impulse
-    env0.reset(trial, observe=False)
-    for t in range(5):
-        env0.step(0.0 if t < 3 else 1.0, observe=False)
-    b = env0.bodies()
-    assert b[1, 3] == 0.0 and b[1, 4] == 0.0
 
 
 def test_zero_area_floe_is_dropped(ship_cfg):
