@@ -580,10 +580,12 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
     const double *wp = Q.wp + (size_t)env * BD_MAXWP * 3;
     const int nwp = Q.nwp[env];
     const double *sf = Q.stepf + (size_t)env * 8;
-    const double ix = sf[1], iy = sf[2], ih = sf[3];
     // box-delivery clears robot_hit_obstacle at the start of a step (:640), area-clearing at its end (area_clearing.py:776)
     S.robot_hit = (B.task == 1) ? (int)sf[4] : 0;
-    double robot_distance = 0.0;
+    // Wave-uniform doubles of the path controller live in LDS (L.ctl), not in VGPRs: the kernel sits at the 256-VGPR line and spilled them to scratch around
+    // every sim step; they are touched a handful of times per sim step.  ctl[0] prev_heading_diff, [1] path length, [2] advanced length, [3] robot_distance.
+    if (lane < 4) L.ctl[lane] = 0.0;
+    lds_sync();
     unsigned total_sub = 0;
     // One loop with a single substep call site (the physics is one large inlined function); the phase selects what happens
     // before and after each sim step:
@@ -596,7 +598,6 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
     // path-execution state.  Wave-uniform doubles live in VGPRs, so only what cannot be re-read is kept across the sim step:
     // waypoints / set-point candidates are re-read from the waypoint list (scalar loads), the pose from the body arrays.
     int wi = 1, path0 = 0;
-    double prev_hd = 0.0, plen = 0, al = 0;
     bool done_turning = false, dp_valid = false, sp_one = false;
     int sim_steps = 0, kcount = 0;
     // until-still state
@@ -627,17 +628,19 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
 #endif
             const double prevx = L.sp[0].x, prevy = L.sp[0].y, prevh = bd_restrict(L.ag[0].x); // pose left by the last sim step
             const double hd = bd_hdiff(prevh, wp[3 * wi + 2]);
-            if (!(__builtin_fabs(hd) > 15 * (BP_PI / 180.0) && __builtin_fabs(hd - prev_hd) > 0.001)) done_turning = true;
-            prev_hd = hd; // prev_heading_diff of the next iteration (only read above)
+            if (!(__builtin_fabs(hd) > 15 * (BP_PI / 180.0) && __builtin_fabs(hd - L.ctl[0]) > 0.001)) done_turning = true;
+            lds_sync();
+            if (lane == 0) L.ctl[0] = hd; // prev_heading_diff of the next iteration (only read above)
             const double cx0 = wp[3 * path0], cy0 = wp[3 * path0 + 1], cx1 = wp[3 * path0 + 3], cy1 = wp[3 * path0 + 4];
             if (!dp_valid) { // DP(...) -> TargetCourse.init_setpoint (dp.py:67-88)
                 const double dx = cx1 - cx0, dy = cy1 - cy0;
-                plen = __builtin_sqrt(dx * dx + dy * dy);
+                const double plen0 = __builtin_sqrt(dx * dx + dy * dy);
                 const double d0 = bd_dist2(prevx, prevy, cx0, cy0), d1 = bd_dist2(prevx, prevy, cx1, cy1);
                 bool one = d1 < d0;
                 // look-ahead (dp.py:78-83): only ever advances from point 0 to point 1; never runs with Lfc == 0
                 if (!one && B.lfc > d0) one = true;
-                al = plen;
+                if (lane == 0) { L.ctl[1] = plen0; L.ctl[2] = plen0; }
+                lds_sync();
                 sp_one = one;
                 dp_valid = true;
             }
@@ -655,8 +658,10 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
             double omega = 1.0 * theta_e;
             omega = omega / B.ctrl_dt;
             const double gvx = cy_ * B.target_speed + -sy_ * 0.0, gvy = sy_ * B.target_speed + cy_ * 0.0;
-            al += B.target_speed * B.ctrl_dt;  // TargetCourse.advance
-            sp_one = plen < al;
+            const double al = L.ctl[2] + B.target_speed * B.ctrl_dt;  // TargetCourse.advance
+            sp_one = L.ctl[1] < al;
+            lds_sync();
+            if (lane == 0) L.ctl[2] = al;
             // apply_controller (box_delivery_env.py:887-889 / area_clearing.py:903-906)
             if (lane < P.nkin) {
                 L.sw[lane] = mk2(omega * B.omega_scale, L.sw[lane].y);
@@ -782,7 +787,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
             if (bd_dist2(pwx, pwy, px, py) > 0.05 && S.robot_hit) leave = true;
             else {
                 if (bd_dist2(px, py, wpx_, wpy_) < 0.6 && __builtin_fabs(ph - wph_) < 10 * (BP_PI / 180.0)) {
-                    robot_distance += bd_dist2(pwx, pwy, px, py);
+                    { const double rd = L.ctl[3] + bd_dist2(pwx, pwy, px, py); lds_sync(); if (lane == 0) L.ctl[3] = rd; lds_sync(); }
                     if (wi == nwp - 1) leave = true;
                     else { wi++; done_turning = false; dp_valid = false; path0++; }
                 }
@@ -792,7 +797,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
         } else if (phase == PH_VEL) {
             kcount++;
             if (S.robot_hit || kcount >= P.steps) {
-                robot_distance = bd_dist2(ix, iy, L.sp[0].x, L.sp[0].y);
+                { const double rd = bd_dist2(sf[1], sf[2], L.sp[0].x, L.sp[0].y); lds_sync(); if (lane == 0) L.ctl[3] = rd; lds_sync(); }
                 phase = after_move; sim_steps = 0; kcount = 0;
             }
         } else if (phase == PH_FIXED) {
@@ -820,7 +825,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
         D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
         if (err_any) atomicOr(&D.e_err[env], err_any);
         double *o = Q.stepf + (size_t)env * 8;
-        o[0] = robot_distance; o[4] = (double)S.robot_hit; o[5] = (double)total_sub;
+        o[0] = L.ctl[3]; o[4] = (double)S.robot_hit; o[5] = (double)total_sub;
     }
 }
 __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)

@@ -150,7 +150,7 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // host (launch size), so the two cannot drift apart.
 struct LdsMap {
     unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, cc, cc_hw, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, sbody, mv,
-        slot_of, rf, ev_d, ev_key, prof, total;
+        slot_of, rf, ev_d, ev_key, ctl, prof, total;
 };
 __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
 {
@@ -192,6 +192,7 @@ __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, c
     m.ev_d = p; if (box) p += 16u * 3 * BP_EVCAP;
     m.ev_key = p; if (box) p += 4u * BP_EVCAP;
     p = (p + 7u) & ~7u;
+    m.ctl = p; if (box) p += 8u * 4;           // box-delivery: wave-uniform doubles of the path controller, kept out of the VGPR file across the sim step
     m.prof = p; if (prof) p += 8u * BP_PROFN;
     m.total = (p + 15u) & ~15u;
     return m;

@@ -101,6 +101,7 @@ struct LdsCtx {
     // box-delivery only (substep<BP_ENV_BOX>): (1,3)/(2,3) pre_solve calls of the current sub-step
     unsigned *ev_key;          // [BP_EVCAP] shapeA << 16 | shapeB
     d2 *ev_d;                  // [BP_EVCAP][3] normal, r1, r2 of contact 0
+    double *ctl;               // [4] box-delivery path controller: prev_heading_diff, path length, advanced length, robot_distance (k_bd_physics)
 #ifdef BP_PROF
     unsigned long long *prof;  // [BP_PROFN] phase cycle counters and trip counts of this run (diagnostic build)
 #endif
