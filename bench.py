@@ -12,7 +12,9 @@ function of the trial when cfg.random_start is off -- tested identical to settli
 Inputs (scenarios, actions) are resident in HBM before the timed region.  `value` is measured from freshly reset episodes
 (steps W..W+K); `steady_state` repeats the measurement with the envs spread uniformly over the phases of an episode.
 Multi-GPU: environments shard over ranks (4096 per GPU, weak scaling, no data-path collective); the only collective is the
-all-gather of the [E/R, 6] episode-metric rows after the timed region (RCCL over xGMI).
+all-gather of the [E/R, 6] episode-metric rows after the timed region (RCCL over xGMI).  For N > 1 the line also carries
+`allgather_ms` (median of 20 timed gathers of the real block on device tensors) and `strong_scaling` (a second timed region with
+the same 4096 envs split over the N ranks: value, ms_per_step, speed-up and efficiency against this run's own one-GPU time).
 
     --config c2 (default)  BASELINE.json configs[1]: 4096 envs per GPU, 30 % concentration
     --config c5            BASELINE.json configs[4]: 4096 envs per GPU, 50 % concentration (32 768 envs on 8 GPUs)
@@ -160,6 +162,26 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+def time_allgather(rows, cnt, dist, sync, reps=20):
+    """Median wall time in ms (this rank's own clock; rank 0's is printed) of `gather_episode_block` on the given tensors -- the one collective of the path ("RCCL all-gather time").  `sync` drains the
+    device (torch.cuda.synchronize for nccl, a no-op for CPU tensors); a barrier before each repetition aligns the ranks."""
+    from benchpush_amd.parallel import gather_episode_block
+    ts = []
+    for _ in range(reps):
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        gather_episode_block(rows, cnt, dist)
+        sync()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts.sort()
+    return {"median_ms": ts[len(ts) // 2], "min_ms": ts[0], "max_ms": ts[-1], "reps": reps,
+            "payload_bytes_per_rank": int(rows.shape[0]) * (int(rows.shape[1]) + 1) * 8,
+            "what": "gather_episode_block: one all_gather_into_tensor of the [E/R, 7] float64 episode block (%s tensors, backend %s)"
+                    % (rows.device.type, dist.get_backend() if dist is not None else "none")}
+
+
 def plumbing_only(args, rank, world):
     """The N > 1 path without an environment: process group, barrier, the episode-block all-gather with the real [E/R, 6] shape.  Rank 0
     prints a line whose `n_gpus` is the number of ranks that joined the group (what the CPU test of `--gpus N` checks)."""
@@ -177,10 +199,17 @@ def plumbing_only(args, rank, world):
         dist.barrier()
         allr, allc = gather_episode_block(rows, cnt, dist)
         summarize_episode_block(allr, allc)
+        ag = time_allgather(rows, cnt, dist, lambda: None)
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "plumbing only: rank launch + rendezvous + episode-block all-gather", "value": None, "n_gpus": joined,
-                          "plumbing_only": True, "gathered_shape": None if allr is None else [int(allr.shape[0]), int(allr.shape[1])]}))
+        line = {"metric": "plumbing only: rank launch + rendezvous + episode-block all-gather", "value": None, "n_gpus": joined,
+                "plumbing_only": True, "gathered_shape": None if allr is None else [int(allr.shape[0]), int(allr.shape[1])]}
+        if world > 1:   # the keys the measured N > 1 line carries (no environment here: the strong-scaling block names its split only)
+            line["allgather_ms"] = ag["median_ms"]
+            line["allgather"] = ag
+            line["strong_scaling"] = {"total_envs": args.envs_per_gpu, "envs_per_gpu": args.envs_per_gpu // world, "value": None, "ms_per_step": None,
+                                      "speedup_vs_one_gpu": None, "efficiency": None, "note": "plumbing only: no environment was stepped"}
+        print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
     return 0
@@ -214,6 +243,7 @@ def main():
     ap.add_argument("--no-steady-state", action="store_true", help="skip the staggered-phase (steady-state) measurement")
     ap.add_argument("--steady-steps", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-strong", action="store_true", help="N > 1: skip the strong-scaling region (E envs split over the ranks)")
     ap.add_argument("--no-auto-reset", action="store_true")
     ap.add_argument("--env", default="ship-ice", choices=["ship-ice", "maze", "box", "area"],
                     help="ship-ice = BASELINE.json configs[1] (the headline); maze = configs[2], box = configs[3] (box-delivery-v0, "
@@ -346,6 +376,10 @@ def main():
         episode_summary["gathered_shape"] = [int(allr.shape[0]), int(allr.shape[1])]
     total_envs = E * world
     value = total_envs * K / tmax
+    allgather = None
+    if dist is not None and args.env == "ship-ice":
+        allgather = time_allgather(rows.to(coll_device), cnt.to(coll_device), dist,
+                                   torch.cuda.synchronize if coll_device.type == "cuda" else (lambda: None))
 
     # ---- steady state: spread the envs uniformly over the phases of an episode (forced resets of E/PH envs per step, untimed), then
     #      time KS more steps; episodes run ~36 steps under U(-1,1) actions, so freshly reset batches are lighter than the mix ----
@@ -380,6 +414,46 @@ def main():
                   "raster_ms": sr_ms, "phases": PH,
                   "how": "envs pre-advanced to uniformly spread episode steps (E/%d envs force-reset per step over %d untimed steps), "
                          "then %d timed steps with auto-reset" % (PH, PH, KS)}
+
+    # ---- strong scaling: the SAME total of E envs split over the ranks, E / world per GPU, on the same ranks;
+    #      T1 is this run's own weak region (every rank stepped E envs on one GPU), so speed-up = T1 / T_N and efficiency = speed-up / world ----
+    strong = None
+    if dist is not None and args.env == "ship-ice" and not args.no_strong and E % world == 0:
+        Es = E // world
+        env_s = BatchedShipIceEnv(Es, cfg={"concentration": args.concentration}, trials=trials, device=device, env_id_offset=rank * Es)
+        env_s.reset()
+        acts_s = actions[:, :Es].contiguous()
+
+        def strong_step(t):
+            _, _, term_s, _, _ = env_s.step(acts_s[t])
+            if not args.no_auto_reset:
+                env_s.reset(term_s)
+        for t in range(W):
+            strong_step(t)
+        torch.cuda.synchronize()
+        env_s.enable_timing(True)
+        dist.barrier()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for t in range(W, W + K):
+            strong_step(t)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        dtS = time.perf_counter() - t2
+        sp_ms2, _, _ = env_s.kernel_time_ms()
+        env_s.enable_timing(False)
+        _check_errors(env_s)
+        tm3 = torch.tensor([dtS], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(tm3, op=dist.ReduceOp.MAX)
+        dtS = float(tm3.item())
+        strong = {"total_envs": E, "envs_per_gpu": Es, "value": E * K / dtS, "unit": "env-steps/s", "steps": K, "ms_per_step": dtS / K * 1e3,
+                  "physics_ms": sp_ms2, "one_gpu_ms_per_step": tmax / K * 1e3, "speedup_vs_one_gpu": tmax / dtS, "efficiency": tmax / dtS / world,
+                  "how": "a second handle of E / world = %d envs per rank (global env ids rank * %d ..., same trials and action stream), same W + K steps, "
+                         "barrier + synchronize on both sides, max over ranks; T1 = this run's weak region (E envs on every GPU)" % (Es, Es),
+                  "expectation": "below ~3300 envs per GPU a launch lasts as long as its heaviest env's own chain (profiles/r04_final/launch_vs_envs.txt: "
+                                 "12.5 ms at 1024 envs, 13.3 at 2048, 16.0 at 4096), so fixed E = 4096 over N GPUs gains at most ~1.3 x"}
+        env_s.close()
 
     if rank == 0:
         sched_chunk = int(env.L.bp_sched_chunk(env.h)) if hasattr(env, "L") and hasattr(env.L, "bp_sched_chunk") else 0
@@ -464,6 +538,11 @@ def main():
             "substeps_per_s": value * env.params["steps"],
             "roofline": roof,
         }
+        if allgather is not None:
+            out["allgather_ms"] = allgather["median_ms"]
+            out["allgather"] = allgather
+        if dist is not None and args.env == "ship-ice":
+            out["strong_scaling"] = strong
         if steady is not None:
             out["steady_state"] = steady
         if episode_summary is not None:

@@ -24,7 +24,8 @@ EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp
            "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_costmap_update", "bp_nb_cap", "bp_obs_height",
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_set_step_cost_hint", "bp_sched_chunk", "bp_sched_warnings", "bp_get_clock_stamps", "bp_last_error",
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
-           "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2", "bp_debug_scramble_hints"]
+           "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2", "bp_debug_scramble_hints",
+           "bp_copy_rows_masked"]
 
 
 class BpCostmapConfig(C.Structure):
@@ -117,6 +118,7 @@ def load():
     L.bp_start_uniform.argtypes = [C.c_uint64, C.c_int64, C.c_int64]
     L.bp_start_uniform.restype = C.c_double
     L.bp_debug_round2.argtypes = [vp, vp, C.c_int32, vp]
+    L.bp_copy_rows_masked.argtypes = [vp, vp, vp, vp, C.c_int64, C.c_int64, vp]
     if hasattr(L, "bp_debug_scramble_hints"):
         L.bp_debug_scramble_hints.argtypes = [vp, C.c_uint64, vp]
     L.bp_costmap_update.argtypes = [vp, C.POINTER(BpCostmapConfig), vp, C.c_double, vp, vp]

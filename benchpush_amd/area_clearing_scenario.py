@@ -84,7 +84,9 @@ def cut_edge_by_wall(p0, p1, wall, r=0.1):
                 ts.append((t, "cap", None))
     if not ts and not inside0:
         return [(list(p0), list(p1))]                      # the wall's buffer does not reach this edge
-    if any(k == "cap" for _, k, _ in ts) or (inside0 and inside1 and not ts):
+    if inside0 and inside1 and not ts:
+        return []   # the whole edge lies inside the buffer (convex: both ends inside, no crossing): LineString.difference is empty, the length filter drops it
+    if any(k == "cap" for _, k, _ in ts):
         raise NotImplementedError("a wall whose rounded end (buffer cap) reaches the clearance boundary needs shapely's polygon of the cap")
     first = None if inside0 else min(ts, key=lambda c: c[0])
     last = None if inside1 else max(ts, key=lambda c: c[0])

@@ -728,6 +728,8 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                     }
                 }
                 const unsigned long long pm = ballot(pre);
+                static_assert(BP_QCAP >= 64 && BD_MAXBOX <= 64, "a flush leaves room for one wave's survivors in q_meta[BP_QCAP]; L.rf[64] is indexed by box rank");
+                static_assert(BP_NSLOT + 2 <= 255, "slot_of keeps 255 as its no-slot sentinel");
                 if (pm) {
                     if (nsurv + __popcll(pm) > BP_QCAP) { lds_sync(); run_queries(); lds_sync(); }
                     if (pre) surv[nsurv + popc_below(pm, lane)] = (unsigned)it;

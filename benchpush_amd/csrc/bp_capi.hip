@@ -857,6 +857,33 @@ int bp_debug_scramble_hints(bp_handle *h, uint64_t seed, void *stream)
     return host; // number of hint words rewritten (>= 0; negative = BP_E*)
 }
 
+// rows of `src` whose mask byte is set -> the same rows of `dst`; one workgroup per row, 16-byte accesses when the row allows them
+__global__ __launch_bounds__(256) void k_copy_rows_masked(const unsigned char *__restrict__ mask, const unsigned *__restrict__ src, unsigned *__restrict__ dst,
+                                                          const long long row_words)
+{
+    const long long r = blockIdx.x;
+    if (mask[r] == 0) return;
+    const unsigned *s = src + r * row_words;
+    unsigned *d = dst + r * row_words;
+    if ((row_words & 3) == 0 && ((((size_t)s) | ((size_t)d)) & 15) == 0) {
+        const uint4 *s4 = (const uint4 *)s; uint4 *d4 = (uint4 *)d;
+        for (long long i = threadIdx.x; i < row_words / 4; i += blockDim.x) d4[i] = s4[i];
+    } else
+        for (long long i = threadIdx.x; i < row_words; i += blockDim.x) d[i] = s[i];
+}
+
+int bp_copy_rows_masked(bp_handle *h, const uint8_t *mask, const void *src, void *dst, int64_t rows, int64_t row_bytes, void *stream)
+{
+    if (!h || !mask || !src || !dst || rows < 0 || row_bytes <= 0 || (row_bytes & 3) != 0 || rows > 0x7FFFFFFF) return BP_EINVAL;
+    if ((((size_t)src) | ((size_t)dst)) & 3) return BP_EINVAL;
+    BP_DEVICE(h);
+    if (rows == 0) return BP_OK;
+    hipLaunchKernelGGL(k_copy_rows_masked, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const unsigned char *)mask, (const unsigned *)src,
+                       (unsigned *)dst, (long long)(row_bytes / 4));
+    HIPCHK(h, hipGetLastError());
+    return BP_OK;
+}
+
 int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream)
 {
     if (!in_dev || !out_dev || n < 0) return BP_EINVAL;

@@ -134,6 +134,8 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 // the true sequence is unimodal and the computed dot products are within ~1e-13 of the true ones (coordinates below 64 m), so every other vertex
 // is then larger too and j is the unique first minimum.
 #define BP_SUPPORT_MARGIN 1e-10
+// narrow phase, parallel facing edges: how much higher above the winning plane the stand-in support vertex may lie (the CPU checker uses the same constant)
+#define BP_TIE_TOL 1e-9
 #ifndef BP_QCAP
 #define BP_QCAP 96          // support queries per batch (LDS)
 #endif

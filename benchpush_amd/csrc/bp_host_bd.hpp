@@ -2,6 +2,7 @@
 // BoxDeliveryEnv.update_configuration_space / create_global_shortest_path_to_receptacle_map (box_delivery_env.py:1115-1175):
 // cv2.fillPoly of the obstacle polygons, skimage disk dilation, scipy's nearest-free-cell indices, spfa from the receptacle.
 #pragma once
+#include <algorithm>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -135,7 +136,7 @@ static void bd_fill_poly(std::vector<unsigned char> &img, int H, int W, const lo
         long long xs[16]; int cnt = 0;
         for (int i = 0; i < n && cnt < 16; i++) {
             const int j = (i + n - 1) % n;
-            const long long x0 = px[j] << 16, x1 = px[i] << 16, y0 = py[j], y1 = py[i];
+            const long long x0 = px[j] * 65536, x1 = px[i] * 65536, y0 = py[j], y1 = py[i];   // 16.16 fixed point (a left shift of a negative value is undefined before C++20)
             if (y0 == y1) continue;
             const long long edx = (x1 - x0) / (y1 - y0);
             long long ex, ey0, ey1;

@@ -50,11 +50,13 @@ static int hull_reduce(double tol, P2 *pts, int n, P2 a, P2 pivot, P2 b, P2 *out
 {
     if (n < 0) return 0;
     if (n == 0) { out[0] = pivot; return 1; }
+    // the pivot of an empty side is never used (count - 1 < 0 returns at once), and with nl == n the element pts[nl] does not exist: Chipmunk's QHullReduce
+    // evaluates verts[0] as an argument regardless; here it is not read (found by the ASan pass of tests/test_host_sanitize.py)
     const int nl = hull_partition(pts, n, a, pivot, tol);
-    int k = hull_reduce(tol, pts + 1, nl - 1, a, pts[0], pivot, out);
+    int k = hull_reduce(tol, pts + 1, nl - 1, a, nl > 0 ? pts[0] : pivot, pivot, out);
     out[k++] = pivot;
     const int nr = hull_partition(pts + nl, n - nl, pivot, b, tol);
-    return k + hull_reduce(tol, pts + nl + 1, nr - 1, pivot, pts[nl], b, out + k);
+    return k + hull_reduce(tol, pts + nl + 1, nr - 1, pivot, nr > 0 ? pts[nl] : pivot, b, out + k);
 }
 
 // cpConvexHull(count, verts, result, NULL, 0.0)

@@ -431,7 +431,9 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (it == nsub - 50) pr_c50 = S.costp;
         if (it == nsub - 10) pr_c10 = S.costp;
 #endif
-        substep<KIND, DAMP>(P, E, L, A, S, P.dt_sub, mode == MODE_STEP);
+        // agent rules: a ship-ice handle gets the yaw + boundary rules, a maze handle the boundary rule alone -- also when a generic KIND 0 kernel
+        // serves it (k_physics_step_damp, k_physics_step with hulls above 8 vertices); the scheduled ship kernel is only ever launched for ship-ice handles
+        substep<KIND, DAMP>(P, E, L, A, S, P.dt_sub, (mode != MODE_STEP) ? 0 : (KIND == BP_ENV_SHIP_ICE && (CHUNKED || P.env_kind == BP_ENV_SHIP_ICE)) ? 1 : 2);
         if (BP_UNLIKELY2(S.quiescent && !BP_TRACE_ON(D))) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active

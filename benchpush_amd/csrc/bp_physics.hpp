@@ -274,7 +274,9 @@ __device__ __forceinline__ void support_queries(const EnvCtx &E, const LdsCtx &L
     }
 }
 
-// One sub-step.  ship_rules: apply the yaw / boundary rules of ShipIceEnv.step after the sub-step.
+// One sub-step.  ship_rules: agent rules applied after the sub-step -- 0 none (reset / settle), 1 the yaw + boundary rules of ShipIceEnv.step
+// (ship_ice_env.py:284-290), 2 the boundary rule alone (MazeNAMO.step, maze_NAMO_env.py:417-419: a maze handle served by a generic KIND 0 instantiation
+// -- damping != 0, hulls above 8 vertices -- must not get the ship's yaw clamp).
 // KIND == BP_ENV_BOX adds box-delivery's collision handlers (box_delivery_env.py:208-229,294-311); other values compile them out.
 // DAMP: space.damping != 0 (ship_ice_env.py:120, maze_NAMO_env.py:148: `space.damping = cfg.sim.damping`; every shipped config sets 0).  cpBodyUpdateVelocity
 // then multiplies the velocities of the dynamic bodies by damping^dt instead of clearing them, so a body keeps moving after its contacts are gone: the
@@ -283,7 +285,7 @@ __device__ __forceinline__ void support_queries(const EnvCtx &E, const LdsCtx &L
 // shortcut -- holds as stated, because each rests on "did not move" / "zero velocity", not on how a velocity came to be zero.
 template <int KIND, bool DAMP = false>
 __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, const LdsCtx &L, ArbReg &A, SubState &S,
-                                        const double dt, const bool ship_rules)
+                                        const double dt, const int ship_rules)
 {
     const int lane = lane_id();
     // vertex loops run to the largest hull of the environment family (box-delivery: quads and triangles only; maze: the
@@ -716,9 +718,22 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 const d2 eB = vsub(bB, aB);
                 const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
                 const bool spanB = !(uB < 0.0) && !(uB > eeB);
+                // Facing edges that are parallel to rounding and overlap only partly: the first-minimum support vertex of a side can be the end of the other
+                // shape's facing edge that lies beyond this edge while its neighbour lies over it (narrow-phase hardening) -- the closest
+                // features are then the two edges, not a vertex pair.  The neighbour towards the span (both hulls counter-clockwise: along the facing side the
+                // tangential coordinate falls with the index) stands in if it lies over the edge and at most BP_TIE_TOL higher above the plane.  Rare: the
+                // neighbour is fetched only here.
+                auto tie_partner = [&](const d2 aP, const d2 eP, const double eeP, const d2 nP, const d2 *Qv, const int nQ, const int j, const d2 q0, const double u) -> bool {
+                    const int jn = (u < 0.0) ? ((j == 0) ? nQ - 1 : j - 1) : ((j + 1 >= nQ) ? 0 : j + 1);
+                    const d2 q1 = Qv[jn];
+                    const double u1 = vdot(vsub(q1, aP), eP);
+                    return !(u1 < 0.0) && !(u1 > eeP) && (vdot(nP, q1) - vdot(nP, q0) <= BP_TIE_TOL);
+                };
                 if (useA) {
                     if (spanA) { n = nAi; src = 0; }
                     else if (sB > 0.0 && spanB) { n = vneg(nBi); src = 1; }
+                    else if (tie_partner(aA, eA, eeA, nAi, Bv, nB, jA, qA, uA)) { n = nAi; src = 0; }
+                    else if (sB > 0.0 && tie_partner(aB, eB, eeB, nBi, Av, nA, jB, qB, uB)) { n = vneg(nBi); src = 1; }
                     else {
                         const d2 pp = vsub(qA, (uA < 0.0) ? aA : bA);
                         const double dl = vlen(pp);
@@ -728,6 +743,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 } else {
                     if (spanB) { n = vneg(nBi); src = 1; }
                     else if (sA > 0.0 && spanA) { n = nAi; src = 0; }
+                    else if (tie_partner(aB, eB, eeB, nBi, Av, nA, jB, qB, uB)) { n = vneg(nBi); src = 1; }
+                    else if (sA > 0.0 && tie_partner(aA, eA, eeA, nAi, Bv, nB, jA, qA, uA)) { n = nAi; src = 0; }
                     else {
                         const d2 pp = vsub((uB < 0.0) ? aB : bB, qB);
                         const double dl = vlen(pp);
@@ -1305,7 +1322,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
     if (ship_rules) {
         const double a0 = L.ag[0].x;
         const double x0 = L.sp[0].x;
-        if (KIND == BP_ENV_SHIP_ICE && (a0 <= 0.0 || a0 >= BP_PI)) {
+        if (KIND == BP_ENV_SHIP_ICE && ship_rules == 1 && (a0 <= 0.0 || a0 >= BP_PI)) {
             if (lane < P.nkin) L.sw[lane] = mk2(0.0, L.sw[lane].y);
             S.yaw_violated = 1;
         }

@@ -254,17 +254,22 @@ class BatchedShipIceEnv(_BatchedBase):
         return out
 
     @staticmethod
-    def clock_hz_between(c0, c1):
-        """Shader clock between two `clock_stamps()` readings: both counters of ONE XCD (the counters of different XCDs are not synchronised), the XCD
-        with the longest span of reference time between its two stamps.  Returns (hz, xcd) or (None, None) if no XCD was stamped before both readings."""
-        best = (None, None, 0)
+    def clock_hz_between(c0, c1, with_span=False):
+        """Shader clock between two `clock_stamps()` readings: both counters of ONE XCD (the counters of different XCDs are not synchronised).  Only the
+        thread of env 0 stamps, so most XCDs are refreshed rarely: an XCD whose first stamp is old (load, warm-up) would bring idle clocks into the span.  The
+        XCD chosen is therefore the one whose FIRST stamp is the newest -- closest to the start of the timed region -- among those stamped again afterwards.
+        Returns (hz, xcd) or (None, None) if no XCD was stamped before both readings; with_span=True appends the reference-time span in seconds."""
+        best = None
         for x in range(8):
             if c0[x, 1] == 0 or c1[x, 1] <= c0[x, 1]:
                 continue
-            span = int(c1[x, 1]) - int(c0[x, 1])
-            if span > best[2]:
-                best = ((int(c1[x, 0]) - int(c0[x, 0])) / span * 1e8, x, span)
-        return best[0], best[1]
+            if best is None or int(c0[x, 1]) > int(c0[best, 1]):
+                best = x
+        if best is None:
+            return (None, None, None) if with_span else (None, None)
+        span = int(c1[best, 1]) - int(c0[best, 1])
+        hz = (int(c1[best, 0]) - int(c0[best, 0])) / span * 1e8
+        return (hz, best, span / 1e8) if with_span else (hz, best)
 
     def sched_warnings(self):
         """(watchdog events, envs finished by the completion launch) of the step scheduler since load: (0, 0) unless a scheduler fault occurred."""

@@ -1,12 +1,25 @@
 """Stable-Baselines3-shaped vectorised environment over a batched GPU env.
 
-The reference trains with ``PPO("CnnPolicy", env, ...)`` on a single ``gym.Env`` (baselines/ship_ice_nav/ppo/policy.py:29-69),
-which SB3 wraps into a ``DummyVecEnv`` of one environment.  ``BatchedVecEnv`` exposes all E device environments through the
-same ``VecEnv`` protocol instead (``reset()``, ``step_async(actions)`` / ``step_wait()`` -> ``(obs, rewards, dones, infos)``,
-auto-reset with ``infos[i]['terminal_observation']`` and ``infos[i]['TimeLimit.truncated']``).  If stable_baselines3 is
-importable the class derives from its ``VecEnv``; this image ships without it, so the protocol is implemented directly.
-Observations stay on the GPU until ``step_wait`` converts the batch once (``to_numpy=False`` keeps torch tensors).
+The reference trains with ``PPO("CnnPolicy", env, ...)`` on a single ``gym.Env`` (baselines/ship_ice_nav/ppo/policy.py:29-69, ResNet18 extractor
+baselines/feature_extractors.py:11-45), which SB3 wraps into a ``DummyVecEnv`` of one environment.  ``BatchedVecEnv`` exposes all E device environments
+through the same ``VecEnv`` protocol instead (``reset()``, ``step_async(actions)`` / ``step_wait()`` -> ``(obs, rewards, dones, infos)``, auto-reset with
+``infos[i]['terminal_observation']`` and ``infos[i]['TimeLimit.truncated']``).  If stable_baselines3 is importable the class derives from its ``VecEnv``;
+this image ships without it, so the protocol is implemented directly.
+
+What the adapter costs per step is what bounds a learner behind it, so it is built to cost nothing it does not have to (tools/bench_vecenv.py measures it):
+
+* ``to_numpy=False`` (on-device learners): observations, rewards and dones stay device tensors and ``step_wait`` never synchronises with the GPU -- the
+  done mask goes to the masked reset as a device tensor, the observations of the envs about to be reset are saved on the device by
+  ``bp_copy_rows_masked`` (cost proportional to the rows that finished), the step counters are updated with tensor ops, and capacity flags are polled
+  every ``check_every`` steps instead of on every batch with a finished episode.
+* ``to_numpy=True`` (SB3 itself): one non-blocking device-to-host copy per output into pre-allocated PINNED host buffers and ONE synchronisation per step;
+  the arrays returned are views of those buffers (valid until the next ``step_wait``, as with SB3's own ``DummyVecEnv`` buffers).
+* ``infos`` is a lazy sequence in both modes: ``infos[i]`` builds env i's dict on first access from one host copy of the info block; only ``len``,
+  indexing and iteration are offered, which is all SB3 uses.  4096 dicts are no longer built per step.
 """
+import collections.abc
+import ctypes as C
+
 import numpy as np
 import torch
 
@@ -17,11 +30,56 @@ try:  # pragma: no cover - not installed in the build image
 except ImportError:
     _Base = object
 
-__all__ = ["BatchedVecEnv", "make_ship_ice_vec_env", "make_maze_vec_env", "make_box_delivery_vec_env", "make_area_clearing_vec_env"]
+__all__ = ["BatchedVecEnv", "LazyInfos", "make_ship_ice_vec_env", "make_maze_vec_env", "make_box_delivery_vec_env", "make_area_clearing_vec_env"]
+
+
+class LazyInfos(collections.abc.Sequence):
+    """``infos`` of one ``step_wait``: a sequence of E dicts built on demand.
+
+    ``infos[i]`` holds the env's info scalars under the adapter's ``info_keys`` and, for an env whose episode ended in this step,
+    ``'terminal_observation'`` (numpy, or a device tensor with ``to_numpy=False``) and ``'TimeLimit.truncated'``.  The first access copies the
+    [E, K] info block (and the done / truncation masks) to the host once; nothing is copied if nobody looks."""
+
+    def __init__(self, keys, info, done, trunc, term_obs, to_numpy):
+        self._keys, self._info, self._done, self._trunc, self._term_obs, self._to_numpy = keys, info, done, trunc, term_obs, to_numpy
+        self._host = None
+        self._cache = {}
+
+    def _pull(self):
+        if self._host is None:
+            as_np = lambda t: t if isinstance(t, np.ndarray) else t.cpu().numpy()   # noqa: E731
+            self._host = (as_np(self._info), as_np(self._done).astype(bool), as_np(self._trunc).astype(bool))
+        return self._host
+
+    def __len__(self):
+        return int(self._info.shape[0])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        d = self._cache.get(i)
+        if d is None:
+            info_h, done_h, trunc_h = self._pull()
+            d = dict(zip(self._keys, info_h[i].tolist()))
+            if done_h[i]:
+                to = self._term_obs[i]
+                d["terminal_observation"] = to.cpu().numpy() if (self._to_numpy and torch.is_tensor(to)) else to
+                d["TimeLimit.truncated"] = bool(trunc_h[i])
+            self._cache[i] = d
+        return d
+
+    def done_indices(self):
+        """Host indices of the envs whose episode ended in this step (one small copy)."""
+        return np.nonzero(self._pull()[1])[0]
 
 
 class BatchedVecEnv(_Base):
-    def __init__(self, batched_env, info_keys, max_episode_steps=None, to_numpy=True, action_shape=()):
+    def __init__(self, batched_env, info_keys, max_episode_steps=None, to_numpy=True, action_shape=(), check_every=64):
         self.env = batched_env
         self.num_envs = batched_env.num_envs
         self.observation_space = spaces.Box(low=0, high=255, shape=batched_env.obs_shape, dtype=np.uint8)
@@ -30,54 +88,87 @@ class BatchedVecEnv(_Base):
         self.info_keys = list(info_keys)
         self.max_episode_steps = max_episode_steps
         self.to_numpy = to_numpy
-        self._steps = torch.zeros(self.num_envs, dtype=torch.int64, device=batched_env.device)
+        self.check_every = int(check_every)
+        dv = batched_env.device
+        self._steps = torch.zeros(self.num_envs, dtype=torch.int64, device=dv)
         self._actions = None
+        self._nstep = 0
+        self._term_obs = torch.zeros((self.num_envs,) + tuple(batched_env.obs_shape), dtype=torch.uint8, device=dv)   # rows of finished envs, saved before the reset
+        self._host = None          # pinned host buffers of the to_numpy path, allocated on first use
         if _Base is not object:
             _Base.__init__(self, self.num_envs, self.observation_space, self.action_space)
 
-    def _out(self, t):
-        return t.cpu().numpy() if self.to_numpy else t
+    # -- host buffers of the numpy path: pinned, allocated once ------------------------------------------
+    def _host_buffers(self):
+        if self._host is None:
+            E, e = self.num_envs, self.env
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
+            self._host = {"obs": pin((E,) + tuple(e.obs_shape), torch.uint8), "rew": pin((E,), torch.float64), "done": pin((E,), torch.bool),
+                          "trunc": pin((E,), torch.bool), "info": pin(tuple(e.info.shape), torch.float64)}
+        return self._host
+
+    def _save_terminal_rows(self, done_u8, obs):
+        from .. import _lib
+        e = self.env
+        row_bytes = int(np.prod(e.obs_shape))
+        stream = C.c_void_p(torch.cuda.current_stream(e.device).cuda_stream)
+        _lib.check(e.L, e.h, e.L.bp_copy_rows_masked(e.h, C.c_void_p(done_u8.data_ptr()), C.c_void_p(obs.data_ptr()), C.c_void_p(self._term_obs.data_ptr()),
+                                                     self.num_envs, row_bytes, stream), "bp_copy_rows_masked")
 
     def reset(self):
         obs, _ = self.env.reset()
         self._steps.zero_()
-        return self._out(obs)
+        if not self.to_numpy:
+            return obs
+        hb = self._host_buffers()
+        hb["obs"].copy_(obs, non_blocking=True)
+        torch.cuda.current_stream(self.env.device).synchronize()
+        return hb["obs"].numpy()
 
     def step_async(self, actions):
         a = torch.as_tensor(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._adim)) if not torch.is_tensor(actions) else actions
         self._actions = a.reshape(self.num_envs * self._adim).to(torch.float32).to(torch.float64)
 
     def step_wait(self):
-        obs, rew, term, trunc, info = self.env.step(self._actions)
+        env = self.env
+        obs, rew, term, trunc, info = env.step(self._actions)
+        term_b, env_trunc = term.bool(), trunc.bool()
         self._steps += 1
-        trunc_b = torch.zeros_like(term, dtype=torch.bool)
-        if self.max_episode_steps is not None:  # gym's TimeLimit (ids registered with max_episode_steps)
-            trunc_b = (self._steps >= self.max_episode_steps) & ~term.bool()
-        trunc_b = trunc_b | (trunc.bool() & ~term.bool())   # truncation reported by the env itself (box-delivery, area-clearing)
-        done = term.bool() | trunc.bool() | trunc_b
-        info_h = info.cpu().numpy()
-        done_h = done.cpu().numpy()
-        trunc_h = trunc_b.cpu().numpy()
-        infos = [dict(zip(self.info_keys, info_h[e].tolist())) for e in range(self.num_envs)]
-        rew_out = self._out(rew.clone())
-        if done_h.any():
-            term_obs = obs[done].cpu().numpy()  # terminal observations before the auto-reset overwrites them
-            for k, e in enumerate(np.nonzero(done_h)[0]):
-                infos[e]["terminal_observation"] = term_obs[k]
-                infos[e]["TimeLimit.truncated"] = bool(trunc_h[e])
-            # an in-kernel capacity overflow (neighbour list, arbiter / velocity slots, colours) only raises a per-env flag while the
-            # step carries on with dropped items: surface it here, once per batch of finished episodes, instead of never
-            self.env.check_errors()
-            obs, _ = self.env.reset(done)
-            self._steps[done] = 0
-        return self._out(obs), rew_out, (done_h if self.to_numpy else done), infos
+        trunc_b = env_trunc & ~term_b                                   # truncation reported by the env itself (box-delivery, area-clearing)
+        if self.max_episode_steps is not None:                          # gym's TimeLimit (ids registered with max_episode_steps)
+            trunc_b = trunc_b | ((self._steps >= self.max_episode_steps) & ~term_b)
+        done = term_b | env_trunc | trunc_b
+        done_u8 = done.to(torch.uint8)
+        rew_out = rew.clone()                                           # the env's buffers are rewritten by the next step
+        info_out = info.clone()
+        self._save_terminal_rows(done_u8, obs)                          # terminal observations, before the auto-reset overwrites those rows
+        obs, _ = env.reset(done_u8)                                     # masked reset, device mask: a batch with no finished env launches two empty kernels
+        self._steps.mul_((~done).to(torch.int64))
+        self._nstep += 1
+        if self.check_every > 0 and self._nstep % self.check_every == 0:
+            # an in-kernel capacity overflow (neighbour list, arbiter / velocity slots, colours) only raises a per-env flag while the step carries on
+            # with dropped items: surfaced here every `check_every` steps (a host synchronisation) and in close()
+            env.check_errors()
+        if not self.to_numpy:
+            return obs, rew_out, done, LazyInfos(self.info_keys, info_out, done, trunc_b, self._term_obs, False)
+        hb = self._host_buffers()
+        hb["obs"].copy_(obs, non_blocking=True); hb["rew"].copy_(rew_out, non_blocking=True); hb["done"].copy_(done, non_blocking=True)
+        hb["trunc"].copy_(trunc_b, non_blocking=True); hb["info"].copy_(info_out, non_blocking=True)
+        torch.cuda.current_stream(env.device).synchronize()             # the one synchronisation of the step
+        # rewards and dones are small: returned as copies (SB3's DummyVecEnv copies its buffers too); the observation batch is a view of the pinned buffer
+        return (hb["obs"].numpy(), hb["rew"].numpy().copy(), hb["done"].numpy().copy(),
+                LazyInfos(self.info_keys, hb["info"].numpy(), hb["done"].numpy(), hb["trunc"].numpy(), self._term_obs, True))
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
 
     def close(self):
-        self.env.close()
+        if getattr(self.env, "h", None):
+            try:
+                self.env.check_errors()
+            finally:
+                self.env.close()
 
     # minimal VecEnv plumbing used by SB3
     def seed(self, seed=None):
@@ -96,24 +187,24 @@ class BatchedVecEnv(_Base):
         return [False] * self.num_envs
 
 
-def make_ship_ice_vec_env(num_envs, cfg=None, **kw):
+def make_ship_ice_vec_env(num_envs, cfg=None, to_numpy=True, **kw):
     from .. import _lib
     from .ship_ice import BatchedShipIceEnv
-    return BatchedVecEnv(BatchedShipIceEnv(num_envs, cfg=cfg, **kw), _lib.INFO_KEYS, max_episode_steps=300)
+    return BatchedVecEnv(BatchedShipIceEnv(num_envs, cfg=cfg, **kw), _lib.INFO_KEYS, max_episode_steps=300, to_numpy=to_numpy)
 
 
-def make_maze_vec_env(num_envs, cfg=None, **kw):
+def make_maze_vec_env(num_envs, cfg=None, to_numpy=True, **kw):
     from .maze_namo import MAZE_INFO_KEYS, BatchedMazeEnv
-    return BatchedVecEnv(BatchedMazeEnv(num_envs, cfg=cfg, **kw), MAZE_INFO_KEYS, max_episode_steps=400)
+    return BatchedVecEnv(BatchedMazeEnv(num_envs, cfg=cfg, **kw), MAZE_INFO_KEYS, max_episode_steps=400, to_numpy=to_numpy)
 
 
-def make_box_delivery_vec_env(num_envs, cfg=None, **kw):
+def make_box_delivery_vec_env(num_envs, cfg=None, to_numpy=True, **kw):
     from .box_delivery import BD_INFO_KEYS, BatchedBoxDeliveryEnv
     env = BatchedBoxDeliveryEnv(num_envs, cfg=cfg, **kw)
-    return BatchedVecEnv(env, BD_INFO_KEYS, max_episode_steps=30000, action_shape=(env.action_dim,))
+    return BatchedVecEnv(env, BD_INFO_KEYS, max_episode_steps=30000, action_shape=(env.action_dim,), to_numpy=to_numpy)
 
 
-def make_area_clearing_vec_env(num_envs, cfg=None, **kw):
+def make_area_clearing_vec_env(num_envs, cfg=None, to_numpy=True, **kw):
     from .area_clearing import AC_INFO_KEYS, BatchedAreaClearingEnv
     env = BatchedAreaClearingEnv(num_envs, cfg=cfg, **kw)
-    return BatchedVecEnv(env, AC_INFO_KEYS, max_episode_steps=30000, action_shape=(env.action_dim,))
+    return BatchedVecEnv(env, AC_INFO_KEYS, max_episode_steps=30000, action_shape=(env.action_dim,), to_numpy=to_numpy)

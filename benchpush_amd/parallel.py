@@ -19,9 +19,10 @@ def shard_range(total_envs, rank, world):
 def allgather_episode_metrics(local, dist=None):
     """All-gather a fixed-shape [n, k] float64 metric block from every rank -> [world*n, k] (rank-major).
 
-    `dist` is torch.distributed (initialised) or None for single-process runs.
+    `dist` is torch.distributed (initialised) or None for single-process runs.  An initialised group of ONE rank still goes through the
+    collective (that is how tests/test_gpu_rccl.py loads RCCL on a one-GPU box).
     """
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return local.clone()
     world = dist.get_world_size()
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 8
+#define BP_ABI_VERSION 9
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -208,6 +208,11 @@ int bp_get_episode_metrics(bp_handle *h, double *rows, uint32_t *counts, void *s
  *   counts device uint32 [E] episodes finished so far.  Any pointer may be NULL. */
 #define BP_EPM_RING 8
 int bp_get_episode_history(bp_handle *h, double *ring, double *sums, uint32_t *counts, void *stream);
+/* Rollout plumbing for vectorised callers (the reference's learners wrap the env in SB3's VecEnv, whose auto-reset hands the LAST observation of a
+ * finished episode back as infos[i]['terminal_observation'], baselines/ship_ice_nav/ppo/policy.py:29-69): copies row r of src to row r of dst for every r with
+ * mask[r] != 0 -- device pointers, rows of row_bytes bytes (a multiple of 4), nothing is read back, so the caller can save the observations of the envs that are
+ * about to be reset without a host synchronisation.  Cost is proportional to the rows selected.  ABI 9. */
+int bp_copy_rows_masked(bp_handle *h, const uint8_t *mask, const void *src, void *dst, int64_t rows, int64_t row_bytes, void *stream);
 /* test hook: out[i] = the device's restatement of python's round(in[i], 2) (device doubles [n]) */
 int bp_debug_round2(const double *in_dev, double *out_dev, int32_t n, void *stream);
 /* test hook: overwrite every cached-plane hint word of the live envs with random valid contents (indices below the recorded vertex counts, random

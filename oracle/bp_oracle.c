@@ -393,6 +393,24 @@ static int in_span(const shape_t *P, int i, vec q, int *k)
     return 1;
 }
 
+/* Facing edges that are parallel (to rounding) and overlap only partly: the plane search's support vertex of Q -- the FIRST minimum of n . q, a tie or
+ * one ulp apart between the two ends of Q's facing edge -- can be the end that lies beyond edge i of P while the other end lies over it, and the same
+ * on the other side; the closest features are then the two edges (distance = the plane separation), not the vertex pair.  k = the end of P's edge
+ * that the support vertex j lies beyond (in_span); the neighbour of j towards the span (both hulls are counter-clockwise, so along Q's facing side the
+ * tangential coordinate falls with the index) takes its place if it lies over the edge and no higher above the plane than BP_TIE_TOL.  Chipmunk's GJK
+ * returns a point pair of the overlap with the edge normal in this configuration (cpCollision.c ClosestPoints). */
+#define BP_TIE_TOL 1e-9
+static int tie_partner_in_span(const shape_t *P, int i, const shape_t *Q, int j, int k)
+{
+    if (k < 0 || Q->n < 2) return 0;
+    int i0 = (i - 1 + P->n) % P->n;
+    int jn = (k == i0) ? (j - 1 + Q->n) % Q->n : (j + 1) % Q->n;
+    vec n = P->wn[i];
+    int kk;
+    if (!in_span(P, i, Q->wv[jn], &kk)) return 0;
+    return vdot(n, Q->wv[jn]) - vdot(n, Q->wv[j]) <= BP_TIE_TOL;
+}
+
 typedef struct { int count; vec n; vec p1[2], p2[2]; uint32_t hash[2]; } manifold_t;
 
 /* Returns 1 and fills *n when the core polygons are within rsum of each other (Chipmunk:
@@ -420,8 +438,10 @@ static int closest_normal(const shape_t *A, const shape_t *B, vec *nout)
     int k;
     if (useA) {
         if (in_span(A, iA, B->wv[jA], &k)) { *nout = A->wn[iA]; return 1; }
-        int k2;
+        int k2 = -1;
         if (sB > 0.0 && in_span(B, iB, A->wv[jB], &k2)) { *nout = vneg(B->wn[iB]); return 1; }
+        if (tie_partner_in_span(A, iA, B, jA, k)) { *nout = A->wn[iA]; return 1; }
+        if (sB > 0.0 && tie_partner_in_span(B, iB, A, jB, k2)) { *nout = vneg(B->wn[iB]); return 1; }
         vec p = vsub(B->wv[jA], A->wv[k]);
         double d2 = vlength(p);
         if (d2 > rsum) return 0;
@@ -429,8 +449,10 @@ static int closest_normal(const shape_t *A, const shape_t *B, vec *nout)
         return 1;
     } else {
         if (in_span(B, iB, A->wv[jB], &k)) { *nout = vneg(B->wn[iB]); return 1; }
-        int k2;
+        int k2 = -1;
         if (sA > 0.0 && in_span(A, iA, B->wv[jA], &k2)) { *nout = A->wn[iA]; return 1; }
+        if (tie_partner_in_span(B, iB, A, jB, k)) { *nout = vneg(B->wn[iB]); return 1; }
+        if (sA > 0.0 && tie_partner_in_span(A, iA, B, jA, k2)) { *nout = A->wn[iA]; return 1; }
         vec p = vsub(B->wv[k], A->wv[jB]);
         double d2 = vlength(p);
         if (d2 > rsum) return 0;

@@ -74,6 +74,32 @@ def test_parity_random_start_per_layout():
     _run(E=3, nbox=6, T=3, steps=12, seed=3, random_start=True, maze_version=2)
 
 
+def test_maze_damping_and_large_hulls_do_not_get_the_ship_yaw_clamp():
+    """A maze handle served by a generic KIND 0 kernel -- `sim.damping != 0` (k_physics_step_damp) or a robot outline above 8 vertices (k_physics_step) --
+    keeps MazeNAMO.step's rules (maze_NAMO_env.py:405-419: boundary only): the ship's yaw clamp (ship_ice_env.py:284-287) must not zero the commanded
+    angular velocity when the heading is outside (0, pi).  maze_version 2 starts at heading 3 pi / 2, i.e. outside from the first sub-step; the v1 envs turn
+    hard over until they pass pi / 0."""
+    _run(E=3, nbox=6, T=2, steps=12, seed=5, maze_version=2, sim={"damping": 0.8})
+    _run(E=2, nbox=5, T=2, steps=26, seed=6, action_fn=lambda e, t: 1.0 if e == 0 else -1.0, sim={"damping": 0.5})
+    # a 10-vertex outline (the shipped octagon with two extra vertices on its long sides): hulls above 8 vertices take the generic instantiation
+    from benchpush_amd.config import default_cfg
+    verts = [list(map(float, v)) for v in default_cfg("maze_namo").robot.vertices]
+    hull = np.array(verts)
+    i0 = int(np.argmax(np.linalg.norm(np.roll(hull, -1, 0) - hull, axis=1)))           # longest edge and the one opposite: bulge their midpoints outwards
+    ext = []
+    for k, v in enumerate(verts):
+        ext.append(v)
+        if k in (i0, (i0 + len(verts) // 2) % len(verts)):
+            a, b = hull[k], hull[(k + 1) % len(verts)]
+            mid, e = (a + b) / 2, b - a
+            nrm = np.array([e[1], -e[0]]) / np.linalg.norm(e)
+            if np.dot(nrm, mid - hull.mean(0)) < 0:
+                nrm = -nrm
+            ext.append(list(mid + 0.01 * nrm))
+    assert len(ext) == len(verts) + 2
+    _run(E=2, nbox=6, T=2, steps=10, seed=7, maze_version=2, robot={"vertices": ext})
+
+
 def test_parity_straight_drive_pushes_boxes():
     _run(E=2, nbox=20, T=2, steps=30, seed=2, action_fn=lambda e, t: 0.0)
 

@@ -552,6 +552,50 @@ def test_vec_env_protocol_autoreset_and_timelimit():
     venv.close()
 
 
+def test_vec_env_device_mode_matches_numpy_mode_and_keeps_terminal_observations():
+    """`to_numpy=False` (no host synchronisation per step: device done mask into the masked reset, terminal rows saved by bp_copy_rows_masked, lazy infos)
+    returns exactly what the numpy mode returns, and a finished env's `terminal_observation` is the raster of its last state -- the row the raw env
+    produced before the auto-reset overwrote it."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    from benchpush_amd.envs.vec_env import LazyInfos, make_ship_ice_vec_env
+    trials = default_trials(0.1, 3, base_seed=2)
+    vd = make_ship_ice_vec_env(6, cfg={"concentration": 0.1}, trials=trials, to_numpy=False)
+    vn = make_ship_ice_vec_env(6, cfg={"concentration": 0.1}, trials=trials)
+    raw = BatchedShipIceEnv(6, cfg={"concentration": 0.1}, trials=trials)
+    vd.max_episode_steps = vn.max_episode_steps = 12
+    od, on = vd.reset(), vn.reset()
+    raw.reset()
+    rsteps = np.zeros(6, int)
+    assert torch.is_tensor(od) and od.is_cuda and np.array_equal(od.cpu().numpy(), on)
+    ndone = 0
+    for t in range(30):
+        a = np.zeros(6, np.float32)
+        a[0] = 1.0                                   # env 0 leaves the channel: terminated
+        od, rd, dd, idv = vd.step(torch.from_numpy(a).cuda())
+        on, rn, dn, inn = vn.step(a)
+        ro, rr, rt, _, ri = raw.step(torch.from_numpy(a))
+        ro = ro.cpu().numpy().copy()
+        rsteps += 1
+        assert torch.is_tensor(dd) and dd.is_cuda and dd.dtype == torch.bool and rd.is_cuda and isinstance(idv, LazyInfos) and len(idv) == 6
+        assert np.array_equal(od.cpu().numpy(), on) and np.array_equal(rd.cpu().numpy(), rn) and np.array_equal(dd.cpu().numpy(), dn)
+        rdone = rt.cpu().numpy().astype(bool) | (rsteps >= 12)
+        assert np.array_equal(dn, rdone)
+        for e in range(6):
+            assert idv[e]["x"] == inn[e]["x"] == float(ri[e, 0]) and idv[-6 + e] is idv[e]
+            if dn[e]:
+                ndone += 1
+                assert np.array_equal(inn[e]["terminal_observation"], ro[e])                       # the last observation of the finished episode
+                assert torch.is_tensor(idv[e]["terminal_observation"]) and np.array_equal(idv[e]["terminal_observation"].cpu().numpy(), ro[e])
+                assert idv[e]["TimeLimit.truncated"] == inn[e]["TimeLimit.truncated"] == (not bool(rt[e]))
+            else:
+                assert "terminal_observation" not in idv[e] and np.array_equal(on[e], ro[e])
+        assert list(idv.done_indices()) == list(np.nonzero(dn)[0]) and [d["y"] for d in inn[1:3]] == [inn[1]["y"], inn[2]["y"]]
+        raw.reset(torch.from_numpy(rdone))
+        rsteps[rdone] = 0
+    assert ndone >= 8
+    vd.close(); vn.close(); raw.close()
+
+
 def test_global_planner_observation_matches_oracle():
     """cfg.egocentric_obs: false -> uint8 [2, 200, 60] (5x5 block-mean occupancy + footprint), byte for byte."""
     import benchpush_amd

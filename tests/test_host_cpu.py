@@ -21,7 +21,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"bp_create", "bp_step", "bp_reset", "bp_load_scenarios", "bp_get_world_polys"} <= declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bp_abi_version() == 8
+    assert L.bp_abi_version() == 9
     assert set(_lib.EXPORTS) <= declared | {"bp_debug_trace"}
 
 
@@ -219,6 +219,10 @@ def test_bench_gpus_2_really_starts_two_ranks():
     assert len(lines) == 1, p.stdout.decode()
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["plumbing_only"] is True and d["gathered_shape"] == [8192, 6]
+    # the keys BASELINE.md section 3 asks of every N > 1 line: the timed all-gather of the real block and the strong-scaling split
+    assert d["allgather_ms"] > 0 and d["allgather"]["reps"] == 20 and d["allgather"]["payload_bytes_per_rank"] == 4096 * 7 * 8
+    assert d["strong_scaling"]["total_envs"] == 4096 and d["strong_scaling"]["envs_per_gpu"] == 2048
+    assert {"value", "ms_per_step", "speedup_vs_one_gpu", "efficiency"} <= set(d["strong_scaling"])
 
 
 def test_bench_refuses_more_ranks_than_gpus():

@@ -237,3 +237,167 @@ def test_contact_points_known_answers_worked_by_hand():
     assert orc.collide(A, r, D2, r)[0] == 0
     cnt, n2, q1, q2, _ = orc.collide(D, r, A, r)
     assert cnt == 1 and np.allclose(n2, [-c30, -s30], atol=1e-12) and np.allclose(q1[0], p2[0], atol=1e-9) and np.allclose(q2[0], p1[0], atol=1e-9)
+
+
+# ---- hardening of the unpinned narrow phase: the exact closest-feature query that stands in for Chipmunk's GJK / EPA
+# (cpCollision.c ClosestPoints: the touching decision d <= r1 + r2 and the direction of the closest points are all that reach ContactPoints) is
+# held to a brute-force distance computation that shares nothing with it -----------------------------------------------------------------
+def _closest_brute(a, b):
+    """(distance, unit direction from A's closest point to B's, kind) of two convex polygons / segments given as CCW vertex arrays; distance 0 and
+    direction None when they intersect.  Every (vertex, edge) combination of both shapes, vectorised; kind = 'vv' if the closest points are two vertices."""
+    def seg_pairs(P, Q):   # closest point on every edge of P to every vertex of Q
+        A0, A1 = P, np.roll(P, -1, 0)
+        d = A1 - A0
+        dd = np.maximum((d * d).sum(1), 1e-300)
+        t = np.clip(((Q[None, :, :] - A0[:, None, :]) * d[:, None, :]).sum(2) / dd[:, None], 0.0, 1.0)
+        C = A0[:, None, :] + t[:, :, None] * d[:, None, :]
+        D = np.linalg.norm(Q[None, :, :] - C, axis=2)
+        k = np.unravel_index(np.argmin(D), D.shape)
+        return D[k], C[k], Q[k[1]], t[k]
+
+    def inside(P, x):
+        if len(P) < 3:
+            return False
+        e = np.roll(P, -1, 0) - P
+        return bool(np.all(e[:, 0] * (x[1] - P[:, 1]) - e[:, 1] * (x[0] - P[:, 0]) >= 0))
+
+    def cross_any(P, Q):   # proper or touching intersection of any edge pair
+        for i in range(len(P)):
+            p, r = P[i], P[(i + 1) % len(P)] - P[i]
+            for j in range(len(Q)):
+                q, s = Q[j], Q[(j + 1) % len(Q)] - Q[j]
+                den = r[0] * s[1] - r[1] * s[0]
+                if den == 0.0:
+                    continue
+                t = ((q[0] - p[0]) * s[1] - (q[1] - p[1]) * s[0]) / den
+                u = ((q[0] - p[0]) * r[1] - (q[1] - p[1]) * r[0]) / den
+                if 0 <= t <= 1 and 0 <= u <= 1:
+                    return True
+        return False
+    if any(inside(a, x) for x in b) or any(inside(b, x) for x in a) or cross_any(a, b):
+        return 0.0, None, "overlap"
+    dA, cA, qB, tA = seg_pairs(a, b)      # point on A's boundary, vertex of B
+    dB, cB, qA, tB = seg_pairs(b, a)      # point on B's boundary, vertex of A
+    if dA <= dB:
+        d, pa, pb, t = dA, cA, qB, tA
+    else:
+        d, pa, pb, t = dB, qA, cB, tB
+    return float(d), (pb - pa) / d, ("vv" if t in (0.0, 1.0) else "ve")
+
+
+def _rot(p, ang, about=(0.0, 0.0)):
+    c, s = math.cos(ang), math.sin(ang)
+    q = np.asarray(p, float) - about
+    return np.stack([c * q[:, 0] - s * q[:, 1], s * q[:, 0] + c * q[:, 1]], 1) + about
+
+
+def _check_pair(a, ra, b, rb, stats, eps=1e-9):
+    d, ndir, kind = _closest_brute(a, b)
+    cnt, n, p1, p2, _ = orc.collide(a, ra, b, rb)
+    rs = ra + rb
+    if d < rs - eps:
+        assert cnt > 0, ("missed contact", d, rs, kind, a.tolist(), b.tolist())
+        stats["touch"] += 1
+    elif d > rs + eps:
+        assert cnt == 0, ("phantom contact", d, rs, kind, a.tolist(), b.tolist())
+        stats["apart"] += 1
+    if cnt > 0:
+        assert abs(np.linalg.norm(n) - 1) < 1e-12 and cnt <= 2
+        assert all(np.dot(p2[k] - p1[k], n) <= 1e-15 for k in range(cnt))
+        if d > 1e-7:     # separated cores: the normal is the direction of the closest points (unique for convex sets), from A to B
+            assert np.linalg.norm(n - ndir) < 1e-9 * max(1.0, 1e-3 / d), ("normal", n, ndir, d, kind, a.tolist(), b.tolist())
+            stats[kind] += 1
+            # the contact points sit on the two rounded surfaces; the deepest one realises the distance: dist = d - (ra + rb)
+            deepest = min(np.dot(p2[k] - p1[k], n) for k in range(cnt))
+            assert abs(deepest - (d - rs)) < 1e-9, ("depth", deepest, d - rs, kind)
+
+
+def test_narrowphase_against_brute_force_on_10000_convex_pairs():
+    """Random convex pairs moved to gaps around r1 + r2 (incl. just inside / just outside), constructed vertex-vertex and (near-)parallel-edge
+    configurations, radii 0 and 0.02: touching decision both ways, normal = brute-force closest-points direction, depth = d - (r1 + r2)."""
+    import collections
+    import random
+    from benchpush_amd.scenario import generate_polygon
+    rng = random.Random(11)
+    nrng = np.random.default_rng(11)
+    stats = collections.Counter()
+    polys = [orc.convex_hull(generate_polygon(rng.uniform(0.6, 2.0), (0.0, 0.0), rng=rng)) for _ in range(400)]
+    n_pairs = 0
+    # (1) random pairs, B pushed along the closest direction to a prescribed gap: exact for convex sets while the gap stays positive
+    for it in range(7000):
+        a = polys[rng.randrange(len(polys))]
+        b = _rot(polys[rng.randrange(len(polys))], rng.uniform(0, 2 * math.pi)) + nrng.uniform(-2.5, 2.5, 2)
+        r = 0.02 if it % 3 else 0.0
+        d, ndir, _ = _closest_brute(a, b)
+        if ndir is not None:
+            gap = rng.choice([rng.uniform(1e-6, 2 * r + 0.05), 2 * r - 1e-7, 2 * r + 1e-7, 2 * r * rng.random(), d])
+            if gap > 0:
+                b = b + (gap - d) * ndir
+        _check_pair(a, r, b, r, stats)
+        n_pairs += 1
+    # (2) vertex against vertex: B's vertex j put on the outward bisector of A's vertex i at gap g, B turned so that -u lies inside j's normal cone
+    for it in range(1500):
+        a, b0 = polys[rng.randrange(len(polys))], polys[rng.randrange(len(polys))]
+        i, j = rng.randrange(len(a)), rng.randrange(len(b0))
+        def cone(P, k):
+            e0, e1 = P[k] - P[k - 1], P[(k + 1) % len(P)] - P[k]
+            n0, n1 = np.array([e0[1], -e0[0]]) / np.linalg.norm(e0), np.array([e1[1], -e1[0]]) / np.linalg.norm(e1)
+            return n0, n1
+        n0, n1 = cone(a, i)
+        w = rng.uniform(0.05, 0.95)
+        u = n0 * w + n1 * (1 - w)
+        u /= np.linalg.norm(u)
+        m0, m1 = cone(b0, j)
+        v = m0 * 0.5 + m1 * 0.5
+        v /= np.linalg.norm(v)
+        ang = math.atan2(-u[1], -u[0]) - math.atan2(v[1], v[0])       # turn B so that its vertex bisector points along -u
+        b = _rot(b0, ang + rng.uniform(-0.02, 0.02))
+        r = 0.02 if it % 4 else 0.0
+        g = rng.choice([rng.uniform(1e-5, 0.039), 0.04 - 1e-7, 0.04 + 1e-7, rng.uniform(0.041, 0.2)])
+        b = b + (a[i] + g * u - b[j])
+        _check_pair(a, r, b, r, stats)
+        n_pairs += 1
+    # (3) an edge of B parallel (exactly, and off by 1e-12 .. 1e-4 rad) to an edge of A, facing it at gap g with partial tangential overlap
+    for it in range(1500):
+        a, b0 = polys[rng.randrange(len(polys))], polys[rng.randrange(len(polys))]
+        i, j = rng.randrange(len(a)), rng.randrange(len(b0))
+        ea, eb = a[i] - a[i - 1], b0[j] - b0[j - 1]
+        ang = math.atan2(-ea[1], -ea[0]) - math.atan2(eb[1], eb[0]) + rng.choice([0.0, 1e-12, -1e-12, 1e-9, 1e-6, -1e-4])
+        b = _rot(b0, ang)
+        na = np.array([ea[1], -ea[0]]) / np.linalg.norm(ea)
+        r = 0.02 if it % 4 else 0.0
+        g = rng.choice([rng.uniform(1e-5, 0.039), 0.04 - 1e-7, 0.04 + 1e-7, 0.0401, rng.uniform(0.05, 0.3)])
+        mid_b = 0.5 * (b[j] + b[j - 1])
+        b = b + (a[i - 1] + rng.uniform(-0.2, 1.2) * ea + g * na - mid_b)
+        _check_pair(a, r, b, r, stats)
+        n_pairs += 1
+    assert n_pairs == 10000
+    assert stats["vv"] > 800 and stats["ve"] > 800 and stats["touch"] > 3000 and stats["apart"] > 1500, dict(stats)
+
+
+def test_narrowphase_segments_against_brute_force():
+    """The 2-vertex hulls of the maze walls (pymunk.Segment radius 0.5, sim_utils.py:174-181) against boxes / robot outlines (radius 0.02) and against
+    each other: the same three properties."""
+    import collections
+    import random
+    rng = random.Random(3)
+    stats = collections.Counter()
+    box = np.array([[-0.5, -0.5], [0.5, -0.5], [0.5, 0.5], [-0.5, 0.5]])
+    octa = orc.convex_hull(np.array([[0.7, -0.5], [0.55, -0.6], [-0.55, -0.6], [-0.7, -0.5], [-0.7, 0.5], [-0.55, 0.6], [0.55, 0.6], [0.7, 0.5]]))   # the maze robot, counter-clockwise like every hull the envs build
+    for it in range(3000):
+        L = rng.uniform(0.5, 8.0)
+        seg = _rot(np.array([[0.0, 0.0], [L, 0.0]]), rng.uniform(0, 2 * math.pi))
+        other = _rot(box if it % 2 else octa, rng.uniform(0, 2 * math.pi)) + np.array([rng.uniform(-1.5, L + 1.5), rng.uniform(-2.0, 2.0)])
+        ra, rb = 0.5, 0.02
+        if it % 5 == 0:
+            other = _rot(np.array([[0.0, 0.0], [rng.uniform(0.5, 4.0), 0.0]]), rng.uniform(0, 2 * math.pi)) + other.mean(0)
+            rb = 0.5
+        d, ndir, _ = _closest_brute(seg, other)
+        if ndir is not None:
+            gap = rng.choice([rng.uniform(1e-6, ra + rb + 0.1), ra + rb - 1e-7, ra + rb + 1e-7, d])
+            other = other + (gap - d) * ndir
+        if it % 2:
+            _check_pair(seg, ra, other, rb, stats)
+        else:
+            _check_pair(other, rb, seg, ra, stats)
+    assert stats["touch"] > 800 and stats["apart"] > 500 and stats["vv"] > 100 and stats["ve"] > 300, dict(stats)
