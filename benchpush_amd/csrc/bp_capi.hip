@@ -25,6 +25,7 @@ struct bp_handle {
     bool resettle = false; // true: reset() re-runs the settle sub-steps instead of copying the settled template
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
     bool damp = false;     // bp_config.damping_pow != 0: k_physics_step_damp / k_physics_reset_damp (generic vertex loops, no scheduler)
+    int pair_mode = 0;              // two envs per wavefront (bp_physics_pair.hpp): 1 = fixed pairs for the whole step (k_physics_step_pair), 2 = inside the scheduler
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
     hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -319,6 +320,14 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         // Preemptive scheduler (k_physics_step_sched), the default step kernel of a ship-ice handle: chunks of 40 sub-steps.  It pays while the launch
         // is a few rounds of the wave slots (+14 % at 4096 envs; -1 % at 16 384, where the tail is amortised): BP_SCHED=<chunk> forces it, BP_SCHED=0
         // selects the one-wave-per-env kernel.
+        // two environments per wavefront: the half-wave LDS image is laid out for PP_NBCAP body slots, element offsets are 32-bit
+        const bool can_pair = plain && nbcap <= PP_NBCAP && h->lds_bytes <= 2 * PL_HALF &&
+                              ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_KADJ < (size_t)0x7FFFFFFF;
+        if (const char *evp = getenv("BP_PAIR")) { if (can_pair) h->pair_mode = atoi(evp); }
+        if (h->pair_mode == 1) {
+            h->P.pair_mode = 1;
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * PL_HALF)));
+        }
         int ch = (h->num_envs <= 8192) ? 40 : 0;
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
@@ -621,7 +630,9 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             h->D.order = h->order_buf;
         }
         if (mode == MODE_STEP) h->steps_done = true;
-        if (mode == MODE_STEP && h->sched_chunk > 0 && h->D.dbg == nullptr) {
+        if (mode == MODE_STEP && h->pair_mode == 1 && h->D.dbg == nullptr)
+            hipLaunchKernelGGL(k_physics_step_pair, dim3((h->num_envs + 1) / 2), dim3(64), 2 * PL_HALF, st, h->P, h->D, actions, reward, term, trunc, info);
+        else if (mode == MODE_STEP && h->sched_chunk > 0 && h->D.dbg == nullptr) {
             // preemptive scheduler: one workgroup per (env, chunk) task (most leave at once: only parked envs need a second workgroup)
             hipLaunchKernelGGL(k_sched_init, dim3(16), dim3(1024), 0, st, h->P, h->D);
             HIPCHK(h, hipGetLastError());
@@ -1266,6 +1277,8 @@ int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
     HIPCHK(h, hipMemcpy(out2_host, h->D.clk, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return BP_OK;
 }
+
+int32_t bp_pair_mode(bp_handle *h) { return h ? h->pair_mode : 0; }
 
 int bp_sched_warnings(bp_handle *h, int32_t *out2_host)
 {

@@ -37,6 +37,10 @@ struct DevParams {
     int sq_debug;                              // test hook (BP_SCHED_DEBUG_DROP=1): env 1 is parked after its first chunk and never queued, the watchdog is short
     int dbg_paths;                             // test hook (BP_DEBUG_PATHS bit mask): 1 no candidate cache, 2 bound rounds through the sequential (flushing) loop,
                                                // 4 cached planes always through the support query, 8 manifold support vertices always through the support query
+    // two environments per wavefront (bp_physics_pair.hpp): 0 off, 1 fixed pairs (2b, 2b + 1) for the whole step (k_physics_step_pair: parity tests),
+    // 2 inside the preemptive scheduler (the pair_solo heaviest envs of the dispatch order start alone, the others in pairs)
+    int pair_mode, pair_solo;
+    int pp_max_keys, pp_max_slots, pp_max_mv, pp_max_act, pp_max_work;   // when a half leaves its pair (pair_should_leave)
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
     double start_x_range, ship_mass;
     unsigned long long start_seed;
@@ -72,6 +76,8 @@ struct DevPtrs {
     unsigned char *sq_moved; // [E][nbcap] shape moved in an earlier chunk of this step
     int *sq_done;            // [E] the env's step is complete (cleared by k_sched_init)
     int *sq_lev;             // [E] chunks completed when the env was last parked
+    int *sq_sub;             // [E] sub-steps of the current step completed when the env was last parked (0: not parked in this step); cleared by k_sched_init
+    int *sq_pairctr;         // [2] next pair task of the scheduled launch, pairs started
     int *sq_rescue;          // [1 + SQ_RESCUE] count and ids of the envs the scheduled launch left unfinished (k_sched_scan)
     int *sq_warn;            // [2] scheduler watchdog events, envs finished by the completion launch (cumulative; bp_sched_warnings)
     d2 *pxy;                 // [E][nbcap] position of COG

@@ -31,6 +31,8 @@ __device__ __forceinline__ d2 poly_centroid_seq(const d2 *v, int n)
     return mk2(__builtin_fabs(f * sx), __builtin_fabs(f * sy));
 }
 
+#include "bp_physics_pair.hpp"
+
 #ifdef BP_PROF
 #define BP_PROF_ON true
 #else
@@ -647,6 +649,21 @@ __global__ __launch_bounds__(64, 2) void k_physics_step(const DevParams P, const
                                                      unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     physics_body<MODE_STEP, 0>(P, D, actions, nullptr, reward, terminated, truncated, info, 0);
+}
+// Two environments per wavefront, fixed pairs for the whole step (P.pair_mode == 1; BP_PAIR=1): workgroup b steps the envs at positions 2b and 2b + 1 of the
+// dispatch order.  No env leaves its pair here: the half-wave capacities are hard limits (per-env error bits as in the solo kernel).  The parity tests run
+// the paired sub-step through this kernel; the product path is the scheduler below with P.pair_mode == 2.
+__global__ __launch_bounds__(64, 2) void k_physics_step_pair(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                          double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                          unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    const int p0 = 2 * (int)blockIdx.x, p1 = p0 + 1;
+    const int e0 = D.order != nullptr ? D.order[p0] : p0;
+    const int e1 = p1 < P.num_envs ? (D.order != nullptr ? D.order[p1] : p1) : -1;
+    PairLimits Q;
+    Q.max_keys = Q.max_slots = Q.max_mv = Q.max_act = Q.max_work = 0x7FFFFFFF;
+    int it;
+    pair_task<false>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it);
 }
 // ---- preemptive step scheduler ------------------------------------------------------------------------------------------------------
 // A launch ends with its last env, and which envs will be heavy in a step is only half predictable from the previous one: with the static

@@ -20,7 +20,7 @@
 #define PP_QCAP 48         // support queries per batch
 #define PP_MBOX 8          // manifold mailbox entries per hand-over batch
 #define PP_MVCAP 68        // moving list: the ship + two bodies per arbiter lane at most (65)
-#define PP_NBCAP 272       // body slots per env the half-wave image is laid out for (bp_load_scenarios enables pairing only below)
+#define PP_NBCAP 448       // body slots per env the half-wave image is laid out for (30 %: 272, 50 %: 360; bp_load_scenarios enables pairing only up to this)
 #define PP_CC 64           // candidate-cache entries: the first TWO candidate rounds of 32 (the mean env has 34 candidate slots)
 
 // LDS image of one half (byte offsets from the half's base).  Compile-time constants: the accesses fold them into the instruction's offset field.
@@ -35,7 +35,8 @@ enum : unsigned {
     PL_RSMA = PL_CCHW + 8u * PP_CC,              // res_smA .. res_jB contiguous: the AABB keys of the integrate phase ([32][4] u64) alias them
     PL_RSMB = PL_RSMA + 8u * 32, PL_RIA = PL_RSMB + 8u * 32, PL_RIB = PL_RIA + 4u * 32, PL_RJA = PL_RIB + 4u * 32, PL_RJB = PL_RJA + 4u * 32,
     PL_MVS = PL_RJB + 4u * 32,
-    PL_OWNER = PL_MVS + 4u * PP_NBCAP, PL_COLMASK = PL_OWNER + 2u * (PP_NSLOT + 4), PL_MVO = PL_COLMASK + 2u * (PP_NSLOT + 4),
+    PL_OWNER = PL_MVS + 2u * PP_NBCAP,           // mvs: 16-bit stamps relative to the task's first sub-step (at most 400 per step)
+    PL_COLMASK = PL_OWNER + 2u * (PP_NSLOT + 4), PL_MVO = PL_COLMASK + 2u * (PP_NSLOT + 4),
     PL_MV = PL_MVO + 4u * (PP_NSLOT + 2),
     PL_SLOTOF = PL_MV + 2u * PP_MVCAP,
     PL_RF = PL_SLOTOF + PP_NBCAP,
@@ -60,7 +61,7 @@ struct PW {
 };
 // per-half sub-step state kept in registers (the cold part lives in the half's LDS scalars)
 struct PState {
-    unsigned stamp;
+    unsigned stamp, stamp0;   // stamp0: the env's stamp when this task took it over ("moved in sub-step" marks in LDS are relative to it)
     int nmv, nslots, nlevels;
     unsigned prev_amask;
     int cc_ok, cc_kmax;
@@ -195,7 +196,8 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     const unsigned eo = W.eo, to = W.to;
     d2 *const Lsv = PLDS(d2, PL_SV), *const Lsw = PLDS(d2, PL_SW), *const Lsb = PLDS(d2, PL_SB), *const Lsp = PLDS(d2, PL_SP), *const Lag = PLDS(d2, PL_AG);
     unsigned char *const Lslot_of = PLDS(unsigned char, PL_SLOTOF), *const Lrf = PLDS(unsigned char, PL_RF);
-    unsigned *const Lmvs = PLDS(unsigned, PL_MVS), *const Lmvo = PLDS(unsigned, PL_MVO);
+    unsigned *const Lmvo = PLDS(unsigned, PL_MVO);
+    unsigned short *const Lmvs = PLDS(unsigned short, PL_MVS);
     unsigned short *const Lmv = PLDS(unsigned short, PL_MV), *const Lowner = PLDS(unsigned short, PL_OWNER), *const Lcolmask = PLDS(unsigned short, PL_COLMASK);
     d2 *const Ltf = PLDS(d2, PL_QDIR), *const Lq_dir = PLDS(d2, PL_QDIR), *const Lmbox = PLDS(d2, PL_QDIR), *const Lpt_thr = PLDS(d2, PL_PTTHR);
     double *const Lq_c = PLDS(double, PL_QC), *const Lr_val = PLDS(double, PL_RVAL), *const Lhs = PLDS(double, PL_HS);
@@ -208,6 +210,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
 
     S.stamp += 1u;
     const unsigned now = S.stamp;
+    const unsigned short nowr = (unsigned short)(now - S.stamp0);   // 1 .. 400: what the LDS marks of "moved in this sub-step" hold
     const double prev_dt = Lhs[0];
     lds_sync();
     if (hl == 0) Lhs[0] = dt;
@@ -244,7 +247,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             t.w = p.y - (ms.z * r.y + ms.w * r.x);
             Ltf[2 * hl] = mk2(t.x, t.y);
             Ltf[2 * hl + 1] = mk2(t.z, t.w);
-            Lmvs[i] = now;
+            Lmvs[i] = nowr;
         }
         const int cnt = min(32, S.nmv - k0);
         unsigned long long *bbk = Lres_smA; // [32][4] = min x, max x, min y, max y
@@ -331,7 +334,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             j = jr < W.nb ? jr : 0;
             hw = D.hint[(eo + i) * BP_KADJ + sc];
             valid = inlist && (s < adjn_i);
-            if (valid && Lmvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
+            if (valid && Lmvs[j] == nowr && j < i) valid = false; // pair is evaluated from j's list
             const int ki = D.sc_kind[to + i], kj = D.sc_kind[to + j];
             const double mi = D.sc_mass[to + i].x, mj = D.sc_mass[to + j].x;
             nA_h = D.sc_nv[to + min(i, j)]; nB_h = D.sc_nv[to + max(i, j)];
@@ -733,7 +736,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     // arbiters whose bodies did not move keep last sub-step's contacts
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
         const int a = (int)(A.key >> 16), b = (int)(A.key & 0xFFFFu);
-        if (Lmvs[a] != now && Lmvs[b] != now) A.stamp = now;
+        if (Lmvs[a] != nowr && Lmvs[b] != nowr) A.stamp = now;
     }
     // ---- 5. cpSpaceArbiterSetFilter ---------------------------------------------------------------------------
     if (A.key != ARB_FREE_KEY) {
@@ -1071,10 +1074,10 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
     const unsigned eo = W.eo, to = W.to;
     d2 *const Lsv = PLDS(d2, PL_SV), *const Lsw = PLDS(d2, PL_SW), *const Lsb = PLDS(d2, PL_SB), *const Lsp = PLDS(d2, PL_SP), *const Lag = PLDS(d2, PL_AG);
     unsigned char *const Lslot_of = PLDS(unsigned char, PL_SLOTOF);
-    unsigned *const Lmvs = PLDS(unsigned, PL_MVS), *const Lmvo = PLDS(unsigned, PL_MVO), *const Lkq = PLDS(unsigned, PL_KQ);
-    unsigned short *const Lmv = PLDS(unsigned short, PL_MV);
+    unsigned *const Lmvo = PLDS(unsigned, PL_MVO), *const Lkq = PLDS(unsigned, PL_KQ);
+    unsigned short *const Lmv = PLDS(unsigned short, PL_MV), *const Lmvs = PLDS(unsigned short, PL_MVS);
     double *const Lhs = PLDS(double, PL_HS);
-    for (int i = hl; i < PP_NBCAP; i += 32) { Lmvs[i] = 0u; Lslot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
+    for (int i = hl; i < PP_NBCAP; i += 32) { Lmvs[i] = 0; Lslot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     for (int i = hl; i < PP_NSLOT + 2; i += 32) Lmvo[i] = 0u;
     if (hl < P.nkin) { Lsv[hl] = D.velv[eo + hl]; Lsw[hl] = D.velw[eo + hl]; Lsb[hl] = D.velb[eo + hl]; Lsp[hl] = D.pxy[eo + hl]; }
     if (hl == 0) {
@@ -1118,7 +1121,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
         const double4 q1 = D.sc_prop[to + (A.key >> 16)], q2 = D.sc_prop[to + (A.key & 0xFFFFu)];
         A.e = q1.y * q2.y; A.u = q1.z * q2.z;
     }
-    S.stamp = D.e_stamp[env];
+    S.stamp = D.e_stamp[env]; S.stamp0 = S.stamp;
     S.total_ke = D.e_ke[env]; S.total_imp = D.e_imp[env];
     S.n_post = D.e_cnt[env * 4 + 0]; S.n_contact = D.e_cnt[env * 4 + 1]; S.n_first = D.e_cnt[env * 4 + 2];
     if (resumed) {
@@ -1242,7 +1245,6 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         pair_load_state(P, D, W, A, S, actions, resumed);
         if (!resumed && CAN_LEAVE) { unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap; for (int i = W.hl; i < nbcap; i += 32) mvd_[i] = 0; }
     }
-    const unsigned stamp_start = S.stamp;
     const int nsub = P.steps;
     bool running = have;
     while (__ballot(running)) {
@@ -1270,11 +1272,11 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
     }
     it_out = it;
     if (!have) return 0;
-    unsigned *const Lmvs = PLDS(unsigned, PL_MVS);
+    const unsigned short *const Lmvs = PLDS(unsigned short, PL_MVS);
     if (status == 2) {
         // ---- parked at a sub-step boundary: exactly the park of the preemptive scheduler (step-local flags and the shapes moved so far go along)
         unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap;
-        for (int i = W.hl; i < W.nb; i += 32) if (Lmvs[i] > stamp_start) mvd_[i] = 1;
+        for (int i = W.hl; i < W.nb; i += 32) if (Lmvs[i] != 0) mvd_[i] = 1;
         pair_gsync();
         pair_store_state(P, D, W, A, S);
         if (W.hl == 0) {
@@ -1291,7 +1293,7 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         double *const scr = PLDS(double, PL_QDIR);   // [32] contributions of a chunk of bodies
         for (int base = 0; base < W.nb; base += 32) {
             const int i = base + W.hl;
-            const bool mvd = (i < W.nb) && ((Lmvs[i] > stamp_start) || (resumed && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
+            const bool mvd = (i < W.nb) && ((Lmvs[i] != 0) || (resumed && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
                              (kind_ctype(D.sc_kind[W.to + i]) == 2);
             double contrib = 0.0;
             if (mvd) {

@@ -237,6 +237,11 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
  * behind, and resumed by another workgroup; results are identical), 0 = one wavefront per env for the whole step.  Default 40 for ship-ice and
  * maze handles of up to 8192 envs; environment variable BP_SCHED=<chunk> (0 = off) overrides it at load time. */
 int32_t bp_sched_chunk(bp_handle *h);
+/* Two environments per wavefront (ship-ice handles with space.damping == 0 and at most 272 body slots; lanes 0..31 one env, lanes 32..63 another, results
+ * identical): 0 = off, 1 = fixed pairs of the dispatch order for the whole step (test kernel), 2 = inside the step scheduler: the heaviest envs of the
+ * dispatch order start alone, the others in pairs, and an env that outgrows the half-wave capacities or turns heavy is parked at a sub-step boundary and
+ * resumed in a wavefront of its own.  Environment variable BP_PAIR=<mode> selects it at load time.  ABI 9. */
+int32_t bp_pair_mode(bp_handle *h);
 /* Clock calibration for bench.py: the shader-clock counter (s_memtime) and the 100 MHz reference counter (s_memrealtime) stamped on the device right
  * after every physics launch of bp_step / bp_reset (ship-ice and maze handles) by one thread, filed under the XCD it ran on (the shader-clock counters
  * of different XCDs are not synchronised): out[x][0..1] = the latest pair taken on XCD x, zeros if none yet.  The clock the chip held between two

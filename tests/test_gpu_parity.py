@@ -28,6 +28,8 @@ def _run_parity(E, conc, T, steps, seed, action_fn=None, **cfgkw):
     from benchpush_amd.envs.ship_ice import default_trials
     trials = default_trials(conc, T, base_seed=seed)
     env = _mk(E, conc, trials, **cfgkw)
+    import os
+    assert int(env.L.bp_pair_mode(env.h)) == int(os.environ.get("BP_PAIR", "0") or 0)   # a test that asks for the paired kernels must get them
     obs, info = env.reset()
     orcs = _oracles(env, E)
     eps = [0] * E
