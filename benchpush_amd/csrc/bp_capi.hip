@@ -326,6 +326,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         if (const char *evp = getenv("BP_PAIR")) { if (can_pair) h->pair_mode = atoi(evp); }
         if (h->pair_mode == 1) {
             h->P.pair_mode = 1;
+            if (const char *evs = getenv("BP_PAIR_SNAKE")) h->P.pair_solo = atoi(evs);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * PL_HALF)));
         }
         int ch = (h->num_envs <= 8192) ? 40 : 0;
@@ -347,13 +348,29 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_lev, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
-              h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn; }
+              h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn;
+              int *d_sub;
+              if ((rc = dalloc(h, &d_sub, (size_t)h->num_envs))) return rc;
+              h->D.sq_sub = d_sub; }
 #ifdef BP_DEBUG_PATHS   // fault injection lives in the diagnostic twin only: a stray variable in a job environment cannot disturb the product library
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
 #endif
+            if (h->pair_mode == 2) {
+                // two environments per wavefront inside the scheduler: who starts alone, and when a half leaves its pair (pair_should_leave)
+                auto envint = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
+                h->P.pair_mode = 2;
+                h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", h->num_envs / 16)));
+                h->P.pp_max_keys = std::min(30, envint("BP_PP_KEYS", 26));
+                h->P.pp_max_slots = std::min(PP_NSLOT - 4, envint("BP_PP_SLOTS", 34));
+                h->P.pp_max_mv = std::min(PP_MVCAP - 4, envint("BP_PP_MV", 40));
+                h->P.pp_max_act = envint("BP_PP_ACT", 12);
+                h->P.pp_max_work = envint("BP_PP_WORK", 16);
+                h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));
+            }
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         }
     }
+    if (h->pair_mode == 2 && h->P.pair_mode != 2) h->pair_mode = 0;   // pairing inside the scheduler needs the scheduler
     if (!settle) return BP_OK;
     h->maze8 = (h->P.env_kind == BP_ENV_MAZE);
     for (int v : h_nv) if (v > 8) h->maze8 = false;
@@ -376,7 +393,10 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_lev, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
-              h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn; }
+              h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn;
+              int *d_sub;
+              if ((rc = dalloc(h, &d_sub, (size_t)h->num_envs))) return rc;
+              h->D.sq_sub = d_sub; }
 #ifdef BP_DEBUG_PATHS
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
 #endif

@@ -254,7 +254,8 @@ __device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, co
 // lane 0: is some env behind one that has completed `lev` chunks?  Envs whose first chunk has not been dispatched yet are behind everybody.
 __device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevPtrs &D, const int x, const int lev)
 {
-    bool any = sq_ld(sq_started(D)) < P.num_envs;
+    // (with paired first tasks every first task fits the wave slots -- or, with a few solo starters, only the lightest pairs wait for one: nobody yields to them)
+    bool any = P.pair_mode != 2 && sq_ld(sq_started(D)) < P.num_envs;
     if (!any && sq_ld(sq_waiting(D, x)) > 0)
         for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
     return any;
@@ -285,6 +286,9 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
 #endif
     if (mode == MODE_RESET && !tmpl && mask != nullptr && mask[env] == 0) return true;
     const int nbcap = P.nbcap;
+    // CHUNKED: sub-steps of this step the env had completed when it was parked (0 = the step starts here).  A park of the scheduler leaves a multiple of
+    // P.sq_chunk; an env that left a paired wave (bp_physics_pair.hpp) any sub-step.  c_lev only ranks the env in the queues.
+    const int c_sub = CHUNKED ? D.sq_sub[env] : 0;
 
     // ---- carve LDS ----
     LdsCtx L;
@@ -389,13 +393,13 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         __syncthreads();
     } else {
         load_state_a<KIND>(P, D, E, L, A, S, env);
-        if (CHUNKED && c_lev > 0) {
+        if (CHUNKED && c_sub > 0) {
             const unsigned *cy = D.sq_carry + (size_t)env * 4;
             S.yaw_violated = (int)(cy[0] & 1u); S.boundary_violated = (int)(cy[1] & 1u); S.costp = cy[2];
             S.wall_flag = (int)((cy[0] >> 1) & 1u);
         }
         // ship control (ship_ice_env.py:265-274): set once per env step
-        if ((!CHUNKED || c_lev == 0) && lane < P.nkin) { // every part of the kinematic agent carries the same velocity
+        if ((!CHUNKED || c_sub == 0) && lane < P.nkin) { // every part of the kinematic agent carries the same velocity
             const double act = actions[env] * P.max_yaw_rate;
             const d2 r = E.rot[0];
             L.sv[lane] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
@@ -407,10 +411,11 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
 
     const unsigned stamp_start = S.stamp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
-    const int it_first = CHUNKED ? c_lev * P.sq_chunk : 0;
+    const int it_first = CHUNKED ? c_sub : 0;
+    int c_it_parked = 0;
     bool step_done = true;
     int to_boundary = CHUNKED ? P.sq_chunk : 0x7FFFFFFF;   // sub-steps until the next chunk boundary
-    if (CHUNKED && c_lev == 0) { // nothing has moved in this step yet
+    if (CHUNKED && c_sub == 0) { // nothing has moved in this step yet
         unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap;
         for (int i = lane; i < nbcap; i += 64) mvd_[i] = 0;
     }
@@ -422,7 +427,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             if (to_boundary == 0) { // chunk boundary: yield to an env that is further behind, otherwise carry on without a context switch
                 int yield = 0;
                 if (lane == 0 && !c_noyield) yield = (sq_someone_behind(P, D, c_x, it / P.sq_chunk) || (P.sq_debug && c_env == 1 && it == P.sq_chunk)) ? 1 : 0;
-                if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = it / P.sq_chunk; break; }
+                if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = it / P.sq_chunk; c_it_parked = it; break; }
                 to_boundary = P.sq_chunk;
             }
             to_boundary--;
@@ -481,7 +486,8 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
             unsigned *cy = D.sq_carry + (size_t)env * 4;
             cy[0] = (unsigned)S.yaw_violated | ((unsigned)S.wall_flag << 1); cy[1] = (unsigned)S.boundary_violated; cy[2] = S.costp;
-            cy[3] = (c_lev == 0 ? 0u : cy[3]) + (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
+            cy[3] = (c_sub == 0 ? 0u : cy[3]) + (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
+            D.sq_sub[env] = c_it_parked;
             if (err_c) atomicOr(&D.e_err[env], err_c);
         }
 #ifdef BP_PROF
@@ -499,7 +505,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         for (int base = 0; base < E.nb; base += 64) {
             const int i = base + lane;
             // shapes that did not move contribute exactly +0, so the test only saves work; across chunks the flag comes from D.sq_moved
-            const bool mvd = (i < E.nb) && ((L.mvs[i] > stamp_start) || (CHUNKED && c_lev > 0 && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
+            const bool mvd = (i < E.nb) && ((L.mvs[i] > stamp_start) || (CHUNKED && c_sub > 0 && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
                              (kind_ctype(E.kind[i]) == 2); // floes / boxes only
             double contrib = 0.0;
             if (mvd) {
@@ -551,7 +557,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         const d2 sp = E.pxy[0];
         const double sa = E.ang[0];
         D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
-        if (mode == MODE_STEP) D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + ((CHUNKED && c_lev > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
+        if (mode == MODE_STEP) D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + ((CHUNKED && c_sub > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
         D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
         D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
         if (err_any) atomicOr(&D.e_err[env], err_any);
@@ -657,13 +663,15 @@ __global__ __launch_bounds__(64, 2) void k_physics_step_pair(const DevParams P, 
                                                           double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
-    const int p0 = 2 * (int)blockIdx.x, p1 = p0 + 1;
+    // P.pair_solo != 0 (experiment switch of this test kernel): heaviest with lightest (positions b and N - 1 - b of the dispatch order) instead of neighbours
+    const int p0 = P.pair_solo ? (int)blockIdx.x : 2 * (int)blockIdx.x, p1 = P.pair_solo ? P.num_envs - 1 - (int)blockIdx.x : p0 + 1;
     const int e0 = D.order != nullptr ? D.order[p0] : p0;
-    const int e1 = p1 < P.num_envs ? (D.order != nullptr ? D.order[p1] : p1) : -1;
+    const int e1 = (p1 < P.num_envs && p1 != p0) ? (D.order != nullptr ? D.order[p1] : p1) : -1;
     PairLimits Q;
     Q.max_keys = Q.max_slots = Q.max_mv = Q.max_act = Q.max_work = 0x7FFFFFFF;
-    int it;
-    pair_task<false>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it);
+    Q.gc_slots = PP_NSLOT - 12;
+    int it, score;
+    pair_task<false>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it, score);
 }
 // ---- preemptive step scheduler ------------------------------------------------------------------------------------------------------
 // A launch ends with its last env, and which envs will be heavy in a step is only half predictable from the previous one: with the static
@@ -678,7 +686,7 @@ __global__ void k_sched_init(const DevParams P, const DevPtrs D)
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
     for (int i = tid; i < 8 * SQ_MAXLEV * P.sq_cap; i += nthr) D.sq_items[i] = -1;
     for (int i = tid; i < 8 * (SQ_MAXLEV + 2) * 2; i += nthr) D.sq_ctr[i] = 0;
-    for (int i = tid; i < P.num_envs; i += nthr) { D.sq_done[i] = 0; D.sq_lev[i] = 0; }
+    for (int i = tid; i < P.num_envs; i += nthr) { D.sq_done[i] = 0; D.sq_lev[i] = 0; D.sq_sub[i] = 0; }
 }
 // After the scheduled launch: the envs whose step is not complete (none, unless the scheduler's watchdog fired) are listed for the completion launch;
 // more than SQ_RESCUE of them is reported as BP_ERR_SCHED_TIMEOUT (the step is then incomplete).
@@ -711,6 +719,13 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     const int home = sq_xcc_id();
     int item = -1, lev = 0, x = home;
     const bool completion = P.sq_mode == 1;
+    // Two environments per wavefront (P.pair_mode == 2, ship-ice): the first P.pair_solo positions of the dispatch order (the envs that were heaviest in the
+    // previous step) start in a wavefront of their own, the others two to a wavefront, neighbours of the order together (similar envs share trip counts).
+    // With every env paired the 2 048 wave slots hold 4 096 envs from the first cycle.  A paired wave whose env turns heavy or outgrows the half-wave
+    // parks BOTH its envs at that sub-step boundary, hands the lighter one to the queues and carries on with the heavy one alone, in the same slot.
+    const bool pairing = KIND == BP_ENV_SHIP_ICE && P.pair_mode == 2 && !completion;
+    const int npairs = pairing ? (P.num_envs - P.pair_solo + 1) / 2 : 0;
+    const int nfirst = pairing ? P.pair_solo + npairs : P.num_envs;     // workgroups that start envs without touching a queue
     if (completion) {
         // Completion launch (always follows the scheduled one and k_sched_scan, SQ_RESCUE workgroups): workgroup b takes the b-th env of the list of
         // unfinished envs and leaves at once if the list is shorter -- the normal case: it is empty.  After a scheduler fault (watchdog) such an env's
@@ -718,7 +733,40 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         if ((int)blockIdx.x >= D.sq_rescue[0]) return;
         item = D.sq_rescue[1 + blockIdx.x]; lev = D.sq_lev[item];
         if (lane == 0) atomicAdd(&D.sq_warn[1], 1);
-    } else if ((int)blockIdx.x < P.num_envs) {
+    } else if (pairing && (int)blockIdx.x >= P.pair_solo && (int)blockIdx.x < nfirst) {
+        // ---- a paired first task ----
+        const int p0 = P.pair_solo + 2 * ((int)blockIdx.x - P.pair_solo), p1 = p0 + 1;
+        const int e0 = D.order != nullptr ? D.order[p0] : p0;
+        const int e1 = p1 < P.num_envs ? (D.order != nullptr ? D.order[p1] : p1) : -1;
+        if (lane == 0) atomicAdd(sq_started(D), e1 >= 0 ? 2 : 1);
+        PairLimits Q;
+        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work; Q.gc_slots = P.pp_max_slots - 6;
+        int it_half = 0, score_half = 0;
+        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it_half, score_half);
+        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
+        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
+        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
+        pair_gsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
+        if (lane == 0) {
+            if (st0 == 1) D.sq_done[e0] = 1;
+            if (st1 == 1) D.sq_done[e1] = 1;
+            if (nfin) atomicAdd(sq_finished(D), nfin);
+        }
+        if (st0 != 2 && st1 != 2) return;
+        // the env that carries on here: the heavier of the parked ones; the other goes to the queue of its level
+        const bool keep0 = st0 == 2 && (st1 != 2 || sc0 >= sc1);
+        const int cont = keep0 ? e0 : e1, cit = keep0 ? it0 : it1;
+        if (st0 == 2 && st1 == 2 && lane == 0) {
+            const int oth = keep0 ? e1 : e0, oit = keep0 ? it1 : it0;
+            D.sq_lev[oth] = oit / P.sq_chunk;
+            sq_push(P, D, home, oit / P.sq_chunk, oth);
+        }
+        item = cont | (3 << 24);   // top issue priority: it left its pair because it is heavy
+        lev = cit / P.sq_chunk;
+        __syncthreads();
+    } else if ((int)blockIdx.x < nfirst) {
         const int pos = (int)blockIdx.x;
         // issue-priority class of the env for the whole step: the heaviest quarter of the predicted order 3, the next quarter 1
         const int cls = (pos < P.num_envs / 4) ? 3 : (pos < P.num_envs / 2) ? 1 : 0;

@@ -49,6 +49,7 @@ enum : unsigned {
 static_assert(PL_END <= PL_HALF, "half-wave LDS image exceeds 10 240 bytes");
 static_assert(16u * 32 * 2 <= 16u * PP_QCAP + 8u * PP_QCAP, "the integrate transforms alias q_dir + q_c");
 static_assert(96u * PP_MBOX <= 16u * PP_QCAP, "the manifold mailbox aliases q_dir");
+static_assert(PP_NSLOT + 1 <= 64, "pair_compact_slots moves at most two slots per lane");
 static_assert(PP_NSLOT + 1 <= 255 && PP_MVCAP >= 66, "slot_of sentinel / moving-list bound");
 
 // What a lane knows about the half it serves.
@@ -1086,7 +1087,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
     }
     S.nslots = P.nkin;
     S.costp = 0u; S.cc_ok = 0; S.cc_kmax = 0; S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.err = 0;
-    S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0u; S.nlevels = 0; S.nkeys = 0; S.nact = 0; S.nwarm = 0;
+    S.yaw_violated = 0; S.boundary_violated = 0; S.prev_amask = 0u; S.nlevels = 0; S.nact = 0; S.nwarm = 0;
     A.level = 0; A.rank = 0; A.ma = A.ia = A.mb = A.ib = 0.0; A.e = 0.0; A.u = 0.0;
     // persisted arbiters: BP_ACAP = 64 entries per env, of which a half-wave holds 32 -- the live ones are compacted onto the lanes (which lane holds an
     // arbiter is free: pairs are matched by key and solved in (colour, key) order)
@@ -1101,6 +1102,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
         if (live && pos < 32) Lkq[pos] = (unsigned)idx;
         nlive += __popc(m);
     }
+    S.nkeys = nlive;
     if (nlive > 32) { S.err |= BP_ERR_ARB_OVERFLOW; nlive = 32; }
     lds_sync();
     A.key = ARB_FREE_KEY; A.stamp = 0; A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0;
@@ -1204,11 +1206,61 @@ __device__ __forceinline__ void pair_store_state(const DevParams &P, const DevPt
     }
 }
 
+// Velocity slots are handed out on first use and never returned within a task, and a half has 40 of them instead of 96: over the 400 sub-steps of a
+// step the ship touches more bodies than that.  A slot whose body has no arbiter lane (its pair has aged out) and an all-zero velocity is exactly "no
+// slot" -- that is how a parked env comes back (load_state_b hands slots to bodies with a velocity or an arbiter) -- so such slots are dropped and the
+// rest moved down in order.  Called between sub-steps, by the halves that need it.
+__device__ __forceinline__ void pair_compact_slots(const DevParams &P, const PW &W, ArbReg &A, PState &S)
+{
+    const int hl = W.hl, h = W.h;
+    d2 *const Lsv = PLDS(d2, PL_SV), *const Lsw = PLDS(d2, PL_SW), *const Lsb = PLDS(d2, PL_SB), *const Lsp = PLDS(d2, PL_SP);
+    unsigned char *const Lslot_of = PLDS(unsigned char, PL_SLOTOF);
+    unsigned *const Lmvo = PLDS(unsigned, PL_MVO);
+    unsigned short *const keep = PLDS(unsigned short, PL_OWNER), *const remap = PLDS(unsigned short, PL_COLMASK);   // both are scratch between sub-steps
+    const int n = S.nslots;
+    lds_sync();
+    for (int s = hl; s < n; s += 32) {
+        const d2 v = Lsv[s], w2 = Lsw[s], vb = Lsb[s];
+        keep[s] = (s < P.nkin || v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0) ? 1 : 0;
+    }
+    lds_sync();
+    if (A.key != ARB_FREE_KEY) { keep[A.slotA] = 1; keep[A.slotB] = 1; }
+    lds_sync();
+    int base = 0;
+    for (int s0 = 0; s0 < n; s0 += 32) {
+        const int s = s0 + hl;
+        const bool k = s < n && keep[s] != 0;
+        const unsigned m = hballot(k, h);
+        if (s < n) remap[s] = k ? (unsigned short)(base + popc_below32(m, hl)) : (unsigned short)0xFFFF;
+        base += __popc(m);
+    }
+    lds_sync();
+    {   // every kept slot is read before any is written: a slot moves down onto an index that may still hold another kept slot's data
+        const int s0 = hl, s1 = hl + 32;
+        const bool k0 = s0 < n && remap[s0] != 0xFFFF, k1 = s1 < n && remap[s1] != 0xFFFF;
+        d2 a0 = mk2(0, 0), b0 = a0, c0 = a0, d0 = a0, a1 = a0, b1 = a0, c1 = a0, d1 = a0;
+        unsigned m0 = 0, m1 = 0;
+        if (k0) { a0 = Lsv[s0]; b0 = Lsw[s0]; c0 = Lsb[s0]; d0 = Lsp[s0]; m0 = Lmvo[s0]; }
+        if (k1) { a1 = Lsv[s1]; b1 = Lsw[s1]; c1 = Lsb[s1]; d1 = Lsp[s1]; m1 = Lmvo[s1]; }
+        lds_sync();
+        if (k0) { const int r = remap[s0]; Lsv[r] = a0; Lsw[r] = b0; Lsb[r] = c0; Lsp[r] = d0; Lmvo[r] = m0; }
+        if (k1) { const int r = remap[s1]; Lsv[r] = a1; Lsw[r] = b1; Lsb[r] = c1; Lsp[r] = d1; Lmvo[r] = m1; }
+    }
+    lds_sync();
+    for (int i = hl; i < W.nb; i += 32) {
+        const int sl = Lslot_of[i];
+        if (sl != 255) { const unsigned r = remap[sl]; Lslot_of[i] = (r == 0xFFFFu) ? (unsigned char)255 : (unsigned char)r; }
+    }
+    if (A.key != ARB_FREE_KEY) { A.slotA = remap[A.slotA]; A.slotB = remap[A.slotB]; }
+    S.nslots = base;
+    lds_sync();
+}
+
 // When does a half leave the pair?  Capacity first: the half-wave image holds 32 arbiter lanes, PP_NSLOT velocity slots and a moving list of PP_MVCAP; an env
 // that approaches them is parked at the sub-step boundary (the margins are what one sub-step can add at most in practice, and a capacity that is hit
 // anyway raises the same per-env error bits as in the solo kernel).  Heaviness second: an env with many active arbiters and colours sets the pace of the
 // wave for its mate and would itself run faster alone.
-struct PairLimits { int max_keys, max_slots, max_mv, max_act, max_work; };
+struct PairLimits { int max_keys, max_slots, max_mv, max_act, max_work, gc_slots; };   // gc_slots: pair_compact_slots runs above this many slots in use
 __device__ __forceinline__ bool pair_should_leave(const PState &S, const PairLimits &Q)
 {
     return S.nkeys > Q.max_keys || S.nslots > Q.max_slots || S.nmv > Q.max_mv || S.nact > Q.max_act || S.nwarm * S.nlevels > Q.max_work;
@@ -1219,7 +1271,7 @@ __device__ __forceinline__ bool pair_should_leave(const PState &S, const PairLim
 template <bool CAN_LEAVE>
 __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions, double *__restrict__ reward,
                                          unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated, double *__restrict__ info,
-                                         const int env0, const int env1, const PairLimits Q, int &it_out)
+                                         const int env0, const int env1, const PairLimits Q, int &it_out, int &score_out)
 {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = (int)(threadIdx.x & 63);
@@ -1241,9 +1293,18 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
     PState S;
     int status = 0;
     int it = it_first;
-    if (have) {
-        pair_load_state(P, D, W, A, S, actions, resumed);
-        if (!resumed && CAN_LEAVE) { unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap; for (int i = W.hl; i < nbcap; i += 32) mvd_[i] = 0; }
+    if (have) pair_load_state(P, D, W, A, S, actions, resumed);
+    // An env that does not fit the half-wave as it stands (arbiter lanes, velocity slots or moving list above the leave limits: a heavy env that the
+    // dispatch order took for a light one) is declined before anything has been written: its state is untouched, and so is its mate's -- the wave hands
+    // both back (status 2, `it` where they were) and sched_body carries on with the heavier one alone.
+    if (CAN_LEAVE) {
+        const bool declined = have && (S.err != 0 || S.nkeys > Q.max_keys || S.nslots > Q.max_slots || S.nmv > Q.max_mv);
+        if (__ballot(declined) != 0ull) {
+            it_out = it;
+            score_out = have ? S.nkeys * 64 + S.nmv : 0;
+            return have ? 2 : 0;
+        }
+        if (have && !resumed) { unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap; for (int i = W.hl; i < nbcap; i += 32) mvd_[i] = 0; }
     }
     const int nsub = P.steps;
     bool running = have;
@@ -1267,10 +1328,14 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
                 it = nsub;
             }
             if (it >= nsub) { running = false; status = 1; }
-            else if (CAN_LEAVE && pair_should_leave(S, Q)) { running = false; status = 2; }
+            else if (S.nslots > Q.gc_slots) pair_compact_slots(P, W, A, S);   // slots leak over a step: drop the ones nobody needs any more
         }
+        // a half that must leave takes its mate along: the wave carries on with one of them alone (sched_body), the other waits in a queue -- an env that is
+        // heavy must not wait for its mate to finish, nor run on in half a wavefront
+        if (CAN_LEAVE && __ballot(running && pair_should_leave(S, Q)) != 0ull && running) { running = false; status = 2; }
     }
     it_out = it;
+    score_out = have ? (int)min(S.costp / (unsigned)max(it - it_first, 1), 0x7FFFFFFFu) : 0;   // mean work proxy per sub-step of this task: which of two parked envs is the heavier
     if (!have) return 0;
     const unsigned short *const Lmvs = PLDS(unsigned short, PL_MVS);
     if (status == 2) {

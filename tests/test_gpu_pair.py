@@ -21,7 +21,7 @@ def test_fixed_pairs_match_the_oracle_30pct(monkeypatch):
 def test_fixed_pairs_match_the_oracle_50pct_and_ragged_last_wave(monkeypatch):
     """50 % concentration (more arbiters, colours and moving bodies per half) and an odd env count: the last wave carries one env and an idle half."""
     monkeypatch.setenv("BP_PAIR", "1")
-    assert _run_parity(E=7, conc=0.5, T=2, steps=10, seed=21) > 100   # (step 11 of env 3 outgrows the half-wave: fixed pairs cannot leave, the scheduler path can)
+    assert _run_parity(E=7, conc=0.5, T=2, steps=10, seed=21) > 100   # (beyond step 11 env 3 outgrows the 32 arbiter lanes of a half: fixed pairs cannot leave, the scheduler path can)
     assert _run_parity(E=5, conc=0.1, T=2, steps=20, seed=3) >= 0
 
 
@@ -33,7 +33,7 @@ def test_fixed_pairs_boundary_and_yaw_edges(monkeypatch):
 
 def _run_batch(E, steps, conc, env_vars, monkeypatch, trials):
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
-    for k in ("BP_PAIR", "BP_SCHED"):
+    for k in ("BP_PAIR", "BP_SCHED", "BP_PP_ACT", "BP_PP_WORK", "BP_PAIR_SOLO", "BP_PP_KEYS", "BP_PP_SLOTS", "BP_PP_MV"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env_vars.items():
         monkeypatch.setenv(k, v)
@@ -71,3 +71,33 @@ def test_fixed_pairs_equal_the_solo_kernel_on_512_envs(monkeypatch):
     assert ref[5] == got[5] and ref[5] > 100
     for a, b in zip(ref[:5], got[:5]):
         assert torch.equal(a, b)
+
+
+def test_pairs_inside_the_scheduler_match_the_oracle(monkeypatch):
+    """BP_PAIR=2, the product path: paired first tasks, envs leaving their pair at a sub-step boundary (tight limits force it within every step), the
+    heavier one carrying on alone in the same wavefront, the other resumed from the queues by another workgroup -- bit-identical to the oracle."""
+    monkeypatch.setenv("BP_PAIR", "2")
+    monkeypatch.setenv("BP_PAIR_SOLO", "2")
+    assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
+    monkeypatch.setenv("BP_PP_ACT", "3")        # leave as soon as four arbiters are active: every pair splits, at arbitrary sub-steps
+    monkeypatch.setenv("BP_PP_WORK", "2")
+    monkeypatch.setenv("BP_PAIR_SOLO", "0")
+    assert _run_parity(E=8, conc=0.3, T=3, steps=25, seed=0) > 500
+    monkeypatch.setenv("BP_PP_ACT", "12")
+    monkeypatch.setenv("BP_PP_WORK", "16")
+    assert _run_parity(E=7, conc=0.5, T=2, steps=14, seed=21) > 100   # 50 %: the env that outgrows the half-wave at step 11 leaves its pair instead of overflowing
+
+
+def test_pairs_inside_the_scheduler_equal_the_solo_kernel_at_full_size(monkeypatch):
+    """4096 envs x 40 steps with auto-reset: the product path (BP_PAIR=2) and the same with limits that split most pairs against one wavefront per env
+    (BP_SCHED=0): body state, summed rewards, observations, info, episode metrics torch.equal; no capacity flag, no scheduler warning."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    trials = default_trials(0.3, 48, base_seed=1)
+    ref = _run_batch(4096, 40, 0.3, {"BP_SCHED": "0"}, monkeypatch, trials)
+    assert ref[6] is None and ref[5] > 500
+    for variant in ({"BP_PAIR": "2"}, {"BP_PAIR": "2", "BP_PP_ACT": "6", "BP_PP_WORK": "6", "BP_PAIR_SOLO": "1000"}):
+        got = _run_batch(4096, 40, 0.3, variant, monkeypatch, trials)
+        assert got[6] is None, got[6]
+        assert got[5] == ref[5]
+        for a, b in zip(ref[:5], got[:5]):
+            assert torch.equal(a, b), variant
