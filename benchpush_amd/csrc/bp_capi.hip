@@ -336,8 +336,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch;
             h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
-            if ((rc = dalloc(h, &d_items, (size_t)8 * SQ_MAXLEV * h->P.sq_cap))) return rc;
-            if ((rc = dalloc(h, &d_ctr, (size_t)8 * (SQ_MAXLEV + 2) * 2))) return rc;
+            if ((rc = dalloc(h, &d_items, (size_t)SQ_NX * SQ_MAXLEV * h->P.sq_cap))) return rc;
+            if ((rc = dalloc(h, &d_ctr, (size_t)SQ_NX * (SQ_MAXLEV + 2) * 2))) return rc;
             if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;
@@ -365,6 +365,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 h->P.pp_max_mv = std::min(PP_MVCAP - 4, envint("BP_PP_MV", 40));
                 h->P.pp_max_act = envint("BP_PP_ACT", 12);
                 h->P.pp_max_work = envint("BP_PP_WORK", 16);
+                h->P.pp_rate = envint("BP_PP_RATE", 100);
                 h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));
             }
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -381,8 +382,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch; h->P.sq_cap = h->num_envs;
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
-            if ((rc = dalloc(h, &d_items, (size_t)8 * SQ_MAXLEV * h->P.sq_cap))) return rc;
-            if ((rc = dalloc(h, &d_ctr, (size_t)8 * (SQ_MAXLEV + 2) * 2))) return rc;
+            if ((rc = dalloc(h, &d_items, (size_t)SQ_NX * SQ_MAXLEV * h->P.sq_cap))) return rc;
+            if ((rc = dalloc(h, &d_ctr, (size_t)SQ_NX * (SQ_MAXLEV + 2) * 2))) return rc;
             if ((rc = dalloc(h, &d_carry, (size_t)h->num_envs * 4))) return rc;
             if ((rc = dalloc(h, &d_moved, (size_t)h->num_envs * nbcap))) return rc;
             h->D.sq_items = d_items; h->D.sq_ctr = d_ctr; h->D.sq_carry = d_carry; h->D.sq_moved = d_moved;

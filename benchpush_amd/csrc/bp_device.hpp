@@ -41,6 +41,7 @@ struct DevParams {
     // 2 inside the preemptive scheduler (the pair_solo heaviest envs of the dispatch order start alone, the others in pairs)
     int pair_mode, pair_solo;
     int pp_max_keys, pp_max_slots, pp_max_mv, pp_max_act, pp_max_work;   // when a half leaves its pair (pair_should_leave)
+    int pp_rate;                               // an env whose mean work proxy per sub-step (S.costp) is above this is parked as heavy: it carries on alone
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
     double start_x_range, ship_mass;
     unsigned long long start_seed;
@@ -70,8 +71,8 @@ struct DevPtrs {
     unsigned *e_cost;        // [E] wave cycles (>>8) the env's last step took: dispatch-order hint only
     const int *order;        // [E] env handled by workgroup b (heaviest first), or null = identity
     // preemptive step scheduler (k_physics_step_sched): per XCD and level (= chunks of the step already done) a queue of waiting envs
-    int *sq_items;           // [8][SQ_MAXLEV][sq_cap] env ids, -1 = not yet written
-    int *sq_ctr;             // [8][SQ_MAXLEV + 2][2]: (head, tail) per level; row SQ_MAXLEV = (finished, total) of the XCD
+    int *sq_items;           // [16][SQ_MAXLEV][sq_cap] env ids, -1 = not yet written (rows 0..7: XCD x, envs that run alone; 8..15: XCD x - 8, envs that were light when parked)
+    int *sq_ctr;             // [16][SQ_MAXLEV + 2][2]: (head, tail) per level; row SQ_MAXLEV = (finished, total) of the XCD
     unsigned *sq_carry;      // [E][4] step-local state across chunks: yaw_violated, boundary_violated, work proxy, wave cycles >> 8
     unsigned char *sq_moved; // [E][nbcap] shape moved in an earlier chunk of this step
     int *sq_done;            // [E] the env's step is complete (cleared by k_sched_init)

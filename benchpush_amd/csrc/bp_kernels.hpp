@@ -223,41 +223,52 @@ __device__ __forceinline__ int *sq_finished(const DevPtrs &D) { return sq_row(D,
 __device__ __forceinline__ int *sq_started(const DevPtrs &D) { return sq_row(D, 0, SQ_MAXLEV + 1) + 1; }
 __device__ __forceinline__ int *sq_waiting(const DevPtrs &D, const int x) { return sq_row(D, x, SQ_MAXLEV); }
 __device__ __forceinline__ int *sq_abort(const DevPtrs &D) { return sq_row(D, 1, SQ_MAXLEV + 1); }   // set by the watchdog: every poller leaves
-// lane 0: take the waiting env of XCD x that has completed the fewest chunks; -1 = nothing waiting
-__device__ __forceinline__ int sq_pop(const DevParams &P, const DevPtrs &D, const int x, int &lev)
+// Queue rows: SQ_NX = 16 = 8 XCDs x 2 kinds.  Kind 0 (rows 0..7) holds envs that run in a wavefront of their own, kind 1 (rows 8..15, used with
+// P.pair_mode == 2) envs that were light when they were parked: a workgroup that takes one of those takes a second one along and runs the two in one wavefront.
+#define SQ_NX 16
+// lane 0: take a waiting env of row xk that has completed exactly l chunks; -1 = none
+__device__ __forceinline__ int sq_pop_level(const DevParams &P, const DevPtrs &D, const int xk, const int l)
 {
-    if (sq_ld(sq_waiting(D, x)) <= 0) return -1;
-    for (int l = 0; l < P.sq_levels; l++) {
-        int *ctr = sq_row(D, x, l);
-        int h = sq_ld(ctr);
-        while (h < sq_ld(ctr + 1)) {
-            const int got = atomicCAS(ctr, h, h + 1);
-            if (got == h) {
-                const int *slot = D.sq_items + ((size_t)x * SQ_MAXLEV + l) * P.sq_cap + h;
-                int e;
-                while ((e = sq_ld(slot)) < 0) __builtin_amdgcn_s_sleep(1); // the pusher has taken the index, the id is on its way
-                atomicSub(sq_waiting(D, x), 1);
-                lev = l;
-                return e;
-            }
-            h = got;
+    int *ctr = sq_row(D, xk, l);
+    int h = sq_ld(ctr);
+    while (h < sq_ld(ctr + 1)) {
+        const int got = atomicCAS(ctr, h, h + 1);
+        if (got == h) {
+            const int *slot = D.sq_items + ((size_t)xk * SQ_MAXLEV + l) * P.sq_cap + h;
+            int e;
+            while ((e = sq_ld(slot)) < 0) __builtin_amdgcn_s_sleep(1); // the pusher has taken the index, the id is on its way
+            atomicSub(sq_waiting(D, xk), 1);
+            return e;
         }
+        h = got;
     }
     return -1;
 }
-__device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, const int x, const int lev, const int item)
+// lane 0: take the waiting env of XCD x that has completed the fewest chunks (either kind; kind 0 first on a tie); -1 = nothing waiting
+__device__ __forceinline__ int sq_pop(const DevParams &P, const DevPtrs &D, const int x, int &lev, int &kind)
 {
-    const int idx = atomicAdd(sq_row(D, x, lev) + 1, 1);
-    __hip_atomic_store(D.sq_items + ((size_t)x * SQ_MAXLEV + lev) * P.sq_cap + idx, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    atomicAdd(sq_waiting(D, x), 1);
+    const bool any0 = sq_ld(sq_waiting(D, x)) > 0, any1 = P.pair_mode == 2 && sq_ld(sq_waiting(D, x + 8)) > 0;
+    if (!any0 && !any1) return -1;
+    for (int l = 0; l < P.sq_levels; l++) {
+        if (any0) { const int e = sq_pop_level(P, D, x, l); if (e >= 0) { lev = l; kind = 0; return e; } }
+        if (any1) { const int e = sq_pop_level(P, D, x + 8, l); if (e >= 0) { lev = l; kind = 1; return e; } }
+    }
+    return -1;
+}
+__device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, const int xk, const int lev, const int item)
+{
+    const int idx = atomicAdd(sq_row(D, xk, lev) + 1, 1);
+    __hip_atomic_store(D.sq_items + ((size_t)xk * SQ_MAXLEV + lev) * P.sq_cap + idx, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicAdd(sq_waiting(D, xk), 1);
 }
 // lane 0: is some env behind one that has completed `lev` chunks?  Envs whose first chunk has not been dispatched yet are behind everybody.
 __device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevPtrs &D, const int x, const int lev)
 {
-    // (with paired first tasks every first task fits the wave slots -- or, with a few solo starters, only the lightest pairs wait for one: nobody yields to them)
-    bool any = P.pair_mode != 2 && sq_ld(sq_started(D)) < P.num_envs;
+    bool any = sq_ld(sq_started(D)) < P.num_envs;
     if (!any && sq_ld(sq_waiting(D, x)) > 0)
         for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
+    if (!any && P.pair_mode == 2 && sq_ld(sq_waiting(D, x + 8)) > 0)
+        for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x + 8, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
     return any;
 }
 // CHUNKED (k_physics_step_sched): the call resumes env `c_env`'s step after `c_lev` chunks of P.sq_chunk sub-steps and runs until the step is complete
@@ -269,7 +280,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
                                              double *__restrict__ info, const int tmpl, const int boff = 0, const int c_env = 0, const int c_lev = 0,
-                                             const int c_x = 0, int *c_lev_out = nullptr, const bool c_noyield = false)
+                                             const int c_x = 0, int *c_lev_out = nullptr, const bool c_noyield = false, int *c_light_out = nullptr)
 {
     // MODE_RESET with tmpl != 0 settles the per-trial reset templates: state slot num_envs + t holds trial t
     // MODE_STEP: workgroup b steps the env at position boff + b of the dispatch order
@@ -410,6 +421,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     }
 
     const unsigned stamp_start = S.stamp;
+    const unsigned costp_resume = S.costp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     const int it_first = CHUNKED ? c_sub : 0;
     int c_it_parked = 0;
@@ -477,6 +489,13 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         for (int i = lane; i < E.nb; i += 64) if (L.mvs[i] > stamp_start) mvd_[i] = 1;
         __syncthreads();
         store_state(P, D, L, A, env);
+        if (KIND == BP_ENV_SHIP_ICE && P.pair_mode == 2 && c_light_out != nullptr) {
+            // is the env light enough to carry on in half a wavefront (bp_physics_pair.hpp)?  Arbiter lanes and moving bodies well inside the half-wave, and
+            // a mean work proxy per sub-step of this run below the pairing limit
+            const int keys = __popcll(ballot(A.key != ARB_FREE_KEY)), act = __popcll(S.prev_amask);
+            const unsigned rate = (S.costp - costp_resume) / (unsigned)max(c_it_parked - it_first, 1);
+            *c_light_out = (keys <= P.pp_max_keys - 6 && S.nmv <= P.pp_max_mv / 2 && act <= P.pp_max_act && rate <= (unsigned)P.pp_rate) ? 1 : 0;
+        }
         const int err_c = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) |
                           (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
                           (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
@@ -669,9 +688,9 @@ __global__ __launch_bounds__(64, 2) void k_physics_step_pair(const DevParams P, 
     const int e1 = (p1 < P.num_envs && p1 != p0) ? (D.order != nullptr ? D.order[p1] : p1) : -1;
     PairLimits Q;
     Q.max_keys = Q.max_slots = Q.max_mv = Q.max_act = Q.max_work = 0x7FFFFFFF;
-    Q.gc_slots = PP_NSLOT - 12;
-    int it, score;
-    pair_task<false>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it, score);
+    Q.gc_slots = PP_NSLOT - 12; Q.max_rate = 0x7FFFFFFF;
+    int it, score, heavy;
+    pair_task<false>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it, score, heavy, [](const int) { return false; });
 }
 // ---- preemptive step scheduler ------------------------------------------------------------------------------------------------------
 // A launch ends with its last env, and which envs will be heavy in a step is only half predictable from the previous one: with the static
@@ -684,8 +703,8 @@ __global__ __launch_bounds__(64, 2) void k_physics_step_pair(const DevParams P, 
 __global__ void k_sched_init(const DevParams P, const DevPtrs D)
 {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nthr = gridDim.x * blockDim.x;
-    for (int i = tid; i < 8 * SQ_MAXLEV * P.sq_cap; i += nthr) D.sq_items[i] = -1;
-    for (int i = tid; i < 8 * (SQ_MAXLEV + 2) * 2; i += nthr) D.sq_ctr[i] = 0;
+    for (int i = tid; i < SQ_NX * SQ_MAXLEV * P.sq_cap; i += nthr) D.sq_items[i] = -1;
+    for (int i = tid; i < SQ_NX * (SQ_MAXLEV + 2) * 2; i += nthr) D.sq_ctr[i] = 0;
     for (int i = tid; i < P.num_envs; i += nthr) { D.sq_done[i] = 0; D.sq_lev[i] = 0; D.sq_sub[i] = 0; }
 }
 // After the scheduled launch: the envs whose step is not complete (none, unless the scheduler's watchdog fired) are listed for the completion launch;
@@ -718,11 +737,14 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     const int lane = lane_id();
     const int home = sq_xcc_id();
     int item = -1, lev = 0, x = home;
+    int pe0 = -1, pe1 = -1;          // a paired task: two envs for one wavefront
     const bool completion = P.sq_mode == 1;
-    // Two environments per wavefront (P.pair_mode == 2, ship-ice): the first P.pair_solo positions of the dispatch order (the envs that were heaviest in the
-    // previous step) start in a wavefront of their own, the others two to a wavefront, neighbours of the order together (similar envs share trip counts).
-    // With every env paired the 2 048 wave slots hold 4 096 envs from the first cycle.  A paired wave whose env turns heavy or outgrows the half-wave
-    // parks BOTH its envs at that sub-step boundary, hands the lighter one to the queues and carries on with the heavy one alone, in the same slot.
+    // Two environments per wavefront (P.pair_mode == 2, ship-ice).  Light envs advance two to a wavefront, heavy ones alone, and an env changes sides
+    // at any boundary: the first P.pair_solo positions of the dispatch order start alone, the others in pairs (neighbours of the order: similar envs share
+    // trip counts) -- with every env paired the 2 048 wave slots hold 4 096 envs from the first cycle; a paired wave whose env turns heavy (or outgrows the
+    // half-wave) parks both envs at that sub-step boundary, carries on with the heavy one alone in the same slot and queues its mate; paired and solo waves
+    // alike yield at chunk boundaries to envs that are further behind; and an env that is light when it is parked waits in a queue of its own kind, from
+    // which a starting workgroup takes two at a time.
     const bool pairing = KIND == BP_ENV_SHIP_ICE && P.pair_mode == 2 && !completion;
     const int npairs = pairing ? (P.num_envs - P.pair_solo + 1) / 2 : 0;
     const int nfirst = pairing ? P.pair_solo + npairs : P.num_envs;     // workgroups that start envs without touching a queue
@@ -734,38 +756,10 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         item = D.sq_rescue[1 + blockIdx.x]; lev = D.sq_lev[item];
         if (lane == 0) atomicAdd(&D.sq_warn[1], 1);
     } else if (pairing && (int)blockIdx.x >= P.pair_solo && (int)blockIdx.x < nfirst) {
-        // ---- a paired first task ----
         const int p0 = P.pair_solo + 2 * ((int)blockIdx.x - P.pair_solo), p1 = p0 + 1;
-        const int e0 = D.order != nullptr ? D.order[p0] : p0;
-        const int e1 = p1 < P.num_envs ? (D.order != nullptr ? D.order[p1] : p1) : -1;
-        if (lane == 0) atomicAdd(sq_started(D), e1 >= 0 ? 2 : 1);
-        PairLimits Q;
-        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work; Q.gc_slots = P.pp_max_slots - 6;
-        int it_half = 0, score_half = 0;
-        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, e0, e1, Q, it_half, score_half);
-        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
-        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
-        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
-        pair_gsync();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
-        if (lane == 0) {
-            if (st0 == 1) D.sq_done[e0] = 1;
-            if (st1 == 1) D.sq_done[e1] = 1;
-            if (nfin) atomicAdd(sq_finished(D), nfin);
-        }
-        if (st0 != 2 && st1 != 2) return;
-        // the env that carries on here: the heavier of the parked ones; the other goes to the queue of its level
-        const bool keep0 = st0 == 2 && (st1 != 2 || sc0 >= sc1);
-        const int cont = keep0 ? e0 : e1, cit = keep0 ? it0 : it1;
-        if (st0 == 2 && st1 == 2 && lane == 0) {
-            const int oth = keep0 ? e1 : e0, oit = keep0 ? it1 : it0;
-            D.sq_lev[oth] = oit / P.sq_chunk;
-            sq_push(P, D, home, oit / P.sq_chunk, oth);
-        }
-        item = cont | (3 << 24);   // top issue priority: it left its pair because it is heavy
-        lev = cit / P.sq_chunk;
-        __syncthreads();
+        pe0 = D.order != nullptr ? D.order[p0] : p0;
+        pe1 = p1 < P.num_envs ? (D.order != nullptr ? D.order[p1] : p1) : -1;
+        if (lane == 0) atomicAdd(sq_started(D), pe1 >= 0 ? 2 : 1);
     } else if ((int)blockIdx.x < nfirst) {
         const int pos = (int)blockIdx.x;
         // issue-priority class of the env for the whole step: the heaviest quarter of the predicted order 3, the next quarter 1
@@ -773,35 +767,80 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         item = (D.order != nullptr ? D.order[pos] : pos) | (cls << 24);
         if (lane == 0) atomicAdd(sq_started(D), 1);
     } else {
+        int kind = 0, mate = -1;
         if (lane == 0) {
             const int limit = P.sq_debug ? 64 : (1 << 20);
             for (int idle = 0;; idle++) {
-                item = sq_pop(P, D, home, lev);
+                item = sq_pop(P, D, home, lev, kind);
                 if (item < 0 && (idle & 3) == 3)
-                    for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev); if (item >= 0) x = y; }
+                    for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev, kind); if (item >= 0) x = y; }
                 if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs || sq_ld(sq_abort(D)) != 0) break;
                 // watchdog: ~20 s of empty polls can only mean a scheduler fault -- raise the abort flag (every poller leaves on it) and leave rather
                 // than hold the GPU; the completion launch finishes the envs that are still parked
                 if (idle > limit) { if (atomicExch(sq_abort(D), 1) == 0) atomicAdd(&D.sq_warn[0], 1); break; }
                 for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
             }
+            // a light env takes a second light one of the same XCD along: the least advanced that waits, from its own level upwards
+            if (item >= 0 && kind == 1 && sq_ld(sq_waiting(D, x + 8)) > 0)
+                for (int l = lev; l < P.sq_levels && mate < 0; l++) mate = sq_pop_level(P, D, x + 8, l);
         }
         item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
+        mate = __builtin_amdgcn_readfirstlane(mate);
         if (item < 0) return;
+        if (mate >= 0) { pe0 = item & 0xFFFFFF; pe1 = mate & 0xFFFFFF; item = -1; }
+    }
+    if (pe0 >= 0) {
+        // ---- a paired task ----
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the envs' arrays as the waves that parked them left them
+        PairLimits Q;
+        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work;
+        Q.gc_slots = P.pp_max_slots - 6; Q.max_rate = P.pp_rate;
+        int it_half = 0, score_half = 0, heavy_half = 0;
+        auto behind = [&](const int level) -> bool {
+            int y = 0;
+            if (lane == 0) y = sq_someone_behind(P, D, x, level) ? 1 : 0;
+            return __builtin_amdgcn_readfirstlane(y) != 0;
+        };
+        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, Q, it_half, score_half, heavy_half, behind);
+        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
+        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
+        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
+        const int hv0 = __builtin_amdgcn_readlane(heavy_half, 0), hv1 = __builtin_amdgcn_readlane(heavy_half, 32);
+        pair_gsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
+        if (lane == 0) {
+            if (st0 == 1) D.sq_done[pe0] = 1;
+            if (st1 == 1) D.sq_done[pe1] = 1;
+            if (nfin) atomicAdd(sq_finished(D), nfin);
+        }
+        const bool pk0 = st0 == 2, pk1 = st1 == 2;
+        if (!pk0 && !pk1) return;
+        // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
+        const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
+        if (lane == 0) {
+            if (pk0 && !c0) { D.sq_lev[pe0] = it0 / P.sq_chunk; sq_push(P, D, x + (hv0 ? 0 : 8), it0 / P.sq_chunk, pe0); }
+            if (pk1 && !c1) { D.sq_lev[pe1] = it1 / P.sq_chunk; sq_push(P, D, x + (hv1 ? 0 : 8), it1 / P.sq_chunk, pe1); }
+        }
+        if (!c0 && !c1) return;
+        item = (c0 ? pe0 : pe1) | (3 << 24);   // top issue priority: it left its pair because it is heavy
+        lev = (c0 ? it0 : it1) / P.sq_chunk;
+        __syncthreads();
     }
     const int env = item & 0xFFFFFF;
     if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
     else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
-    int lev_out = lev + 1;
-    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, completion);
+    int lev_out = lev + 1, light_out = 0;
+    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, completion,
+                                                          &light_out);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
         if (done) { D.sq_done[env] = 1; if (!completion) atomicAdd(sq_finished(D), 1); }
         else {
             D.sq_lev[env] = lev_out;
-            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x, lev_out, item);   // test hook: the item is lost
+            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((pairing && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
         }
     }
 }

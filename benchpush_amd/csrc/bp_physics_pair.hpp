@@ -1260,7 +1260,7 @@ __device__ __forceinline__ void pair_compact_slots(const DevParams &P, const PW 
 // that approaches them is parked at the sub-step boundary (the margins are what one sub-step can add at most in practice, and a capacity that is hit
 // anyway raises the same per-env error bits as in the solo kernel).  Heaviness second: an env with many active arbiters and colours sets the pace of the
 // wave for its mate and would itself run faster alone.
-struct PairLimits { int max_keys, max_slots, max_mv, max_act, max_work, gc_slots; };   // gc_slots: pair_compact_slots runs above this many slots in use
+struct PairLimits { int max_keys, max_slots, max_mv, max_act, max_work, gc_slots, max_rate; };   // gc_slots: pair_compact_slots runs above this many slots in use
 __device__ __forceinline__ bool pair_should_leave(const PState &S, const PairLimits &Q)
 {
     return S.nkeys > Q.max_keys || S.nslots > Q.max_slots || S.nmv > Q.max_mv || S.nact > Q.max_act || S.nwarm * S.nlevels > Q.max_work;
@@ -1268,10 +1268,11 @@ __device__ __forceinline__ bool pair_should_leave(const PState &S, const PairLim
 
 // One paired task: up to two envs (env1 may be -1), each from its own sub-step `it` on, to the end of the env step or until it leaves the pair.
 // Returns per half (in the lane's registers): status 1 = step complete (outputs written), 2 = parked at sub-step *it_out, 0 = no env.
-template <bool CAN_LEAVE>
+template <bool CAN_LEAVE, typename BehindFn>
 __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions, double *__restrict__ reward,
                                          unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated, double *__restrict__ info,
-                                         const int env0, const int env1, const PairLimits Q, int &it_out, int &score_out)
+                                         const int env0, const int env1, const PairLimits Q, int &it_out, int &score_out, int &heavy_out,
+                                         BehindFn behind)
 {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = (int)(threadIdx.x & 63);
@@ -1302,12 +1303,16 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         if (__ballot(declined) != 0ull) {
             it_out = it;
             score_out = have ? S.nkeys * 64 + S.nmv : 0;
+            heavy_out = declined ? 1 : 0;
             return have ? 2 : 0;
         }
         if (have && !resumed) { unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap; for (int i = W.hl; i < nbcap; i += 32) mvd_[i] = 0; }
     }
     const int nsub = P.steps;
+    const unsigned costp0 = S.costp;
     bool running = have;
+    bool heavy = false;
+    int to_boundary = P.sq_chunk;     // sub-steps of this task until the next look at the queues
     while (__ballot(running)) {
         if (running) {
             substep_pair(P, D, W, A, S, P.dt_sub);
@@ -1332,10 +1337,25 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         }
         // a half that must leave takes its mate along: the wave carries on with one of them alone (sched_body), the other waits in a queue -- an env that is
         // heavy must not wait for its mate to finish, nor run on in half a wavefront
-        if (CAN_LEAVE && __ballot(running && pair_should_leave(S, Q)) != 0ull && running) { running = false; status = 2; }
+        if (CAN_LEAVE) {
+            const bool lv = running && pair_should_leave(S, Q);
+            if (__ballot(lv) != 0ull) { if (running) { running = false; status = 2; heavy = lv; } }
+            else if (--to_boundary == 0) {
+                // chunk boundary of the task: like a solo wave, a paired wave yields to envs that are further behind than its least advanced env
+                to_boundary = P.sq_chunk;
+                const int itv = running ? it : 0x7FFFFFFF;
+                const int itmin = min(__builtin_amdgcn_readlane(itv, 0), __builtin_amdgcn_readlane(itv, 32));
+                if (itmin != 0x7FFFFFFF && behind(itmin / P.sq_chunk) && running) { running = false; status = 2; }
+            }
+        }
     }
     it_out = it;
-    score_out = have ? (int)min(S.costp / (unsigned)max(it - it_first, 1), 0x7FFFFFFFu) : 0;   // mean work proxy per sub-step of this task: which of two parked envs is the heavier
+    {
+        const unsigned rate = have ? (S.costp - costp0) / (unsigned)max(it - it_first, 1) : 0u;   // mean work proxy per sub-step of this task
+        score_out = (int)min(rate, 0x7FFFFFFFu);
+        // parked without having asked for it (its mate left, or the wave yielded): it still counts as heavy if its own work rate is above the pairing limit
+        heavy_out = (heavy || (have && rate > (unsigned)Q.max_rate)) ? 1 : 0;
+    }   // mean work proxy per sub-step of this task: which of two parked envs is the heavier
     if (!have) return 0;
     const unsigned short *const Lmvs = PLDS(unsigned short, PL_MVS);
     if (status == 2) {
