@@ -322,7 +322,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         // selects the one-wave-per-env kernel.
         // two environments per wavefront: the half-wave LDS image is laid out for PP_NBCAP body slots, element offsets are 32-bit
         const bool can_pair = plain && nbcap <= PP_NBCAP && h->lds_bytes <= 2 * PL_HALF &&
-                              ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_KADJ < (size_t)0x7FFFFFFF;
+                              ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_MAXV * sizeof(d2) < (size_t)0xFFFFFFFF &&   // 32-bit byte offsets (gA)
+                              ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_KADJ * sizeof(unsigned long long) < (size_t)0xFFFFFFFF;
         if (const char *evp = getenv("BP_PAIR")) { if (can_pair) h->pair_mode = atoi(evp); }
         if (h->pair_mode == 1) {
             h->P.pair_mode = 1;
@@ -359,13 +360,13 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 // two environments per wavefront inside the scheduler: who starts alone, and when a half leaves its pair (pair_should_leave)
                 auto envint = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
                 h->P.pair_mode = 2;
-                h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", h->num_envs / 16)));
+                h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", h->num_envs / 8)));
                 h->P.pp_max_keys = std::min(30, envint("BP_PP_KEYS", 26));
                 h->P.pp_max_slots = std::min(PP_NSLOT - 4, envint("BP_PP_SLOTS", 34));
                 h->P.pp_max_mv = std::min(PP_MVCAP - 4, envint("BP_PP_MV", 40));
-                h->P.pp_max_act = envint("BP_PP_ACT", 12);
-                h->P.pp_max_work = envint("BP_PP_WORK", 16);
-                h->P.pp_rate = envint("BP_PP_RATE", 100);
+                h->P.pp_max_act = envint("BP_PP_ACT", 16);
+                h->P.pp_max_work = envint("BP_PP_WORK", 9);
+                h->P.pp_rate = envint("BP_PP_RATE", 70);
                 h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));
             }
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));

@@ -77,6 +77,9 @@ struct PState {
 extern __shared__ double2 bp_smem[];
 #define PLDS(T, off) ((T *)((char *)bp_smem + W.lb + (off)))
 
+// Element `idx` of a per-env / per-trial array: the byte offset is formed in 32 bits (bp_load_scenarios enables pairing only while every such array stays
+// below 4 GB), so the access is "uniform base + 32-bit lane offset" -- one address instruction per access instead of a 64-bit multiply-add chain.
+template <typename T> __device__ __forceinline__ T &gA(T *const base, const unsigned idx) { return *(T *)((char *)base + (size_t)(idx * (unsigned)sizeof(T))); }
 __device__ __forceinline__ unsigned hballot(const bool p, const int h)
 {
     const unsigned long long b = __ballot(p);
@@ -101,7 +104,7 @@ __device__ __forceinline__ int pair_slot_get(const DevPtrs &D, const PW &W, PSta
         if (W.hl == 0) {
             PLDS(unsigned char, PL_SLOTOF)[body] = (unsigned char)s;
             PLDS(d2, PL_SV)[s] = mk2(0.0, 0.0); PLDS(d2, PL_SW)[s] = mk2(0.0, 0.0); PLDS(d2, PL_SB)[s] = mk2(0.0, 0.0);
-            PLDS(d2, PL_SP)[s] = D.pxy[W.eo + body];
+            PLDS(d2, PL_SP)[s] = gA(D.pxy, W.eo + body);
         }
         lds_sync();
     }
@@ -113,52 +116,52 @@ __device__ __forceinline__ void pair_refresh_body(const DevParams &P, const DevP
 {
     const int hl = W.hl;
     const unsigned eo = W.eo;
-    const double4 b = D.bb[eo + i];
+    const double4 b = gA(D.bb, eo + i);
     double4 nf;
     nf.x = b.x - P.skin; nf.y = b.y - P.skin; nf.z = b.z + P.skin; nf.w = b.w + P.skin;
-    if (hl == 0) D.fat[eo + i] = nf;
+    if (hl == 0) gA(D.fat, eo + i) = nf;
     pair_gsync();
     int cnt = 0;
     for (int base = 0; base < W.nb; base += 32) {
         const int j = base + hl;
         const bool valid = (j < W.nb) && (j != i);
-        const double4 fj = valid ? D.fat[eo + j] : nf;
+        const double4 fj = valid ? gA(D.fat, eo + j) : nf;
         const bool ov = valid && bb_overlap(nf, fj);
         const unsigned m = hballot(ov, W.h);
         const int pos = cnt + popc_below32(m, hl);
-        if (ov && pos < BP_KADJ) { D.adj[(eo + i) * BP_KADJ + pos] = (unsigned short)j; D.hint[(eo + i) * BP_KADJ + pos] = 0; }
+        if (ov && pos < BP_KADJ) { gA(D.adj, (eo + i) * BP_KADJ + pos) = (unsigned short)j; gA(D.hint, (eo + i) * BP_KADJ + pos) = 0; }
         cnt += __popc(m);
-        if (ov && kind_btype(D.sc_kind[W.to + j]) != BODY_STATIC) {
-            int nj = D.adjn[eo + j];
+        if (ov && kind_btype(gA(D.sc_kind, W.to + j)) != BODY_STATIC) {
+            int nj = gA(D.adjn, eo + j);
             bool found = false;
-            for (int s2 = 0; s2 < nj; s2++) found = found || (D.adj[(eo + j) * BP_KADJ + s2] == (unsigned short)i);
+            for (int s2 = 0; s2 < nj; s2++) found = found || (gA(D.adj, (eo + j) * BP_KADJ + s2) == (unsigned short)i);
             if (!found) {
                 if (nj >= BP_KADJ) {
                     int w = 0;
                     for (int s2 = 0; s2 < nj; s2++) {
-                        const int k = D.adj[(eo + j) * BP_KADJ + s2];
-                        const double4 fk = (k == i) ? nf : D.fat[eo + k];
+                        const int k = gA(D.adj, (eo + j) * BP_KADJ + s2);
+                        const double4 fk = (k == i) ? nf : gA(D.fat, eo + k);
                         if (bb_overlap(fj, fk)) {
-                            D.adj[(eo + j) * BP_KADJ + w] = (unsigned short)k;
-                            D.hint[(eo + j) * BP_KADJ + w] = D.hint[(eo + j) * BP_KADJ + s2];
+                            gA(D.adj, (eo + j) * BP_KADJ + w) = (unsigned short)k;
+                            gA(D.hint, (eo + j) * BP_KADJ + w) = gA(D.hint, (eo + j) * BP_KADJ + s2);
                             w++;
                         }
                     }
                     nj = w;
                 }
                 if (nj < BP_KADJ) {
-                    D.adj[(eo + j) * BP_KADJ + nj] = (unsigned short)i;
-                    D.hint[(eo + j) * BP_KADJ + nj] = 0;
-                    D.adjn[eo + j] = (unsigned char)(nj + 1);
+                    gA(D.adj, (eo + j) * BP_KADJ + nj) = (unsigned short)i;
+                    gA(D.hint, (eo + j) * BP_KADJ + nj) = 0;
+                    gA(D.adjn, eo + j) = (unsigned char)(nj + 1);
                 } else {
-                    D.adjn[eo + j] = (unsigned char)nj;
+                    gA(D.adjn, eo + j) = (unsigned char)nj;
                     err |= BP_ERR_ADJ_OVERFLOW;
                 }
             }
         }
     }
     if (cnt > BP_KADJ) { err |= BP_ERR_ADJ_OVERFLOW; cnt = BP_KADJ; }
-    if (hl == 0) D.adjn[eo + i] = (unsigned char)cnt;
+    if (hl == 0) gA(D.adjn, eo + i) = (unsigned char)cnt;
     pair_gsync();
 }
 
@@ -179,7 +182,7 @@ __device__ __forceinline__ void pair_support_queries(const DevPtrs &D, const PW 
         for (int t = 0; t < (VL + 7) / 8; t++) {
             const int q = l8 + 8 * t;
             const bool ok = act && (q < nv);
-            const d2 v = D.wv[(W.eo + body) * BP_MAXV + (ok ? q : 0)];
+            const d2 v = gA(D.wv, (W.eo + body) * BP_MAXV + (ok ? q : 0));
             const double d = vdot(dir, v);
             if (ok && d < best) { best = d; bi = q; }
         }
@@ -227,19 +230,19 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             const int sl = Lslot_of[i];
             d2 v = mk2(0.0, 0.0), w2 = mk2(0.0, 0.0), vb = mk2(0.0, 0.0);
             if (sl != 255) { v = Lsv[sl]; w2 = Lsw[sl]; vb = Lsb[sl]; }
-            d2 p = D.pxy[eo + i];
+            d2 p = gA(D.pxy, eo + i);
             if (sl != 255) p = Lsp[sl];
-            const double a = D.ang[eo + i];
-            d2 r = D.rot[eo + i];
-            const double4 ms = D.sc_mass[to + i];
-            rad = D.sc_prop[to + i].x;
-            fatb = D.fat[eo + i];
-            Lrf[hl] = (unsigned char)D.sc_nv[to + i];
+            const double a = gA(D.ang, eo + i);
+            d2 r = gA(D.rot, eo + i);
+            const double4 ms = gA(D.sc_mass, to + i);
+            rad = gA(D.sc_prop, to + i).x;
+            fatb = gA(D.fat, eo + i);
+            Lrf[hl] = (unsigned char)gA(D.sc_nv, to + i);
             p.x = p.x + (v.x + vb.x) * dt;
             p.y = p.y + (v.y + vb.y) * dt;
             const double a2 = a + (w2.x + w2.y) * dt;
             if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
-            D.pxy[eo + i] = p; D.ang[eo + i] = a2; D.rot[eo + i] = r;
+            gA(D.pxy, eo + i) = p; gA(D.ang, eo + i) = a2; gA(D.rot, eo + i) = r;
             if (i == 0) { Lag[0] = mk2(a2, 0.0); Lag[1] = r; }
             if (sl != 255) { Lsb[sl] = mk2(0.0, 0.0); Lsw[sl].y = 0.0; Lsp[sl] = p; }
             double4 t;
@@ -262,13 +265,13 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 if (q < (int)Lrf[kk]) {
                     const d2 t0_ = Ltf[2 * kk], t1_ = Ltf[2 * kk + 1];
                     const double c = t0_.x, s = t0_.y;
-                    const d2 lv = D.sc_lv[(to + i) * BP_MAXV + q], ln = D.sc_ln[(to + i) * BP_MAXV + q];
+                    const d2 lv = gA(D.sc_lv, (to + i) * BP_MAXV + q), ln = gA(D.sc_ln, (to + i) * BP_MAXV + q);
                     const double vx = (c * lv.x + (-s) * lv.y) + t1_.x;
                     const double vy = (s * lv.x + c * lv.y) + t1_.y;
                     const double nx = c * ln.x + (-s) * ln.y;
                     const double ny = s * ln.x + c * ln.y;
-                    D.wv[(eo + i) * BP_MAXV + q] = mk2(vx, vy);
-                    D.wn[(eo + i) * BP_MAXV + q] = mk2(nx, ny);
+                    gA(D.wv, (eo + i) * BP_MAXV + q) = mk2(vx, vy);
+                    gA(D.wn, (eo + i) * BP_MAXV + q) = mk2(nx, ny);
                     const unsigned long long kx = f64_key(vx), ky = f64_key(vy);
                     atomicMin(&bbk[kk * 4 + 0], kx); atomicMax(&bbk[kk * 4 + 1], kx);
                     atomicMin(&bbk[kk * 4 + 2], ky); atomicMax(&bbk[kk * 4 + 3], ky);
@@ -282,7 +285,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             double4 nbb;
             nbb.x = key_f64(bbk[hl * 4 + 0]) - rad; nbb.y = key_f64(bbk[hl * 4 + 2]) - rad;
             nbb.z = key_f64(bbk[hl * 4 + 1]) + rad; nbb.w = key_f64(bbk[hl * 4 + 3]) + rad;
-            D.bb[eo + i] = nbb;
+            gA(D.bb, eo + i) = nbb;
             leftfat = !(nbb.x >= fatb.x && nbb.y >= fatb.y && nbb.z <= fatb.z && nbb.w <= fatb.w);
         }
         // ---- 2. Verlet refresh --------------------------------------------------------------------------------
@@ -303,7 +306,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
         kmax = 0;
         for (int k0 = 0; k0 < S.nmv; k0 += 32) {
             const int k = k0 + hl;
-            const int cnt = (k < S.nmv) ? (int)D.adjn[eo + Lmv[k]] : 0;
+            const int cnt = (k < S.nmv) ? (int)gA(D.adjn, eo + Lmv[k]) : 0;
             int m = 0;
             for (int bit = 16; bit >= 1; bit >>= 1) { if (hballot(cnt >= (m | bit), h)) m |= bit; }
             kmax = max(kmax, m);
@@ -330,15 +333,15 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             const bool inlist = k < S.nmv;
             i = inlist ? (int)Lmv[k] : 0;
             const int sc = min(s, BP_KADJ - 1);
-            const int adjn_i = D.adjn[eo + i];
-            const int jr = D.adj[(eo + i) * BP_KADJ + sc];
+            const int adjn_i = gA(D.adjn, eo + i);
+            const int jr = gA(D.adj, (eo + i) * BP_KADJ + sc);
             j = jr < W.nb ? jr : 0;
-            hw = D.hint[(eo + i) * BP_KADJ + sc];
+            hw = gA(D.hint, (eo + i) * BP_KADJ + sc);
             valid = inlist && (s < adjn_i);
             if (valid && Lmvs[j] == nowr && j < i) valid = false; // pair is evaluated from j's list
-            const int ki = D.sc_kind[to + i], kj = D.sc_kind[to + j];
-            const double mi = D.sc_mass[to + i].x, mj = D.sc_mass[to + j].x;
-            nA_h = D.sc_nv[to + min(i, j)]; nB_h = D.sc_nv[to + max(i, j)];
+            const int ki = gA(D.sc_kind, to + i), kj = gA(D.sc_kind, to + j);
+            const double mi = gA(D.sc_mass, to + i).x, mj = gA(D.sc_mass, to + j).x;
+            nA_h = gA(D.sc_nv, to + min(i, j)); nB_h = gA(D.sc_nv, to + max(i, j));
             if (valid) {
                 if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
                 else if (mi == 0.0 && mj == 0.0) valid = false;                            // two infinite masses are never solved (no wall handler in ship-ice)
@@ -352,21 +355,24 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             }
         }
         const int sa = min(i, j), sb = max(i, j);
-        const double4 bbi = D.bb[eo + i];
-        const double4 bbj = D.bb[eo + j];
-        const double radA = D.sc_prop[to + sa].x, radB = D.sc_prop[to + sb].x;
+        const double4 bbi = gA(D.bb, eo + i);
+        const double4 bbj = gA(D.bb, eo + j);
+        const double radA = gA(D.sc_prop, to + sa).x, radB = gA(D.sc_prop, to + sb).x;
         const double rsum = radA + radB;
         const int hA = HW_PLANE_A(hw) < BP_MAXV ? HW_PLANE_A(hw) : 0, hB = HW_PLANE_B(hw) < BP_MAXV ? HW_PLANE_B(hw) : 0;
         const int cnA = HW_NV_A(hw), cnB = HW_NV_B(hw);
         const int jA0 = HW_VERT_A(hw) < BP_MAXV ? HW_VERT_A(hw) : 0, jB0 = HW_VERT_B(hw) < BP_MAXV ? HW_VERT_B(hw) : 0;
         const int jAm = (jA0 == 0) ? max(min(cnB, BP_MAXV) - 1, 0) : jA0 - 1, jAp = (jA0 + 1 >= cnB) ? 0 : jA0 + 1;   // on B
         const int jBm = (jB0 == 0) ? max(min(cnA, BP_MAXV) - 1, 0) : jB0 - 1, jBp = (jB0 + 1 >= cnA) ? 0 : jB0 + 1;   // on A
-        const d2 *const Av = D.wv + (size_t)(eo + sa) * BP_MAXV, *const An = D.wn + (size_t)(eo + sa) * BP_MAXV;
-        const d2 *const Bv = D.wv + (size_t)(eo + sb) * BP_MAXV, *const Bn = D.wn + (size_t)(eo + sb) * BP_MAXV;
-        const d2 fnA = An[hA], fpA = Av[hA];
-        const d2 fnB = Bn[hB], fpB = Bv[hB];
-        const d2 vAm = Bv[jAm], vA0 = Bv[jA0], vAp = Bv[jAp];
-        const d2 vBm = Av[jBm], vB0 = Av[jB0], vBp = Av[jBp];
+        const unsigned oA = (eo + (unsigned)sa) * BP_MAXV, oB = (eo + (unsigned)sb) * BP_MAXV;   // world vertices / normals of the pair's two shapes
+#define Av(k) gA(D.wv, oA + (unsigned)(k))
+#define An(k) gA(D.wn, oA + (unsigned)(k))
+#define Bv(k) gA(D.wv, oB + (unsigned)(k))
+#define Bn(k) gA(D.wn, oB + (unsigned)(k))
+        const d2 fnA = An(hA), fpA = Av(hA);
+        const d2 fnB = Bn(hB), fpB = Bv(hB);
+        const d2 vAm = Bv(jAm), vA0 = Bv(jA0), vAp = Bv(jAp);
+        const d2 vBm = Av(jBm), vB0 = Av(jB0), vBp = Av(jBp);
         if (valid) valid = bb_overlap(bbi, bbj);
         if (hballot(valid, h) == 0) continue;
         // ---- 4a. cached planes -----------------------------------------------------------------------------------------
@@ -406,7 +412,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             valid = false;
             if (hw & HW_BOTH) {
                 const unsigned long long nh = (hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0ull : HW_PRIM_B);
-                D.hint[(eo + i) * BP_KADJ + s] = nh;
+                gA(D.hint, (eo + i) * BP_KADJ + s) = nh;
                 if (incache) Lcc_hw[base + hl] = nh;
             }
         }
@@ -497,10 +503,9 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 round_addr(pa, 0, pb0, qb0, np0, nqv0, hX0, ev0, jc0, jm0, jp0);
                 round_addr(pa, 1, pb1, qb1, np1, nqv1, hX1, ev1, jc1, jm1, jp1);
                 const int fc0 = (f < np0) ? f : 0, fc1 = (f < np1) ? f : 0;
-                const d2 *const P0v = D.wv + (size_t)(eo + pb0) * BP_MAXV, *const P0n = D.wn + (size_t)(eo + pb0) * BP_MAXV;
-                const d2 *const P1v = D.wv + (size_t)(eo + pb1) * BP_MAXV, *const P1n = D.wn + (size_t)(eo + pb1) * BP_MAXV;
-                const d2 fn0 = P0n[fc0], fp0 = P0v[fc0], vb0 = P1v[jc0], vm0 = P1v[jm0], vp0 = P1v[jp0];   // side 0: planes of A (= pb0) against vertices of B (= qb0 = pb1)
-                const d2 fn1 = P1n[fc1], fp1 = P1v[fc1], vb1 = P0v[jc1], vm1 = P0v[jm1], vp1 = P0v[jp1];   // side 1: planes of B against vertices of A
+                const unsigned o0 = (eo + (unsigned)pb0) * BP_MAXV, o1 = (eo + (unsigned)pb1) * BP_MAXV;
+                const d2 fn0 = gA(D.wn, o0 + (unsigned)(fc0)), fp0 = gA(D.wv, o0 + (unsigned)(fc0)), vb0 = gA(D.wv, o1 + (unsigned)(jc0)), vm0 = gA(D.wv, o1 + (unsigned)(jm0)), vp0 = gA(D.wv, o1 + (unsigned)(jp0));   // side 0: planes of A (= pb0) against vertices of B (= qb0 = pb1)
+                const d2 fn1 = gA(D.wn, o1 + (unsigned)(fc1)), fp1 = gA(D.wv, o1 + (unsigned)(fc1)), vb1 = gA(D.wv, o0 + (unsigned)(jc1)), vm1 = gA(D.wv, o0 + (unsigned)(jm1)), vp1 = gA(D.wv, o0 + (unsigned)(jp1));   // side 1: planes of B against vertices of A
                 {
                     const double th = thr.x;
                     const bool pv = (f < np0) && !(ev0 && f == hX0);
@@ -553,12 +558,12 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             const double smax = useA ? sA : sB;
             touching = true;
             const int iA0 = (iA == 0) ? nA - 1 : iA - 1, iB0 = (iB == 0) ? nB - 1 : iB - 1;
-            const d2 nAi = An[iA], nBi = Bn[iB];
-            const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
-            const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
+            const d2 nAi = An(iA), nBi = Bn(iB);
+            const d2 aA = Av(iA0), bA = Av(iA), qA = Bv(jA);
+            const d2 aB = Bv(iB0), bB = Bv(iB), qB = Av(jB);
             const int iA0m = (iA0 == 0) ? nA - 1 : iA0 - 1, iAp = (iA + 1 >= nA) ? 0 : iA + 1;
             const int iB0m = (iB0 == 0) ? nB - 1 : iB0 - 1, iBp = (iB + 1 >= nB) ? 0 : iB + 1;
-            const d2 oA0 = Av[iA0m], oA1 = Av[iAp], oB0 = Bv[iB0m], oB1 = Bv[iBp];
+            const d2 oA0 = Av(iA0m), oA1 = Av(iAp), oB0 = Bv(iB0m), oB1 = Bv(iBp);
             if (smax > rsum) touching = false;
             else if (smax <= 0.0) { n = useA ? nAi : vneg(nBi); src = useA ? 0 : 1; }
             else {
@@ -568,17 +573,17 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 const d2 eB = vsub(bB, aB);
                 const double uB = vdot(vsub(qB, aB), eB), eeB = vdot(eB, eB);
                 const bool spanB = !(uB < 0.0) && !(uB > eeB);
-                auto tie_partner = [&](const d2 aP, const d2 eP, const double eeP, const d2 nP, const d2 *Qv, const int nQ, const int j_, const d2 q0, const double u) -> bool {
+                auto tie_partner = [&](const d2 aP, const d2 eP, const double eeP, const d2 nP, const unsigned oQ, const int nQ, const int j_, const d2 q0, const double u) -> bool {
                     const int jn = (u < 0.0) ? ((j_ == 0) ? nQ - 1 : j_ - 1) : ((j_ + 1 >= nQ) ? 0 : j_ + 1);
-                    const d2 q1 = Qv[jn];
+                    const d2 q1 = gA(D.wv, oQ + (unsigned)jn);
                     const double u1 = vdot(vsub(q1, aP), eP);
                     return !(u1 < 0.0) && !(u1 > eeP) && (vdot(nP, q1) - vdot(nP, q0) <= BP_TIE_TOL);
                 };
                 if (useA) {
                     if (spanA) { n = nAi; src = 0; }
                     else if (sB > 0.0 && spanB) { n = vneg(nBi); src = 1; }
-                    else if (tie_partner(aA, eA, eeA, nAi, Bv, nB, jA, qA, uA)) { n = nAi; src = 0; }
-                    else if (sB > 0.0 && tie_partner(aB, eB, eeB, nBi, Av, nA, jB, qB, uB)) { n = vneg(nBi); src = 1; }
+                    else if (tie_partner(aA, eA, eeA, nAi, oB, nB, jA, qA, uA)) { n = nAi; src = 0; }
+                    else if (sB > 0.0 && tie_partner(aB, eB, eeB, nBi, oA, nA, jB, qB, uB)) { n = vneg(nBi); src = 1; }
                     else {
                         const d2 pp = vsub(qA, (uA < 0.0) ? aA : bA);
                         const double dl = vlen(pp);
@@ -588,8 +593,8 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 } else {
                     if (spanB) { n = vneg(nBi); src = 1; }
                     else if (sA > 0.0 && spanA) { n = nAi; src = 0; }
-                    else if (tie_partner(aB, eB, eeB, nBi, Av, nA, jB, qB, uB)) { n = vneg(nBi); src = 1; }
-                    else if (sA > 0.0 && tie_partner(aA, eA, eeA, nAi, Bv, nB, jA, qA, uA)) { n = nAi; src = 0; }
+                    else if (tie_partner(aB, eB, eeB, nBi, oA, nA, jB, qB, uB)) { n = vneg(nBi); src = 1; }
+                    else if (sA > 0.0 && tie_partner(aA, eA, eeA, nAi, oB, nB, jA, qA, uA)) { n = nAi; src = 0; }
                     else {
                         const d2 pp = vsub((uB < 0.0) ? aB : bB, qB);
                         const double dl = vlen(pp);
@@ -614,7 +619,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             const unsigned long long nh = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
                                                                ((unsigned)nA << 20) | ((unsigned)nB << 25)) |
                                           HW_HAS_A | HW_HAS_B | (useA ? 0ull : HW_PRIM_B) | ((smax > rsum) ? 0ull : HW_BOTH);
-            D.hint[(eo + i) * BP_KADJ + s] = nh;
+            gA(D.hint, (eo + i) * BP_KADJ + s) = nh;
             if (incache) Lcc_hw[base + hl] = nh;
         }
         {
@@ -640,8 +645,8 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             {
                 const int a0 = (i1A == 0) ? nA - 1 : i1A - 1, a2 = (i1A + 1 == nA) ? 0 : i1A + 1;
                 const int b0 = (i1B == 0) ? nB - 1 : i1B - 1, b2 = (i1B + 1 == nB) ? 0 : i1B + 1;
-                const d2 nA1 = An[i1A], nA2 = An[a2], vA0_ = Av[a0], vA1 = Av[i1A], vA2 = Av[a2];
-                const d2 nB1 = Bn[i1B], nB2 = Bn[b2], vB0_ = Bv[b0], vB1 = Bv[i1B], vB2 = Bv[b2];
+                const d2 nA1 = An(i1A), nA2 = An(a2), vA0_ = Av(a0), vA1 = Av(i1A), vA2 = Av(a2);
+                const d2 nB1 = Bn(i1B), nB2 = Bn(b2), vB0_ = Bv(b0), vB1 = Bv(i1B), vB2 = Bv(b2);
                 const bool fa = vdot(n, nA1) > vdot(n, nA2);
                 e1a = fa ? vA0_ : vA1; e1ia = fa ? a0 : i1A; e1b = fa ? vA1 : vA2; e1ib = fa ? i1A : a2;
                 const bool fb = vdot(nn, nB1) > vdot(nn, nB2);
@@ -709,9 +714,9 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 if (BP_UNLIKELY2(fresh)) {
                     A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0;
                     const int usa = (int)(A.key >> 16), usb = (int)(A.key & 0xFFFFu);
-                    const double4 m1 = D.sc_mass[to + usa], m2 = D.sc_mass[to + usb];
+                    const double4 m1 = gA(D.sc_mass, to + usa), m2 = gA(D.sc_mass, to + usb);
                     A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
-                    const double4 q1 = D.sc_prop[to + usa], q2 = D.sc_prop[to + usb];
+                    const double4 q1 = gA(D.sc_prop, to + usa), q2 = gA(D.sc_prop, to + usb);
                     A.e = q1.y * q2.y; A.u = q1.z * q2.z;
                 }
                 double njn0 = 0.0, njt0 = 0.0, njn1 = 0.0, njt1 = 0.0;
@@ -1064,6 +1069,10 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     }
     S.quiescent = (S.nmv == 0) && (wmask == 0);
     lds_sync();
+#undef Av
+#undef An
+#undef Bv
+#undef Bn
 }
 
 // ---- state of one half: persistent env state <-> LDS image / registers (load_state_a / load_state_b / store_state of bp_kernels.hpp for 32 lanes) ----
@@ -1080,10 +1089,10 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
     double *const Lhs = PLDS(double, PL_HS);
     for (int i = hl; i < PP_NBCAP; i += 32) { Lmvs[i] = 0; Lslot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     for (int i = hl; i < PP_NSLOT + 2; i += 32) Lmvo[i] = 0u;
-    if (hl < P.nkin) { Lsv[hl] = D.velv[eo + hl]; Lsw[hl] = D.velw[eo + hl]; Lsb[hl] = D.velb[eo + hl]; Lsp[hl] = D.pxy[eo + hl]; }
+    if (hl < P.nkin) { Lsv[hl] = gA(D.velv, eo + hl); Lsw[hl] = gA(D.velw, eo + hl); Lsb[hl] = gA(D.velb, eo + hl); Lsp[hl] = gA(D.pxy, eo + hl); }
     if (hl == 0) {
-        Lag[0] = mk2(D.ang[eo], 0.0); Lag[1] = D.rot[eo];
-        Lhs[0] = D.e_currdt[env]; Lhs[1] = -1.0; Lhs[2] = 0.0; Lhs[3] = 0.0;
+        Lag[0] = mk2(gA(D.ang, eo), 0.0); Lag[1] = gA(D.rot, eo);
+        Lhs[0] = gA(D.e_currdt, env); Lhs[1] = -1.0; Lhs[2] = 0.0; Lhs[3] = 0.0;
     }
     S.nslots = P.nkin;
     S.costp = 0u; S.cc_ok = 0; S.cc_kmax = 0; S.quiescent = 0; S.ship_post = 0; S.ship_contacts = 0; S.err = 0;
@@ -1096,7 +1105,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
     lds_sync();
     for (int part = 0; part < 2; part++) {
         const int idx = part * 32 + hl;
-        const bool live = D.a_key[ab0 + idx] != ARB_FREE_KEY;
+        const bool live = gA(D.a_key, ab0 + idx) != ARB_FREE_KEY;
         const unsigned m = hballot(live, h);
         const int pos = nlive + popc_below32(m, hl);
         if (live && pos < 32) Lkq[pos] = (unsigned)idx;
@@ -1111,21 +1120,21 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
     A.slotA = A.slotB = 0;
     if (hl < nlive) {
         const size_t ab = ab0 + Lkq[hl];
-        A.key = D.a_key[ab]; A.stamp = D.a_stamp[ab];
-        { const unsigned sc = D.a_sc[ab]; A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
-        A.h0 = D.a_h0[ab]; A.h1 = D.a_h1[ab];
+        A.key = gA(D.a_key, ab); A.stamp = gA(D.a_stamp, ab);
+        { const unsigned sc = gA(D.a_sc, ab); A.state = (int)(sc & 0xFF); A.count = (int)(sc >> 8); }
+        A.h0 = gA(D.a_h0, ab); A.h1 = gA(D.a_h1, ab);
         const double *ad = D.a_d + ab * 14;
         A.jn0 = ad[0]; A.jt0 = ad[1]; A.jn1 = ad[2]; A.jt1 = ad[3];
         A.n = mk2(ad[4], ad[5]);
         A.r1_0 = mk2(ad[6], ad[7]); A.r2_0 = mk2(ad[8], ad[9]); A.r1_1 = mk2(ad[10], ad[11]); A.r2_1 = mk2(ad[12], ad[13]);
-        const double4 m1 = D.sc_mass[to + (A.key >> 16)], m2 = D.sc_mass[to + (A.key & 0xFFFFu)];
+        const double4 m1 = gA(D.sc_mass, to + (A.key >> 16)), m2 = gA(D.sc_mass, to + (A.key & 0xFFFFu));
         A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
-        const double4 q1 = D.sc_prop[to + (A.key >> 16)], q2 = D.sc_prop[to + (A.key & 0xFFFFu)];
+        const double4 q1 = gA(D.sc_prop, to + (A.key >> 16)), q2 = gA(D.sc_prop, to + (A.key & 0xFFFFu));
         A.e = q1.y * q2.y; A.u = q1.z * q2.z;
     }
-    S.stamp = D.e_stamp[env]; S.stamp0 = S.stamp;
-    S.total_ke = D.e_ke[env]; S.total_imp = D.e_imp[env];
-    S.n_post = D.e_cnt[env * 4 + 0]; S.n_contact = D.e_cnt[env * 4 + 1]; S.n_first = D.e_cnt[env * 4 + 2];
+    S.stamp = gA(D.e_stamp, env); S.stamp0 = S.stamp;
+    S.total_ke = gA(D.e_ke, env); S.total_imp = gA(D.e_imp, env);
+    S.n_post = gA(D.e_cnt, env * 4 + 0); S.n_contact = gA(D.e_cnt, env * 4 + 1); S.n_first = gA(D.e_cnt, env * 4 + 2);
     if (resumed) {
         const unsigned *cy = D.sq_carry + (size_t)env * 4;
         S.yaw_violated = (int)(cy[0] & 1u); S.boundary_violated = (int)(cy[1] & 1u); S.costp = cy[2];
@@ -1134,7 +1143,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
     // ship control (ship_ice_env.py:265-274): set once per env step
     if (!resumed && hl < P.nkin) {
         const double act = actions[env] * P.max_yaw_rate;
-        const d2 r = D.rot[eo];
+        const d2 r = gA(D.rot, eo);
         Lsv[hl] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
         Lsw[hl] = mk2(act, Lsw[hl].y);
     }
@@ -1147,7 +1156,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
         d2 v = mk2(0.0, 0.0), w2 = v, vb = v;
         if (i < W.nb) {
             if (i < P.nkin) { v = Lsv[i]; w2 = Lsw[i]; vb = Lsb[i]; }
-            else { v = D.velv[eo + i]; w2 = D.velw[eo + i]; vb = D.velb[eo + i]; }
+            else { v = gA(D.velv, eo + i); w2 = gA(D.velw, eo + i); vb = gA(D.velb, eo + i); }
             mvg = (v.x != 0.0 || v.y != 0.0 || w2.x != 0.0 || w2.y != 0.0 || vb.x != 0.0 || vb.y != 0.0);
         }
         const unsigned m = hballot(mvg, h);
@@ -1157,7 +1166,7 @@ __device__ __forceinline__ void pair_load_state(const DevParams &P, const DevPtr
             int sl = S.nslots + popc_below32(ms, hl);
             if (sl >= PP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = PP_NSLOT - 1; }
             Lslot_of[i] = (unsigned char)sl;
-            Lsv[sl] = v; Lsw[sl] = w2; Lsb[sl] = vb; Lsp[sl] = D.pxy[eo + i];
+            Lsv[sl] = v; Lsw[sl] = w2; Lsb[sl] = vb; Lsp[sl] = gA(D.pxy, eo + i);
         }
         n += __popc(m);
         S.nslots = min(S.nslots + __popc(ms), PP_NSLOT);
@@ -1186,23 +1195,23 @@ __device__ __forceinline__ void pair_store_state(const DevParams &P, const DevPt
     for (int i = hl; i < P.nbcap; i += 32) {
         const int sl = Lslot_of[i];
         const d2 z = mk2(0.0, 0.0);
-        D.velv[eo + i] = (sl != 255) ? Lsv[sl] : z; D.velw[eo + i] = (sl != 255) ? Lsw[sl] : z; D.velb[eo + i] = (sl != 255) ? Lsb[sl] : z;
+        gA(D.velv, eo + i) = (sl != 255) ? Lsv[sl] : z; gA(D.velw, eo + i) = (sl != 255) ? Lsw[sl] : z; gA(D.velb, eo + i) = (sl != 255) ? Lsb[sl] : z;
     }
     {
         const size_t ab = (size_t)env * BP_ACAP + hl;
-        D.a_key[ab] = A.key; D.a_stamp[ab] = A.stamp; D.a_sc[ab] = (unsigned)A.state | ((unsigned)A.count << 8);
-        D.a_h0[ab] = A.h0; D.a_h1[ab] = A.h1;
+        gA(D.a_key, ab) = A.key; gA(D.a_stamp, ab) = A.stamp; gA(D.a_sc, ab) = (unsigned)A.state | ((unsigned)A.count << 8);
+        gA(D.a_h0, ab) = A.h0; gA(D.a_h1, ab) = A.h1;
         double *ad = D.a_d + ab * 14;
         ad[0] = A.jn0; ad[1] = A.jt0; ad[2] = A.jn1; ad[3] = A.jt1; ad[4] = A.n.x; ad[5] = A.n.y;
         ad[6] = A.r1_0.x; ad[7] = A.r1_0.y; ad[8] = A.r2_0.x; ad[9] = A.r2_0.y;
         ad[10] = A.r1_1.x; ad[11] = A.r1_1.y; ad[12] = A.r2_1.x; ad[13] = A.r2_1.y;
-        D.a_key[ab + 32] = ARB_FREE_KEY;   // the upper half of the env's persisted arbiter entries is unused while it runs paired
+        gA(D.a_key, ab + 32) = ARB_FREE_KEY;   // the upper half of the env's persisted arbiter entries is unused while it runs paired
     }
     if (hl == 0) {
-        D.e_stamp[env] = S.stamp; D.e_currdt[env] = PLDS(double, PL_HS)[0];
-        D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
-        D.e_cnt[env * 4 + 0] = S.n_post; D.e_cnt[env * 4 + 1] = S.n_contact; D.e_cnt[env * 4 + 2] = S.n_first;
-        if (S.err) atomicOr(&D.e_err[env], S.err & (BP_ERR_ADJ_OVERFLOW | BP_ERR_ARB_OVERFLOW | BP_ERR_LEVEL_OVERFLOW));
+        gA(D.e_stamp, env) = S.stamp; gA(D.e_currdt, env) = PLDS(double, PL_HS)[0];
+        gA(D.e_ke, env) = S.total_ke; gA(D.e_imp, env) = S.total_imp;
+        gA(D.e_cnt, env * 4 + 0) = S.n_post; gA(D.e_cnt, env * 4 + 1) = S.n_contact; gA(D.e_cnt, env * 4 + 2) = S.n_first;
+        if (S.err) atomicOr(&gA(D.e_err, env), S.err & (BP_ERR_ADJ_OVERFLOW | BP_ERR_ARB_OVERFLOW | BP_ERR_LEVEL_OVERFLOW));
     }
 }
 
@@ -1285,10 +1294,10 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
     W.env = env;
     const int nbcap = P.nbcap;
     W.eo = (unsigned)env * (unsigned)nbcap;
-    const int trial = D.e_trial[env];
+    const int trial = gA(D.e_trial, env);
     W.to = (unsigned)trial * (unsigned)nbcap;
-    W.nb = D.e_nb[env];
-    const int it_first = CAN_LEAVE ? D.sq_sub[env] : 0;
+    W.nb = gA(D.e_nb, env);
+    const int it_first = CAN_LEAVE ? gA(D.sq_sub, env) : 0;
     const bool resumed = it_first > 0;
     ArbReg A;
     PState S;
@@ -1368,7 +1377,7 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
             unsigned *cy = D.sq_carry + (size_t)env * 4;
             cy[0] = (unsigned)S.yaw_violated; cy[1] = (unsigned)S.boundary_violated; cy[2] = S.costp;
             cy[3] = (resumed ? cy[3] : 0u) + (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
-            D.sq_sub[env] = it;
+            gA(D.sq_sub, env) = it;
         }
         return 2;
     }
@@ -1378,11 +1387,11 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         double *const scr = PLDS(double, PL_QDIR);   // [32] contributions of a chunk of bodies
         for (int base = 0; base < W.nb; base += 32) {
             const int i = base + W.hl;
-            const bool mvd = (i < W.nb) && ((Lmvs[i] != 0) || (resumed && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
-                             (kind_ctype(D.sc_kind[W.to + i]) == 2);
+            const bool mvd = (i < W.nb) && ((Lmvs[i] != 0) || (resumed && gA(D.sq_moved, (size_t)env * nbcap + i) != 0)) &&
+                             (kind_ctype(gA(D.sc_kind, W.to + i)) == 2);
             double contrib = 0.0;
             if (mvd) {
-                const int n = D.sc_nv[W.to + i];
+                const int n = gA(D.sc_nv, W.to + i);
                 d2 *prev = D.pv + (size_t)(W.eo + i) * BP_MAXV;
                 const d2 *nowv = D.wv + (size_t)(W.eo + i) * BP_MAXV;
                 const double area = poly_area_seq(prev, n);
@@ -1402,12 +1411,12 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
     pair_gsync();
     pair_store_state(P, D, W, A, S);
     if (W.hl == 0) {
-        const d2 sp = D.pxy[W.eo];
-        const double sa = D.ang[W.eo];
+        const d2 sp = gA(D.pxy, W.eo);
+        const double sa = gA(D.ang, W.eo);
         // solo-equivalent cost of the env for the next step's dispatch order: the wave's cycles until this half finished
-        D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + (resumed ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
-        const double total_work = D.e_total_work[env] + work;
-        D.e_total_work[env] = total_work;
+        gA(D.e_cost, env) = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + (resumed ? gA(D.sq_carry, (size_t)env * 4 + 3) : 0u);
+        const double total_work = gA(D.e_total_work, env) + work;
+        gA(D.e_total_work, env) = total_work;
         int boundary_terminal = 0;
         if (sp.x < 0.0 && __builtin_fabs(sp.x - 0.0) >= 0.0) boundary_terminal = 1;
         if (sp.x > P.map_w && __builtin_fabs(sp.x - P.map_w) >= 0.0) boundary_terminal = 1;
@@ -1416,7 +1425,7 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         else if (boundary_terminal) term = 1;
         double dist_reward = 0.0;
         if (sp.y < P.goal_y) {
-            const d2 r = D.rot[W.eo];
+            const d2 r = gA(D.rot, W.eo);
             dist_reward = 1.0 * (r.x * 0.0 + r.y * 1.0);
         }
         const double coll = -work;
@@ -1428,7 +1437,7 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
         if (reward) reward[env] = rwd;
         if (terminated) terminated[env] = (unsigned char)term;
         if (truncated) truncated[env] = 0;
-        D.e_lastrew[env] = rwd; D.e_lastflag[env] = term | (success << 1);
+        gA(D.e_lastrew, env) = rwd; gA(D.e_lastflag, env) = term | (success << 1);
         if (info) {
             double *o = info + (size_t)env * BP_INFO_COUNT;
             o[BP_I_X] = sp.x; o[BP_I_Y] = sp.y; o[BP_I_THETA] = sa; o[BP_I_TOTAL_WORK] = total_work; o[BP_I_WORK] = work;
