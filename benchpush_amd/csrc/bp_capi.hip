@@ -321,16 +321,20 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         // is a few rounds of the wave slots (+14 % at 4096 envs; -1 % at 16 384, where the tail is amortised): BP_SCHED=<chunk> forces it, BP_SCHED=0
         // selects the one-wave-per-env kernel.
         // two environments per wavefront: the half-wave LDS image is laid out for PP_NBCAP body slots, element offsets are 32-bit
-        const bool can_pair = plain && nbcap <= PP_NBCAP && h->lds_bytes <= 2 * PL_HALF &&
+        const bool can_pair = plain && nbcap <= PP_NBCAP &&
                               ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_MAXV * sizeof(d2) < (size_t)0xFFFFFFFF &&   // 32-bit byte offsets (gA)
                               ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_KADJ * sizeof(unsigned long long) < (size_t)0xFFFFFFFF;
-        if (const char *evp = getenv("BP_PAIR")) { if (can_pair) h->pair_mode = atoi(evp); }
+        // Default: inside the scheduler (mode 2) from 2 560 envs up -- below, every env has a wave slot of its own from the first cycle and the launch is the
+        // chain of its heaviest env, which a mate can only lengthen (2 048 envs: -2 %).  BP_PAIR=0 / 1 / 2 overrides.
+        if (can_pair && h->num_envs > 2560) h->pair_mode = 2;
+        if (const char *evp = getenv("BP_PAIR")) h->pair_mode = can_pair ? atoi(evp) : 0;
         if (h->pair_mode == 1) {
             h->P.pair_mode = 1;
             if (const char *evs = getenv("BP_PAIR_SNAKE")) h->P.pair_solo = atoi(evs);
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * PL_HALF)));
         }
-        int ch = (h->num_envs <= 8192) ? 40 : 0;
+        // (with paired first tasks the scheduler is what lets an env leave its pair, so it stays on at every batch size: chunks of 100 sub-steps above 8192 envs)
+        int ch = (h->num_envs <= 8192) ? 40 : (h->pair_mode == 2 ? 100 : 0);
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
@@ -360,13 +364,17 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 // two environments per wavefront inside the scheduler: who starts alone, and when a half leaves its pair (pair_should_leave)
                 auto envint = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
                 h->P.pair_mode = 2;
-                h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", h->num_envs / 8)));
+                // Up to ~6 000 envs per GPU the launch is within a few per cent of the chain of its heaviest env: only envs that are light right now run
+                // paired (a medium env beside a mate would become the longest chain), and the eighth of the dispatch order that was heaviest in the previous
+                // step starts alone.  Above, the launch is throughput: everything that fits a half-wave runs paired (same-box sweeps in profiles/r05_pair/).
+                const bool tight = h->num_envs < 6144;
+                h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", tight ? h->num_envs / 8 : 0)));
                 h->P.pp_max_keys = std::min(30, envint("BP_PP_KEYS", 26));
                 h->P.pp_max_slots = std::min(PP_NSLOT - 4, envint("BP_PP_SLOTS", 34));
                 h->P.pp_max_mv = std::min(PP_MVCAP - 4, envint("BP_PP_MV", 40));
-                h->P.pp_max_act = envint("BP_PP_ACT", 16);
-                h->P.pp_max_work = envint("BP_PP_WORK", 9);
-                h->P.pp_rate = envint("BP_PP_RATE", 70);
+                h->P.pp_max_act = envint("BP_PP_ACT", tight ? 16 : 30);
+                h->P.pp_max_work = envint("BP_PP_WORK", tight ? 9 : 100);
+                h->P.pp_rate = envint("BP_PP_RATE", tight ? 70 : 1000);
                 h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));
             }
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));

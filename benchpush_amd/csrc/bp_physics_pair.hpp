@@ -75,6 +75,19 @@ struct PState {
 };
 
 extern __shared__ double2 bp_smem[];
+// Diagnostic build (-DBP_PAIR_PROF, tools/prof_pair.py): cycle stamps of the paired sub-step's phases, taken by lane 0 for the wave, kept in the spare
+// bytes of half 0's LDS image and added to D.prof[env of half 0] at the end of the task.
+#ifdef BP_PAIR_PROF
+#define PPROF_SLOT(k) (((unsigned long long *)((char *)bp_smem + PL_END))[k])
+#define PPROF_DECL unsigned long long _pt = __builtin_amdgcn_s_memtime();
+#define PPROF(k) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); if ((threadIdx.x & 63) == 0) PPROF_SLOT(k) += _n - _pt; _pt = _n; }
+#define PCNT(k, v) { if ((threadIdx.x & 63) == 0) PPROF_SLOT(k) += (unsigned long long)(v); }
+static_assert(PL_END + 8u * 19 <= PL_HALF, "phase counters fit the spare bytes of the half-wave image");
+#else
+#define PPROF_DECL
+#define PPROF(k)
+#define PCNT(k, v)
+#endif
 #define PLDS(T, off) ((T *)((char *)bp_smem + W.lb + (off)))
 
 // Element `idx` of a per-env / per-trial array: the byte offset is formed in 32 bits (bp_load_scenarios enables pairing only while every such array stays
@@ -219,6 +232,8 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     lds_sync();
     if (hl == 0) Lhs[0] = dt;
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) A.state = ARB_NORMAL;
+    PPROF_DECL
+    PCNT(12, 1)
 
     // ---- 1. integrate positions of the moving bodies; world geometry; AABBs ----------------------------------
     for (int k0 = 0; k0 < S.nmv; k0 += 32) {
@@ -299,6 +314,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
         lds_sync();
     }
     pair_gsync();
+    PPROF(0)
 
     // ---- 3./4. candidate pairs of moving bodies ----------------------------------------------------------------
     int kmax = S.cc_kmax;
@@ -417,6 +433,8 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             }
         }
         const unsigned cm = hballot(valid, h);
+        PPROF(1)
+        PCNT(13, 1)
         if (cm == 0) continue;
         // ---- 4a'. every other plane of the surviving pairs: one (pair, side) per round -- the half's 32 lanes cover the up to BP_MAXV planes of a side;
         //      the two sides of a pair are taken together so that their loads travel together ------------------------------------------------------
@@ -540,6 +558,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             }
             if (nq > 0) flush(nc);
         }
+        PPROF(2)
         // ---- 4b. closest features -> normal -> Chipmunk ContactPoints, one pair per lane ------------------------------
         Manifold M;
         M.count = 0; M.h0 = M.h1 = 0; M.n = mk2(0, 0);
@@ -675,6 +694,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 }
             }
         }
+        PPROF(3)
         // ---- 4c. cpArbiterUpdate: hand each manifold to the lane of the half that owns the pair's arbiter ---------------------
         const unsigned dmk = hballot(valid && M.count > 0, h);
         const int drank = popc_below32(dmk, hl);
@@ -739,6 +759,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
         }
     }
     S.cc_ok = 1;
+    PPROF(4)
     // arbiters whose bodies did not move keep last sub-step's contacts
     if (A.key != ARB_FREE_KEY && A.stamp == now - 1u) {
         const int a = (int)(A.key >> 16), b = (int)(A.key & 0xFFFFu);
@@ -819,6 +840,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     // bias terms: one copy of the loop for the wave -- the copy with bias arithmetic leaves an env without bias terms bit-identical (its bias velocities and
     // impulses are and stay +0), so it is taken as soon as either half needs it
     const bool any_bias = __ballot(warm && ((bias0 != 0.0) || (A.count > 1 && bias1 != 0.0))) != 0ull;
+    PPROF(5)
     // ---- solve order: greedy colouring of the active set in ascending key order (cached while the set is unchanged) ----------
     if (BP_UNLIKELY(amask != S.prev_amask)) {
         lds_sync();
@@ -859,6 +881,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     }
     S.costp += 16u + 2u * (unsigned)__popc(amask) + 4u * (unsigned)(__popc(wmask) * S.nlevels);
     lds_sync();
+    PPROF(6)
     // ---- 6b. velocity integrate: damping^dt == 0 -> dynamic bodies' v, w := +0 -----------------------------------------
     for (int k0 = 0; k0 < S.nmv; k0 += 32) {
         const int k = k0 + hl;
@@ -899,6 +922,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
         }
         lds_sync();
     }
+    PPROF(7)
     // ---- 6d. sequential impulses (cpArbiterApplyImpulse) ------------------------------------------------------
     const int wA = (A.ma != 0.0) ? A.slotA : PP_NSLOT, wB = (A.mb != 0.0) ? A.slotB : PP_NSLOT;
     auto iterate = [&](auto bias_tag) {
@@ -961,6 +985,32 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
                 }
             }
         };
+        // ---- at most one warm colour in EITHER half (what light envs, the ones that are paired, mostly are): within a half the warm arbiters share no
+        // dynamic body, so nobody else reads or writes the velocities a lane works on between its passes -- they stay in registers for the ten iterations
+        // (one gather, one scatter), exactly as in the solo kernel: an infinite-mass body's velocity is re-read unchanged by every pass of the slot loop,
+        // while here the (zero) impulse is added to the lane's copy, and x + (+-0) == x bit for bit unless a component of x is a negative zero -- lanes check
+        // their infinite-mass sides once and the wave takes the slot loop if any such component exists.
+        if (!AB && __ballot((lvlmask & (lvlmask - 1u)) != 0u) == 0ull) {
+            d2 va = mk2(0.0, 0.0), vb = va, wa2 = va, wb2 = va, vba = va, vbb = va;
+            if (warm) gather(va, vb, wa2, wb2, vba, vbb);
+            auto negzero = [](double x) { return (((unsigned)__double2hiint(x) ^ 0x80000000u) | (unsigned)__double2loint(x)) == 0u; };
+            bool nz = false;
+            if (warm && A.ma == 0.0) nz = negzero(va.x) || negzero(va.y) || negzero(wa2.x);
+            if (warm && A.mb == 0.0) nz = nz || negzero(vb.x) || negzero(vb.y) || negzero(wb2.x);
+            if (!__ballot(nz)) {
+                bool going1 = lvlmask != 0u;
+                for (int it = 0; it < P.iterations; it++) {
+                    if (!__ballot(going1)) break;
+                    double chg = 0.0;
+                    PCNT(15, 1)
+                    if (going1 && warm) contacts(va, vb, wa2, wb2, vba, vbb, chg);
+                    if (going1 && !hballot(warm && chg != 0.0, h)) going1 = false;
+                }
+                if (warm) scatter(va, vb, wa2, wb2, vba, vbb);
+                lds_sync();
+                return;
+            }
+        }
         // each half walks its own colours: pass p of the loop is the half's p-th warm colour, and a half that has reached its fixed point drops out
         bool going = lvlmask != 0u;
         for (int it = 0; it < P.iterations; it++) {
@@ -969,6 +1019,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
             if (going) {
                 for (unsigned lm = lvlmask; lm; lm &= lm - 1u) {
                     const int lvl = __ffs((int)lm) - 1;
+                    PCNT(14, 1)
                     if (warm && A.level == lvl) {
                         d2 va, vb, wa2, wb2, vba, vbb;
                         gather(va, vb, wa2, wb2, vba, vbb);
@@ -983,6 +1034,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
         }
     };
     if (any_bias) iterate(std::true_type{}); else iterate(std::false_type{});
+    PPROF(8)
     // ---- 7. post-solve bookkeeping for ship(0) x floe arbiters, ascending key order ------------------------------
     {
         const bool shiparb = active && ba == 0;
@@ -1040,6 +1092,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
         if (x0 < 0.0 || x0 > P.map_w) S.boundary_violated = 1;
     }
     lds_sync();
+    PPROF(9)
     // ---- next sub-step's moving list: bodies of active arbiters with a non-zero velocity, plus the ship ----------
     {
         bool wantA = false, wantB = false;
@@ -1069,6 +1122,7 @@ __device__ __forceinline__ void substep_pair(const DevParams &P, const DevPtrs &
     }
     S.quiescent = (S.nmv == 0) && (wmask == 0);
     lds_sync();
+    PPROF(10)
 #undef Av
 #undef An
 #undef Bv
@@ -1285,6 +1339,10 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
 {
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = (int)(threadIdx.x & 63);
+#ifdef BP_PAIR_PROF
+    if (lane < 19) PPROF_SLOT(lane) = 0ull;
+    lds_sync();
+#endif
     PW W;
     W.h = lane >> 5; W.hl = lane & 31;
     W.lb = (unsigned)W.h * PL_HALF;
@@ -1358,6 +1416,14 @@ __device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, c
             }
         }
     }
+#ifdef BP_PAIR_PROF
+    if (D.prof != nullptr) {
+        lds_sync();
+        if (lane == 0) PPROF_SLOT(11) = __builtin_amdgcn_s_memtime() - t_begin;
+        lds_sync();
+        if (lane < 19) D.prof[(size_t)env0 * BP_PROFN + lane] += PPROF_SLOT(lane);
+    }
+#endif
     it_out = it;
     {
         const unsigned rate = have ? (S.costp - costp0) / (unsigned)max(it - it_first, 1) : 0u;   // mean work proxy per sub-step of this task
