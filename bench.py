@@ -138,6 +138,53 @@ def cpu_baseline_box(env, trials):
             "sample": "%d envs x %d env.step() of the same trials (heading actions U(-1,1), observation included), one thread, %.2f s" % (nenv, steps, sec)}
 
 
+def cpu_baseline_area(env, trials):
+    """area-clearing oracle on one host core: a bounded sample of the same trials with heading actions."""
+    from benchpush_amd import area_clearing_scenario as A
+    from oracle.oracle_bd import OracleAreaClearing
+
+    nenv, steps = 8, 12
+    rng = np.random.RandomState(0)
+    orcs = []
+    for e in range(nenv):
+        o = OracleAreaClearing(A.area_clearing_physics_params(env.cfg), dict(env.bd_params), env.cfg)
+        o.reset(trials[e % len(trials)], observe=False)
+        orcs.append(o)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for o in orcs:
+            o.step(float(rng.uniform(-1, 1)))
+    sec = time.perf_counter() - t0
+    return {"value": nenv * steps / sec, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d env.step() of the same trials (heading actions U(-1,1), observation included), one thread, %.2f s" % (nenv, steps, sec)}
+
+
+def cpu_baseline_maze(env, layouts):
+    """maze-NAMO oracle (oracle/bp_oracle.c) on one host core: a bounded sample of the same layouts, U(-1, 1) actions, 400 sub-steps + rotated raster per step."""
+    from oracle.oracle import OracleMaze
+
+    nenv, steps = 8, 25
+    rng = np.random.RandomState(0)
+    c = env.cfg
+    orcs = []
+    for e in range(nenv):
+        o = OracleMaze(env.params, c.robot.vertices, c.robot.wheel_vertices, c.obstacle_size)
+        o.reset(layouts[e % len(layouts)])
+        orcs.append(o)
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(steps):
+        for e, o in enumerate(orcs):
+            _, _, term, _ = o.step(float(rng.uniform(-1, 1)))
+            n += 1
+            if term:
+                o.reset(layouts[e % len(layouts)])
+    sec = time.perf_counter() - t0
+    return {"value": n / sec, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": "%d envs x %d env.step() of the same layouts (20 boxes, U(-1,1) actions, observation included; resets inside the loop), one thread, %.2f s"
+                      % (nenv, steps, sec)}
+
+
 def spawn_ranks(n):
     """Start `n` ranks of this script (one per GPU) as a child `torch.distributed.run` on 127.0.0.1 and return its exit code.
 
@@ -455,6 +502,12 @@ def main():
                                  "12.5 ms at 1024 envs, 13.3 at 2048, 16.0 at 4096), so fixed E = 4096 over N GPUs gains at most ~1.3 x"}
         env_s.close()
 
+    pairing = None
+    if rank == 0 and args.env == "ship-ice" and hasattr(env, "pair_stats") and hasattr(env.L, "bp_get_pair_stats"):
+        ps = env.pair_stats()
+        if ps["mode"]:
+            pairing = dict(ps, what="two environments per wavefront (lanes 0..31 / 32..63, one instruction stream; DESIGN.md section 4p): light envs advance in pairs, "
+                                    "heavy ones alone; counters are cumulative since load (warm-up, timed and steady-state steps); BP_PAIR=0 turns it off")
     if rank == 0:
         sched_chunk = int(env.L.bp_sched_chunk(env.h)) if hasattr(env, "L") and hasattr(env.L, "bp_sched_chunk") else 0
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
@@ -470,7 +523,9 @@ def main():
             "clock_mhz": (clock_hz / 1e6) if clock_hz else None,
             "clock_source": ("s_memtime / s_memrealtime stamps of XCD %d around the timed launches" % clock_xcd) if clock_hz else
                             "no stamp pair from one XCD: issue.frac uses the nominal 2.1 GHz",
-            "kernel": ("k_physics_step_sched" if sched_chunk > 0 else "k_physics_step"),
+            "kernel": (("k_physics_step_sched_maze" if args.env == "maze" else "k_physics_step_sched") if sched_chunk > 0 else
+                       ("k_physics_step_maze" if args.env == "maze" else "k_physics_step")),
+            "pairing": pairing,
             "scheduler": ({"chunk_substeps": sched_chunk, "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
                            "least-advanced waiting env first (DESIGN.md 4a); BP_SCHED=0 selects one wavefront per env for the whole step"}
                           if sched_chunk > 0 else None),
@@ -479,8 +534,10 @@ def main():
             "binds": "wave issue slots and dependent-instruction latency of one wavefront per env, not HBM and not MFMA: the state stays "
                      "on-chip for the 400 sub-steps; with the preemptive scheduler the launch is within a few per cent of BOTH the chain of its "
                      "heaviest env and the sum of all chains / 2048 wave slots (DESIGN.md section 4a)",
-            "raster_kernel": {"kernel": "k_observe", "achieved": 4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 if rast_ms > 0 else None,
-                              "ms": rast_ms, "frac": (4 * 150 * 150 * E / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rast_ms > 0 else None},
+            "raster_kernel": {"kernel": {"ship-ice": "k_observe", "maze": "k_observe_maze"}.get(args.env, "k_bd_observe"),
+                              "bytes_written_per_env": int(np.prod(env.obs_shape)),
+                              "achieved": int(np.prod(env.obs_shape)) * E / (rast_ms * 1e-3) / 1e9 if rast_ms > 0 else None,
+                              "ms": rast_ms, "frac": (int(np.prod(env.obs_shape)) * E / (rast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if rast_ms > 0 else None},
             "physics_ms": phys_ms, "launches": nlaunch,
             "bytes_per_env_step": {"A_min": a_min, "A_stream": a_stream, "k_physics_min": a_phys},
             "hypothetical_stream_design": {"GB/s": (a_stream - 4 * 150 * 150) * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
@@ -555,8 +612,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(env, trials)
             out["cpu_baseline"]["single_thread"] = cpu_baseline_single_thread(env)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
-        if world == 1 and not args.no_cpu_baseline and args.env == "box":
-            out["cpu_baseline"] = cpu_baseline_box(env, trials)
+        if world == 1 and not args.no_cpu_baseline and args.env in ("box", "area", "maze"):
+            out["cpu_baseline"] = {"box": cpu_baseline_box, "area": cpu_baseline_area, "maze": cpu_baseline_maze}[args.env](env, trials)
             out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         if _IGNORED_ERRORS:
             out["invalid"] = "capacity errors ignored (BP_BENCH_IGNORE_CAPACITY=1): experiment line, not a result"

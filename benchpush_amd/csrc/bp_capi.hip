@@ -354,9 +354,11 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
               h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn;
-              int *d_sub;
+              int *d_sub, *d_pst;
               if ((rc = dalloc(h, &d_sub, (size_t)h->num_envs))) return rc;
-              h->D.sq_sub = d_sub; }
+              if ((rc = dalloc(h, &d_pst, (size_t)8))) return rc;
+              HIPCHK(h, hipMemset(d_pst, 0, 8 * sizeof(int)));
+              h->D.sq_sub = d_sub; h->D.sq_pairstat = d_pst; }
 #ifdef BP_DEBUG_PATHS   // fault injection lives in the diagnostic twin only: a stray variable in a job environment cannot disturb the product library
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
 #endif
@@ -513,6 +515,14 @@ int bp_load_maze(bp_handle *h, int32_t T, int32_t nbox, const double *centres, i
     HIPCHK(h, hipMemcpy(d_norm, norm.data(), sizeof(double) * norm.size(), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(d_wall, wall.data(), wall.size(), hipMemcpyHostToDevice));
     h->D.dist_map = d_norm; h->D.wall_map = d_wall;
+    {   // the observer's packed copy: sign = wall, magnitude = normalised distance (a wall cell's distance is exactly 1.0, never a zero)
+        std::vector<double> packed(norm.size());
+        for (size_t i = 0; i < norm.size(); i++) packed[i] = wall[i] ? -norm[i] : norm[i];
+        double *d_pk;
+        if ((rc = dalloc(h, &d_pk, packed.size()))) return rc;
+        HIPCHK(h, hipMemcpy(d_pk, packed.data(), sizeof(double) * packed.size(), hipMemcpyHostToDevice));
+        h->D.maze_obs_map = d_pk;
+    }
     double *d_raw;
     if ((rc = dalloc(h, &d_raw, h->goal_raw.size()))) return rc;
     HIPCHK(h, hipMemcpy(d_raw, h->goal_raw.data(), sizeof(double) * h->goal_raw.size(), hipMemcpyHostToDevice));
@@ -1309,6 +1319,22 @@ int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
 }
 
 int32_t bp_pair_mode(bp_handle *h) { return h ? h->pair_mode : 0; }
+
+int bp_get_pair_stats(bp_handle *h, int32_t *out16_host)
+{
+    if (!h || !out16_host) return BP_EINVAL;
+    if (!h->loaded) return fail(h, BP_ESTATE, "not loaded");
+    BP_DEVICE(h);
+    const DevParams &P = h->P;
+    const int32_t par[8] = {h->pair_mode, P.pair_solo, P.pp_max_keys, P.pp_max_slots, P.pp_max_mv, P.pp_max_act, P.pp_max_work, P.pp_rate};
+    memcpy(out16_host, par, sizeof(par));
+    memset(out16_host + 8, 0, 8 * sizeof(int32_t));
+    if (h->D.sq_pairstat != nullptr) {
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, hipMemcpy(out16_host + 8, h->D.sq_pairstat, 8 * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return BP_OK;
+}
 
 int bp_sched_warnings(bp_handle *h, int32_t *out2_host)
 {

@@ -61,6 +61,7 @@ struct DevPtrs {
     const double *dist_map;  // maze: normalised BFS goal map [grid_h][grid_w]
     const unsigned char *wall_map; // maze: wall raster [grid_h][grid_w]
     const double *goal_raw;  // maze: un-normalised wavefront map (info['goal_dt']) [grid_h][grid_w]
+    const double *maze_obs_map; // maze: dist_map with the wall raster in the sign bit (wall cells: -1.0), one load per cell for k_observe_maze
     // env state
     int *e_trial, *e_episode, *e_nb, *e_err;
     int *e_flags;            // [E] maze: bit0 wall_collision (sticky), bit1 prev_dist valid
@@ -78,7 +79,8 @@ struct DevPtrs {
     int *sq_done;            // [E] the env's step is complete (cleared by k_sched_init)
     int *sq_lev;             // [E] chunks completed when the env was last parked
     int *sq_sub;             // [E] sub-steps of the current step completed when the env was last parked (0: not parked in this step); cleared by k_sched_init
-    int *sq_pairctr;         // [2] next pair task of the scheduled launch, pairs started
+    int *sq_pairstat;        // [8] cumulative: paired first tasks, paired tasks taken from the queues, halves that finished their step in a pair, halves that left as
+                             //     heavy (carried on alone in the same slot), heavy halves queued, light halves queued (split mates + yields), tasks declined at load, -
     int *sq_rescue;          // [1 + SQ_RESCUE] count and ids of the envs the scheduled launch left unfinished (k_sched_scan)
     int *sq_warn;            // [2] scheduler watchdog events, envs finished by the completion launch (cumulative; bp_sched_warnings)
     d2 *pxy;                 // [E][nbcap] position of COG

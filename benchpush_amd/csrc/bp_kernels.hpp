@@ -815,12 +815,22 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
             if (nfin) atomicAdd(sq_finished(D), nfin);
         }
         const bool pk0 = st0 == 2, pk1 = st1 == 2;
+        if (lane == 0 && D.sq_pairstat != nullptr) {
+            atomicAdd(&D.sq_pairstat[(int)blockIdx.x < nfirst ? 0 : 1], 1);
+            if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
+        }
         if (!pk0 && !pk1) return;
         // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
         const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
         if (lane == 0) {
             if (pk0 && !c0) { D.sq_lev[pe0] = it0 / P.sq_chunk; sq_push(P, D, x + (hv0 ? 0 : 8), it0 / P.sq_chunk, pe0); }
             if (pk1 && !c1) { D.sq_lev[pe1] = it1 / P.sq_chunk; sq_push(P, D, x + (hv1 ? 0 : 8), it1 / P.sq_chunk, pe1); }
+            if (D.sq_pairstat != nullptr) {
+                if (c0 || c1) atomicAdd(&D.sq_pairstat[3], 1);
+                const int qh = ((pk0 && !c0 && hv0) ? 1 : 0) + ((pk1 && !c1 && hv1) ? 1 : 0), ql = ((pk0 && !c0 && !hv0) ? 1 : 0) + ((pk1 && !c1 && !hv1) ? 1 : 0);
+                if (qh) atomicAdd(&D.sq_pairstat[4], qh);
+                if (ql) atomicAdd(&D.sq_pairstat[5], ql);
+            }
         }
         if (!c0 && !c1) return;
         item = (c0 ? pe0 : pe1) | (3 << 24);   // top issue priority: it left its pair because it is heavy
@@ -1550,6 +1560,7 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe_maze(const DevParams P,
     __syncthreads();
     const int nbox = min(s_nbox, MZ_MAXBOX);
     if (tid == 0 && s_nbox > MZ_MAXBOX) atomicOr(&D.e_err[env], BP_ERR_LEVEL_OVERFLOW);
+
     for (int kx = 0; kx < nbox; kx++) {
         const int r0 = s_bbx[kx][0], r1 = s_bbx[kx][1], c0 = s_bbx[kx][2], c1 = s_bbx[kx][3];
         const int wbox = c1 - c0 + 1, npx = (r1 - r0 + 1) * wbox;
@@ -1586,46 +1597,83 @@ __global__ __launch_bounds__(OBS_THREADS) void k_observe_maze(const DevParams P,
     const int half = infl / 2;
     const size_t plane = (size_t)LH * LW;
     unsigned char *o = obs + (size_t)env * BP_OBS_C * plane;
-    for (int px = tid; px < LH * LW; px += OBS_THREADS) {
-        const int oi = px / LW, oj = px - oi * LW;
-        const int i = half + oi, j = half + oj;
+    // one output pixel = scipy's order-1 sample of the four channels (2 x 2 cells, per-cell ((v * w_row) * w_col) accumulated row-major); a thread takes four
+    // neighbouring pixels of a row and stores one 32-bit word per channel (byte stores were a quarter of this kernel's instructions)
+    // Branch-free: the sixteen cell reads of a thread's four pixels (one global word + two LDS words each) are issued together instead of one dependent
+    // round trip per cell behind a branch; cells outside the window or the map are read at a clamped address and replaced by the channels' cval.
+    // One output pixel = scipy's order-1 sample of the four channels (2 x 2 cells, per-cell ((v * w_row) * w_col) accumulated row-major).  Footprint, boxes
+    // and walls are 0 / 1: 1 * w_row is w_row and 0 * w is +0, which a non-negative sum absorbs bit for bit, so those three channels add the cell's weight
+    // product or nothing; the distance channel keeps its two products.  Walls and distances come from ONE word per cell (sign = wall, magnitude = normalised
+    // distance, bp_load_maze).  Branch-free: cells outside the window or the map are read at a clamped address and replaced by the channels' cval.  A thread
+    // takes four neighbouring pixels of a row and stores one 32-bit word per channel.  The kernel is bound by its arithmetic (about 700 cycles per 64 pixels,
+    // a good part of it quarter-rate int <-> double conversions), not by memory: without any load or store it still takes 0.94 of 1.17 ms (r05 variants:
+    // two-phase fetch / blend, 8 x 8 output tiles per wavefront and a wave-level skip of the empty binary channels were all slower or equal).
+    const int nbits = IH * IW;
+    auto sample = [&](const double di, const double dj, unsigned &b0, unsigned &b1, unsigned &b2, unsigned &b3) {
         double c0 = 0.0, c1 = 0.0;
-        c0 += (double)i * rc; c0 += (double)j * rs; c0 += off0;
-        c1 += (double)i * -rs; c1 += (double)j * rc; c1 += off1;
-        double t0, t1, t2, t3;
-        if (c0 < 0 || c0 > IH - 1 || c1 < 0 || c1 > IW - 1) { t0 = 0.0; t1 = 0.0; t2 = 0.0; t3 = 1.0; }
-        else {
-            const int s0 = (int)__builtin_floor(c0), s1 = (int)__builtin_floor(c1);
-            const double x0 = c0 - s0, x1 = c1 - s1;
-            const double w0[2] = {1.0 - x0, x0}, w1[2] = {1.0 - x1, x1};
-            t0 = t1 = t2 = t3 = 0.0;
+        c0 += di * rc; c0 += dj * rs; c0 += off0;
+        c1 += di * -rs; c1 += dj * rc; c1 += off1;
+        const bool outside = (c0 < 0 || c0 > IH - 1 || c1 < 0 || c1 > IW - 1);
+        const double c0c = outside ? 0.0 : c0, c1c = outside ? 0.0 : c1;
+        const double fl0 = __builtin_floor(c0c), fl1 = __builtin_floor(c1c);   // the double of the integer cell index: x = c - floor(c) needs no conversion back
+        const int s0 = (int)fl0, s1 = (int)fl1;
+        const double x0 = c0c - fl0, x1 = c1c - fl1;
+        const double w0[2] = {1.0 - x0, x0}, w1[2] = {1.0 - x1, x1};
+        double pm[4];
+        unsigned wf[4], wb[4];
+        bool in[4];
+        int sh[4];
 #pragma unroll
-            for (int a = 0; a < 2; a++)
-#pragma unroll
-                for (int b = 0; b < 2; b++) {
-                    const int ii = s0 + a, jj = s1 + b;
-                    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 1.0; // cval of the four channels
-                    if (!(ii > IH - 1 || jj > IW - 1)) {
-                        const int gi = gi0 + ii, gj = gj0 + jj;
-                        if (!(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg)) { // outside the map the window keeps its initial values
-                            const int bit = ii * IW + jj;
-                            v0 = ((s_foot[bit >> 5] >> (bit & 31)) & 1u) ? 1.0 : 0.0;
-                            v1 = ((s_box[bit >> 5] >> (bit & 31)) & 1u) ? 1.0 : 0.0;
-                            v2 = D.wall_map[(size_t)gi * Wg + gj] ? 1.0 : 0.0;
-                            v3 = D.dist_map[(size_t)gi * Wg + gj];
-                        }
-                    }
-                    double q0 = v0, q1 = v1, q2 = v2, q3 = v3;
-                    q0 *= w0[a]; q0 *= w1[b]; t0 += q0;
-                    q1 *= w0[a]; q1 *= w1[b]; t1 += q1;
-                    q2 *= w0[a]; q2 *= w1[b]; t2 += q2;
-                    q3 *= w0[a]; q3 *= w1[b]; t3 += q3;
-                }
+        for (int k = 0; k < 4; k++) {
+            const int ii = s0 + (k >> 1), jj = s1 + (k & 1);
+            const int gi = gi0 + ii, gj = gj0 + jj;
+            in[k] = !(ii > IH - 1 || jj > IW - 1) && !(gi < 0 || gi >= Hg || gj < 0 || gj >= Wg);   // outside the map the window keeps its initial values
+            const int gic = min(max(gi, 0), Hg - 1), gjc = min(max(gj, 0), Wg - 1);
+            const int bit = min(max(ii * IW + jj, 0), nbits - 1);
+            sh[k] = bit & 31;
+            pm[k] = *(const double *)((const char *)D.maze_obs_map + (size_t)((unsigned)(gic * Wg + gjc) * 8u));
+            wf[k] = s_foot[bit >> 5]; wb[k] = s_box[bit >> 5];
         }
-        o[0 * plane + px] = (unsigned char)(t0 * 255);
-        o[1 * plane + px] = (unsigned char)(t1 * 255);
-        o[2 * plane + px] = (unsigned char)(t2 * 255);
-        o[3 * plane + px] = (unsigned char)(t3 * 255);
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int a = k >> 1, b = k & 1;
+            const double ww = w0[a] * w1[b];
+            const bool f0 = in[k] && ((wf[k] >> sh[k]) & 1u) != 0u, f1 = in[k] && ((wb[k] >> sh[k]) & 1u) != 0u, f2 = in[k] && pm[k] < 0.0;
+            const double v3 = in[k] ? __builtin_fabs(pm[k]) : 1.0;   // cval of the distance channel
+            t0 += f0 ? ww : 0.0;
+            t1 += f1 ? ww : 0.0;
+            t2 += f2 ? ww : 0.0;
+            double q3 = v3;
+            q3 *= w0[a]; q3 *= w1[b]; t3 += q3;
+        }
+        if (outside) { t0 = 0.0; t1 = 0.0; t2 = 0.0; t3 = 1.0; }
+        b0 = (unsigned)(unsigned char)(t0 * 255); b1 = (unsigned)(unsigned char)(t1 * 255);
+        b2 = (unsigned)(unsigned char)(t2 * 255); b3 = (unsigned)(unsigned char)(t3 * 255);
+    };
+    if ((LW & 3) == 0) {
+        unsigned *o32 = (unsigned *)o;
+        const int wpr = LW / 4;
+        for (int w = tid; w < LH * wpr; w += OBS_THREADS) {
+            const int oi = w / wpr, oj = (w - oi * wpr) * 4;
+            const double di = (double)(half + oi), dj = (double)(half + oj);   // small integers: dj + k is exactly (double)(j + k)
+            unsigned p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned b0, b1, b2, b3;
+                sample(di, dj + (double)k, b0, b1, b2, b3);
+                p0 |= b0 << (8 * k); p1 |= b1 << (8 * k); p2 |= b2 << (8 * k); p3 |= b3 << (8 * k);
+            }
+            const size_t wi = (size_t)oi * wpr + (oj >> 2);
+            o32[0 * (plane / 4) + wi] = p0; o32[1 * (plane / 4) + wi] = p1; o32[2 * (plane / 4) + wi] = p2; o32[3 * (plane / 4) + wi] = p3;
+        }
+    } else {
+        for (int px = tid; px < LH * LW; px += OBS_THREADS) {
+            const int oi = px / LW, oj = px - oi * LW;
+            unsigned b0, b1, b2, b3;
+            sample((double)(half + oi), (double)(half + oj), b0, b1, b2, b3);
+            o[0 * plane + px] = (unsigned char)b0; o[1 * plane + px] = (unsigned char)b1; o[2 * plane + px] = (unsigned char)b2; o[3 * plane + px] = (unsigned char)b3;
+        }
     }
 }
 

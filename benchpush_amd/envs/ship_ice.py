@@ -277,6 +277,14 @@ class BatchedShipIceEnv(_BatchedBase):
         _lib.check(self.L, self.h, self.L.bp_sched_warnings(self.h, out.ctypes.data_as(C.c_void_p)), "bp_sched_warnings")
         return int(out[0]), int(out[1])
 
+    def pair_stats(self):
+        """Two environments per wavefront (bp_get_pair_stats): dict of the pairing mode and limits, and the cumulative counters since load."""
+        out = np.zeros(16, np.int32)
+        _lib.check(self.L, self.h, self.L.bp_get_pair_stats(self.h, out.ctypes.data_as(C.c_void_p)), "bp_get_pair_stats")
+        keys = ["mode", "solo_first", "max_arbiter_lanes", "max_velocity_slots", "max_moving", "max_active", "max_warm_x_colours", "max_work_rate",
+                "paired_first_tasks", "paired_tasks_from_queues", "envs_finished_in_a_pair", "envs_left_as_heavy", "heavy_envs_queued", "light_envs_queued"]
+        return dict(zip(keys, out.tolist()))
+
     def sched_chunk(self):
         """Sub-steps per chunk of the preemptive step scheduler, 0 = one wavefront per env for the whole step."""
         return int(self.L.bp_sched_chunk(self.h))

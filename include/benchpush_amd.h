@@ -242,6 +242,11 @@ int32_t bp_sched_chunk(bp_handle *h);
  * dispatch order start alone, the others in pairs, and an env that outgrows the half-wave capacities or turns heavy is parked at a sub-step boundary and
  * resumed in a wavefront of its own.  Environment variable BP_PAIR=<mode> selects it at load time.  ABI 9. */
 int32_t bp_pair_mode(bp_handle *h);
+/* Parameters and cumulative counters of the pairing (host int32 [16], synchronises): [0..7] = mode, envs of the dispatch order that start alone, and the
+ * limits above which an env leaves its pair (arbiter lanes, velocity slots, moving bodies, active arbiters, warm arbiters x colours, work proxy per
+ * sub-step); [8..15] = since load: paired first tasks, paired tasks formed from the queues, envs that finished their step in a pair, envs that left a pair
+ * as heavy and carried on alone in the same wave slot, heavy envs queued, light envs queued (mates of split pairs and yields), -, -.  ABI 9. */
+int bp_get_pair_stats(bp_handle *h, int32_t *out16_host);
 /* Clock calibration for bench.py: the shader-clock counter (s_memtime) and the 100 MHz reference counter (s_memrealtime) stamped on the device right
  * after every physics launch of bp_step / bp_reset (ship-ice and maze handles) by one thread, filed under the XCD it ran on (the shader-clock counters
  * of different XCDs are not synchronised): out[x][0..1] = the latest pair taken on XCD x, zeros if none yet.  The clock the chip held between two
