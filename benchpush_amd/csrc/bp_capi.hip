@@ -324,9 +324,12 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         const bool can_pair = plain && nbcap <= PP_NBCAP &&
                               ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_MAXV * sizeof(d2) < (size_t)0xFFFFFFFF &&   // 32-bit byte offsets (gA)
                               ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_KADJ * sizeof(unsigned long long) < (size_t)0xFFFFFFFF;
-        // Default: inside the scheduler (mode 2) from 2 560 envs up -- below, every env has a wave slot of its own from the first cycle and the launch is the
-        // chain of its heaviest env, which a mate can only lengthen (2 048 envs: -2 %).  BP_PAIR=0 / 1 / 2 overrides.
-        if (can_pair && h->num_envs > 2560) h->pair_mode = 2;
+        // Default: inside the scheduler (mode 2) from 6 144 envs per GPU up, where a launch is throughput (+8 % at 6 144, +34 % at 8 192, +30 % at 16 384
+        // env-steps/s, same box).  Below, the launch follows the chains of its heaviest envs and the scheduler's rotation, not the sum of the work: pairing
+        // the light envs saves a tenth of the wave-instructions and moves the launch by 0 ... +2.5 % at 4 096 envs (profiles/r05_pair/), -2 % at 2 048 --
+        // and the kernel that holds both step bodies runs the solo body 6 % slower -- so those handles keep the lean one-env-per-wavefront scheduler kernel.
+        // BP_PAIR=0 / 1 / 2 overrides.
+        if (can_pair && h->num_envs >= 6144) h->pair_mode = 2;
         if (const char *evp = getenv("BP_PAIR")) h->pair_mode = can_pair ? atoi(evp) : 0;
         if (h->pair_mode == 1) {
             h->P.pair_mode = 1;
@@ -377,9 +380,12 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 h->P.pp_max_act = envint("BP_PP_ACT", tight ? 16 : 30);
                 h->P.pp_max_work = envint("BP_PP_WORK", tight ? 9 : 100);
                 h->P.pp_rate = envint("BP_PP_RATE", tight ? 70 : 1000);
+                h->P.pp_snake = envint("BP_PP_SNAKE", 0);
+                h->P.pp_heavy_only = envint("BP_PP_HEAVY_ONLY", 0);
                 h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));
             }
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         }
     }
     if (h->pair_mode == 2 && h->P.pair_mode != 2) h->pair_mode = 0;   // pairing inside the scheduler needs the scheduler
@@ -678,7 +684,25 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             HIPCHK(h, hipGetLastError());
             if (h->maze8)
                 hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
-            else
+            else if (h->P.pair_mode == 2) {
+                // a pairing launch is two kernels side by side: the envs that start alone on the lean solo code (second stream), everything else -- paired
+                // first tasks, the workgroups that serve the queues -- in the kernel that holds both step bodies
+                if (!h->st_aux) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+                }
+                if (h->P.pair_solo > 0) {
+                    HIPCHK(h, hipEventRecord(h->ev_fork, st));
+                    HIPCHK(h, hipStreamWaitEvent(h->st_aux, h->ev_fork, 0));
+                    hipLaunchKernelGGL(k_physics_step_sched, dim3(h->P.pair_solo), dim3(64), h->lds_bytes, h->st_aux, h->P, h->D, actions, reward, term, trunc, info);
+                    HIPCHK(h, hipGetLastError());
+                    HIPCHK(h, hipEventRecord(h->ev_join, h->st_aux));
+                }
+                hipLaunchKernelGGL(k_physics_step_schedp, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+                HIPCHK(h, hipGetLastError());
+                if (h->P.pair_solo > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+            } else
                 hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             HIPCHK(h, hipGetLastError());
             // completion launch: workgroup b finishes the b-th env that the scheduled launch left unfinished (scheduler watchdog); normally all leave at once

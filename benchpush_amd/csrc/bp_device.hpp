@@ -41,6 +41,7 @@ struct DevParams {
     // 2 inside the preemptive scheduler (the pair_solo heaviest envs of the dispatch order start alone, the others in pairs)
     int pair_mode, pair_solo;
     int pp_max_keys, pp_max_slots, pp_max_mv, pp_max_act, pp_max_work;   // when a half leaves its pair (pair_should_leave)
+    int pp_snake, pp_heavy_only;               // pairing order heaviest-with-lightest; waves yield only to waiting HEAVY envs
     int pp_rate;                               // an env whose mean work proxy per sub-step (S.costp) is above this is parked as heavy: it carries on alone
     int random_start;                          // ship-ice: per-episode start x from the counter RNG (ship_ice_env.py:201-203)
     double start_x_range, ship_mass;

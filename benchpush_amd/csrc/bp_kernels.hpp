@@ -267,7 +267,8 @@ __device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevP
     bool any = sq_ld(sq_started(D)) < P.num_envs;
     if (!any && sq_ld(sq_waiting(D, x)) > 0)
         for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
-    if (!any && P.pair_mode == 2 && sq_ld(sq_waiting(D, x + 8)) > 0)
+    // (P.pp_heavy_only: light envs that wait are background work for the slots that free up -- nobody parks itself for them)
+    if (!any && P.pair_mode == 2 && !P.pp_heavy_only && sq_ld(sq_waiting(D, x + 8)) > 0)
         for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x + 8, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
     return any;
 }
@@ -729,7 +730,12 @@ __global__ __launch_bounds__(256) void k_sched_scan(const DevParams P, const Dev
 // the least-advanced-first rule anyway, and workgroups are dispatched in index order); every later workgroup takes the least-advanced waiting env of
 // its XCD, waits if there is none yet, helps another XCD after a few empty polls, and leaves without work only when every env has finished (most of
 // the grid does: only parked envs need a second workgroup).  An env's home XCD is the one its first chunk ran on.
-template <int KIND>
+// ROLE 0: the scheduler with one env per wavefront only (no paired code in the kernel).  ROLE 1 (k_physics_step_schedp): the paired first tasks, every
+// workgroup that starts from the queues, and the solo continuation of split pairs.  The two roles are two kernels because they cannot share one register
+// allocation without loss: with the paired path inlined beside it the solo step body picked up ~100 scratch accesses and ran 6 % slower (230 k against
+// 245 k env-steps/s with pairing switched off, same box) -- and the solo body is the chain of the heaviest envs.  A pairing launch runs both kernels side by
+// side on two streams: ROLE 0 with exactly P.pair_solo workgroups (the envs that start alone, on the lean code), ROLE 1 with the rest.
+template <int KIND, int ROLE = 0>
 __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
@@ -745,9 +751,12 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     // half-wave) parks both envs at that sub-step boundary, carries on with the heavy one alone in the same slot and queues its mate; paired and solo waves
     // alike yield at chunk boundaries to envs that are further behind; and an env that is light when it is parked waits in a queue of its own kind, from
     // which a starting workgroup takes two at a time.
-    const bool pairing = KIND == BP_ENV_SHIP_ICE && P.pair_mode == 2 && !completion;
+    const bool pairing = ROLE == 1 && KIND == BP_ENV_SHIP_ICE && P.pair_mode == 2 && !completion;
     const int npairs = pairing ? (P.num_envs - P.pair_solo + 1) / 2 : 0;
-    const int nfirst = pairing ? P.pair_solo + npairs : P.num_envs;     // workgroups that start envs without touching a queue
+    // workgroups that start envs without touching a queue: ROLE 1 numbers its workgroups from P.pair_solo on (the first P.pair_solo positions of the dispatch
+    // order are the ROLE 0 kernel's, launched beside it)
+    const int bid = (int)blockIdx.x + (ROLE == 1 ? P.pair_solo : 0);
+    const int nfirst = pairing ? P.pair_solo + npairs : P.num_envs;
     if (completion) {
         // Completion launch (always follows the scheduled one and k_sched_scan, SQ_RESCUE workgroups): workgroup b takes the b-th env of the list of
         // unfinished envs and leaves at once if the list is shorter -- the normal case: it is empty.  After a scheduler fault (watchdog) such an env's
@@ -755,13 +764,15 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         if ((int)blockIdx.x >= D.sq_rescue[0]) return;
         item = D.sq_rescue[1 + blockIdx.x]; lev = D.sq_lev[item];
         if (lane == 0) atomicAdd(&D.sq_warn[1], 1);
-    } else if (pairing && (int)blockIdx.x >= P.pair_solo && (int)blockIdx.x < nfirst) {
-        const int p0 = P.pair_solo + 2 * ((int)blockIdx.x - P.pair_solo), p1 = p0 + 1;
+    } else if (pairing && bid >= P.pair_solo && bid < nfirst) {
+        // neighbours of the dispatch order (similar envs share trip counts), or -- P.pp_snake -- the heaviest with the lightest: a heavy env declines its
+        // pair at once and carries on alone from the first cycle, and the mate that has to wait for a wave slot is then one with slack
+        const int p0 = P.pp_snake ? bid : P.pair_solo + 2 * (bid - P.pair_solo), p1 = P.pp_snake ? P.num_envs - 1 - (bid - P.pair_solo) : p0 + 1;
         pe0 = D.order != nullptr ? D.order[p0] : p0;
-        pe1 = p1 < P.num_envs ? (D.order != nullptr ? D.order[p1] : p1) : -1;
+        pe1 = (p1 < P.num_envs && p1 != p0) ? (D.order != nullptr ? D.order[p1] : p1) : -1;
         if (lane == 0) atomicAdd(sq_started(D), pe1 >= 0 ? 2 : 1);
-    } else if ((int)blockIdx.x < nfirst) {
-        const int pos = (int)blockIdx.x;
+    } else if (bid < nfirst) {
+        const int pos = bid;
         // issue-priority class of the env for the whole step: the heaviest quarter of the predicted order 3, the next quarter 1
         const int cls = (pos < P.num_envs / 4) ? 3 : (pos < P.num_envs / 2) ? 1 : 0;
         item = (D.order != nullptr ? D.order[pos] : pos) | (cls << 24);
@@ -781,7 +792,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
                 for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
             }
             // a light env takes a second light one of the same XCD along: the least advanced that waits, from its own level upwards
-            if (item >= 0 && kind == 1 && sq_ld(sq_waiting(D, x + 8)) > 0)
+            if (ROLE == 1 && item >= 0 && kind == 1 && sq_ld(sq_waiting(D, x + 8)) > 0)
                 for (int l = lev; l < P.sq_levels && mate < 0; l++) mate = sq_pop_level(P, D, x + 8, l);
         }
         item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
@@ -789,7 +800,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         if (item < 0) return;
         if (mate >= 0) { pe0 = item & 0xFFFFFF; pe1 = mate & 0xFFFFFF; item = -1; }
     }
-    if (pe0 >= 0) {
+    if (ROLE == 1 && pe0 >= 0) {
         // ---- a paired task ----
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the envs' arrays as the waves that parked them left them
         PairLimits Q;
@@ -816,7 +827,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         }
         const bool pk0 = st0 == 2, pk1 = st1 == 2;
         if (lane == 0 && D.sq_pairstat != nullptr) {
-            atomicAdd(&D.sq_pairstat[(int)blockIdx.x < nfirst ? 0 : 1], 1);
+            atomicAdd(&D.sq_pairstat[bid < nfirst ? 0 : 1], 1);
             if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
         }
         if (!pk0 && !pk1) return;
@@ -850,7 +861,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         if (done) { D.sq_done[env] = 1; if (!completion) atomicAdd(sq_finished(D), 1); }
         else {
             D.sq_lev[env] = lev_out;
-            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((pairing && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
+            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((P.pair_mode == 2 && !completion && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
         }
     }
 }
@@ -861,7 +872,15 @@ __global__ __launch_bounds__(64, BP_SCHED_WAVES) void k_physics_step_sched(const
                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
-    sched_body<0>(P, D, actions, reward, terminated, truncated, info);
+    sched_body<0, 0>(P, D, actions, reward, terminated, truncated, info);
+}
+// the paired half of a pairing launch (two environments per wavefront, bp_physics_pair.hpp): runs beside k_physics_step_sched, which starts the P.pair_solo
+// envs that begin alone
+__global__ __launch_bounds__(64, 2) void k_physics_step_schedp(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
+                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_body<0, 1>(P, D, actions, reward, terminated, truncated, info);
 }
 __global__ __launch_bounds__(64, 2) void k_physics_step_sched_maze(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                                 double *__restrict__ reward, unsigned char *__restrict__ terminated,

@@ -16,6 +16,11 @@
 #pragma once
 #include "bp_physics.hpp"
 
+// pair_task is inlined into the scheduler kernel beside the solo step body (as a function of its own -- __attribute__((noinline)) -- the launch was 20 %
+// slower: 1.7 KB of stack per lane for the by-value structs)
+#ifndef BP_PAIR_TASK_INLINE
+#define BP_PAIR_TASK_INLINE __forceinline__
+#endif
 #define PP_NSLOT 40        // velocity slots per half (+ 1 scratch slot)
 #define PP_QCAP 48         // support queries per batch
 #define PP_MBOX 8          // manifold mailbox entries per hand-over batch
@@ -1332,7 +1337,7 @@ __device__ __forceinline__ bool pair_should_leave(const PState &S, const PairLim
 // One paired task: up to two envs (env1 may be -1), each from its own sub-step `it` on, to the end of the env step or until it leaves the pair.
 // Returns per half (in the lane's registers): status 1 = step complete (outputs written), 2 = parked at sub-step *it_out, 0 = no env.
 template <bool CAN_LEAVE, typename BehindFn>
-__device__ __forceinline__ int pair_task(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions, double *__restrict__ reward,
+__device__ BP_PAIR_TASK_INLINE int pair_task(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions, double *__restrict__ reward,
                                          unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated, double *__restrict__ info,
                                          const int env0, const int env1, const PairLimits Q, int &it_out, int &score_out, int &heavy_out,
                                          BehindFn behind)
