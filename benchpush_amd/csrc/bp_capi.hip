@@ -342,6 +342,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch;
+            h->P.sq_hold = getenv("BP_SCHED_HOLD") ? atoi(getenv("BP_SCHED_HOLD")) : 0;
             h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
             if ((rc = dalloc(h, &d_items, (size_t)SQ_NX * SQ_MAXLEV * h->P.sq_cap))) return rc;

@@ -262,9 +262,10 @@ __device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, co
     atomicAdd(sq_waiting(D, xk), 1);
 }
 // lane 0: is some env behind one that has completed `lev` chunks?  Envs whose first chunk has not been dispatched yet are behind everybody.
-__device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevPtrs &D, const int x, const int lev)
+// `hold`: the caller keeps its slot against envs that merely have not started yet (it still yields to envs that wait in the queues)
+__device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevPtrs &D, const int x, const int lev, const bool hold = false)
 {
-    bool any = sq_ld(sq_started(D)) < P.num_envs;
+    bool any = !hold && sq_ld(sq_started(D)) < P.num_envs;
     if (!any && sq_ld(sq_waiting(D, x)) > 0)
         for (int l = 0; l < lev; l++) { const int *ctr = sq_row(D, x, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
     // (P.pp_heavy_only: light envs that wait are background work for the slots that free up -- nobody parks itself for them)
@@ -281,7 +282,8 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                                              const unsigned char *__restrict__ mask, double *__restrict__ reward,
                                              unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated,
                                              double *__restrict__ info, const int tmpl, const int boff = 0, const int c_env = 0, const int c_lev = 0,
-                                             const int c_x = 0, int *c_lev_out = nullptr, const bool c_noyield = false, int *c_light_out = nullptr)
+                                             const int c_x = 0, int *c_lev_out = nullptr, const bool c_noyield = false, int *c_light_out = nullptr,
+                                             const bool c_hold = false)
 {
     // MODE_RESET with tmpl != 0 settles the per-trial reset templates: state slot num_envs + t holds trial t
     // MODE_STEP: workgroup b steps the env at position boff + b of the dispatch order
@@ -439,7 +441,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (CHUNKED) {
             if (to_boundary == 0) { // chunk boundary: yield to an env that is further behind, otherwise carry on without a context switch
                 int yield = 0;
-                if (lane == 0 && !c_noyield) yield = (sq_someone_behind(P, D, c_x, it / P.sq_chunk) || (P.sq_debug && c_env == 1 && it == P.sq_chunk)) ? 1 : 0;
+                if (lane == 0 && !c_noyield) yield = (sq_someone_behind(P, D, c_x, it / P.sq_chunk, c_hold) || (P.sq_debug && c_env == 1 && it == P.sq_chunk)) ? 1 : 0;
                 if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = it / P.sq_chunk; c_it_parked = it; break; }
                 to_boundary = P.sq_chunk;
             }
@@ -853,8 +855,10 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
     int lev_out = lev + 1, light_out = 0;
+    // P.sq_hold: the envs of the top issue-priority class -- the heaviest quarter of the dispatch order, and envs that left a pair as heavy -- keep their slot
+    // while other envs merely have not started yet: their chain is what the launch waits for at the end, and a first chunk that waits costs it a round
     const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, completion,
-                                                          &light_out);
+                                                          &light_out, P.sq_hold != 0 && (item >> 24) == 3);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {

@@ -101,3 +101,27 @@ def test_pairs_inside_the_scheduler_equal_the_solo_kernel_at_full_size(monkeypat
         assert got[5] == ref[5]
         for a, b in zip(ref[:5], got[:5]):
             assert torch.equal(a, b), variant
+
+
+def test_default_from_6144_envs_is_paired_and_equals_the_solo_kernel(monkeypatch):
+    """Handles of 6144 envs and more pair by default (loose limits: everything that fits a half-wave; the launch is one kernel, every first task a pair);
+    below, the lean one-env-per-wavefront scheduler kernel stays.  6144 envs x 14 steps with auto-reset against BP_PAIR=0: torch.equal."""
+    from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
+    trials = default_trials(0.3, 32, base_seed=9)
+    for k in ("BP_PAIR", "BP_SCHED"):
+        monkeypatch.delenv(k, raising=False)
+    small = BatchedShipIceEnv(64, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+    assert int(small.L.bp_pair_mode(small.h)) == 0
+    small.close()
+    ref = _run_batch(6144, 14, 0.3, {"BP_PAIR": "0"}, monkeypatch, trials)
+    got = _run_batch(6144, 14, 0.3, {"BP_PAIR": "2"}, monkeypatch, trials)      # = the default at this size (asserted below)
+    assert ref[6] is None and got[6] is None, (ref[6], got[6])
+    assert ref[5] == got[5]
+    for a, b in zip(ref[:5], got[:5]):
+        assert torch.equal(a, b)
+    for k in ("BP_PAIR", "BP_SCHED"):
+        monkeypatch.delenv(k, raising=False)
+    big = BatchedShipIceEnv(6144, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+    ps = big.pair_stats()
+    assert ps["mode"] == 2 and ps["solo_first"] == 0 and ps["max_warm_x_colours"] == 100
+    big.close()
