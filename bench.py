@@ -605,6 +605,13 @@ def main():
         if episode_summary is not None:
             out["episode_metrics"] = episode_summary
         if args.env in ("box", "area"):
+            if hasattr(env, "stragglers") and hasattr(env.L, "bp_bd_get_stragglers"):
+                resumed, limited = env.stragglers()
+                out["straggler_env_steps"] = {"ran_into_STEP_LIMIT": limited, "finished_by_the_second_pass": resumed, "env_steps_total": E * (K + W),
+                                              "budget_sim_steps": int(os.environ.get("BP_BD_BUDGET", "3000")),
+                                              "what": "cumulative over warm-up and timed steps: env steps whose execute_robot_path / step_simulation_until_still loop hit the "
+                                                      "reference's STEP_LIMIT (10 000 sim steps: single wavefronts that set the launch time), and env steps that ran past the "
+                                                      "sim-step budget of the first pass and were finished by the second one beside the other envs' finish / map / observation kernels"}
             out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish in physics_ms)"
             out["roofline"]["note"] = "persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c)"
             out["substeps_per_s"] = None

@@ -25,7 +25,7 @@ EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_set_step_cost_hint", "bp_sched_chunk", "bp_sched_warnings", "bp_get_clock_stamps", "bp_last_error",
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
            "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2", "bp_debug_scramble_hints",
-           "bp_copy_rows_masked", "bp_pair_mode", "bp_get_pair_stats"]
+           "bp_copy_rows_masked", "bp_pair_mode", "bp_get_pair_stats", "bp_bd_get_stragglers"]
 
 
 class BpCostmapConfig(C.Structure):
@@ -134,6 +134,7 @@ def load():
     L.bp_sched_chunk.argtypes = [vp]
     L.bp_pair_mode.argtypes = [vp]
     L.bp_get_pair_stats.argtypes = [vp, vp]
+    L.bp_bd_get_stragglers.argtypes = [vp, vp]
     L.bp_sched_chunk.restype = C.c_int32
     if hasattr(L, "bp_get_clock_stamps"):
         L.bp_get_clock_stamps.argtypes = [vp, vp]

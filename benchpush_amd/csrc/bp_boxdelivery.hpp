@@ -34,6 +34,10 @@ struct BdParams {
     double bd_poly[8][2], ob_poly[8][2], footprint[4][2];
     float recept_outside;               // channel-3 map outside the small-map window: box-delivery 0; area-clearing 1, and 2 within
     int out_r;                          // out_r pixels of the window (dilated outer walls: the whole window border is wall, checked at load)
+    // Two-pass step: pass 0 runs every env for at most `budget` sim steps (0 = no limit), pass 1 resumes the envs that were not done.
+    // The envs that finish in pass 0 -- all but the handful that run into the reference's 10 001-step loops -- go through the finish / robot-map / observe
+    // kernels while pass 1 is still running on another stream; `sel_want` tells a tail kernel which of the two groups it serves (-1: every env).
+    int budget, pass, sel_want;
 };
 struct BdPtrs {
     // per map (trial -> map index): window rasters
@@ -58,6 +62,10 @@ struct BdPtrs {
     double *wp;                     // [E][BD_MAXWP][3]
     int *nwp;                       // [E]
     double *stepf;                  // [E][8] robot_distance, ix, iy, ih, hit, substeps, -, -
+    unsigned char *unfin;           // [E] 1 = the env's sim-step loop hit the budget of pass 0 (its loop state is in rs_i / rs_d) -- written by pass 0 for every env
+    int *rs_i;                      // [E][16] phase, wi, path0, done_turning, dp_valid, sp_one, sim_steps, kcount, have_prev, still_done, total_sub, robot_hit, cycles >> 8
+    double *rs_d;                   // [E][4 + 2 * 64] the controller's doubles (L.ctl) and the until-still loop's previous positions (one d2 per lane)
+    unsigned *straggler;            // [2] cumulative: envs resumed by pass 1, envs whose loops ran into STEP_LIMIT
     float *dist;                    // [E][SH*SW] spfa scratch
     float *rmap;                    // [E][SH*SW] spfa map from the robot (observation channel 2)
     const d2 *goals;                // [ngoal] area-clearing goal points
@@ -557,6 +565,8 @@ template <bool DAMP>
 __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtrs &D, const BdParams &B, const BdPtrs &Q)
 {
     const int env = (D.order != nullptr) ? D.order[blockIdx.x] : (int)blockIdx.x;
+    const bool resume = B.pass == 1;
+    if (resume && Q.unfin[env] == 0) return;       // pass 1 serves only the envs that pass 0 left unfinished
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = lane_id();
     LdsCtx L;
@@ -584,7 +594,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
     S.robot_hit = (B.task == 1) ? (int)sf[4] : 0;
     // Wave-uniform doubles of the path controller live in LDS (L.ctl), not in VGPRs: the kernel sits at the 256-VGPR line and spilled them to scratch around
     // every sim step; they are touched a handful of times per sim step.  ctl[0] prev_heading_diff, [1] path length, [2] advanced length, [3] robot_distance.
-    if (lane < 4) L.ctl[lane] = 0.0;
+    if (lane < 4) L.ctl[lane] = resume ? Q.rs_d[(size_t)env * 132 + lane] : 0.0;
     lds_sync();
     unsigned total_sub = 0;
     // One loop with a single substep call site (the physics is one large inlined function); the phase selects what happens
@@ -607,6 +617,18 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
     bool have_prev = false, still_done = false;
     const int first_static = B.first_box + B.nbox;
     const int nstat = E.nb - first_static;
+    bool first_after_resume = false, hit_limit = false;   // hit_limit: one of the two loops ran into STEP_LIMIT in this env step (statistics only)
+    unsigned cycles_before = 0u;
+    if (resume) {
+        // the loop state of pass 0 (the bodies, arbiters and velocities came back through load_state, as after a park of the step scheduler)
+        const int *ri = Q.rs_i + (size_t)env * 16;
+        phase = ri[0]; wi = ri[1]; path0 = ri[2]; done_turning = ri[3] != 0; dp_valid = ri[4] != 0; sp_one = ri[5] != 0;
+        sim_steps = ri[6]; kcount = ri[7]; have_prev = ri[8] != 0; still_done = ri[9] != 0; total_sub = (unsigned)ri[10]; S.robot_hit = ri[11];
+        cycles_before = (unsigned)ri[12]; hit_limit = ri[13] != 0;
+        const double *rd = Q.rs_d + (size_t)env * 132 + 4 + 2 * lane;
+        prevp = mk2(rd[0], rd[1]);
+        first_after_resume = true;   // the "moved in the last sim step" stamps are gone: the first stuck-box test looks at every box (the test is a pure function of the pose)
+    } else
     if (B.action_type == 2) {
         if (B.task == 1) {
             // area-clearing velocity control (area_clearing.py:660-667): set once; the common sim steps follow
@@ -688,7 +710,8 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
             // skipped; the first iteration tests every box.  Of the (box vertex, obstacle shape) items of the boxes that are left, those whose vertex lies
             // outside the shape's AABB -- nearly all -- are dropped by a first pass that costs a comparison; the point query runs on the compacted rest.
             unsigned long long stuck = 0ull;
-            const bool cand = lane < nalive && (!have_prev || L.mvs[B.first_box + order[lane]] == S.stamp);
+            const bool cand = lane < nalive && (!have_prev || first_after_resume || L.mvs[B.first_box + order[lane]] == S.stamp);
+            first_after_resume = false;
             const unsigned long long candm = ballot(cand);
             if (cand) L.rf[popc_below(candm, lane)] = (unsigned char)lane;   // L.rf: scratch of the integrate phase, free between sim steps
             lds_sync();
@@ -793,7 +816,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                     if (wi == nwp - 1) leave = true;
                     else { wi++; done_turning = false; dp_valid = false; path0++; }
                 }
-                if (!leave) { sim_steps++; if (sim_steps > B.step_limit) leave = true; }
+                if (!leave) { sim_steps++; if (sim_steps > B.step_limit) { leave = true; hit_limit = true; } }
             }
             if (leave) { phase = after_move; sim_steps = 0; kcount = 0; }
         } else if (phase == PH_VEL) {
@@ -807,11 +830,32 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
             if (kcount >= P.steps) phase = PH_DONE;
         } else { // PH_STILL
             sim_steps++;
+            if (!still_done && sim_steps > B.step_limit) hit_limit = true;
             if (still_done || sim_steps > B.step_limit) phase = PH_DONE;
         }
+        if (B.pass == 0 && B.budget > 0 && (int)total_sub >= B.budget && phase != PH_DONE) break;   // out of budget: pass 1 carries on from here
     }
+    const bool unfinished = phase != PH_DONE;
     __syncthreads();
     store_state(P, D, L, A, env);
+    if (B.pass == 0 && lane == 0) Q.unfin[env] = unfinished ? 1 : 0;
+    if (unfinished) {
+        int *ri = Q.rs_i + (size_t)env * 16;
+        double *rd = Q.rs_d + (size_t)env * 132;
+        if (lane == 0) {
+            ri[0] = phase; ri[1] = wi; ri[2] = path0; ri[3] = done_turning; ri[4] = dp_valid; ri[5] = sp_one; ri[6] = sim_steps; ri[7] = kcount;
+            ri[8] = have_prev; ri[9] = still_done; ri[10] = (int)total_sub; ri[11] = S.robot_hit;
+            ri[12] = (int)((__builtin_amdgcn_s_memtime() - t_begin) >> 8); ri[13] = hit_limit;
+            D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
+            if (Q.straggler != nullptr) atomicAdd(&Q.straggler[0], 1u);
+        }
+        if (lane < 4) rd[lane] = L.ctl[lane];
+        rd[4 + 2 * lane] = prevp.x; rd[4 + 2 * lane + 1] = prevp.y;
+        const int err_u = (ballot((S.err & BP_ERR_ADJ_OVERFLOW) != 0) ? BP_ERR_ADJ_OVERFLOW : 0) | (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
+                          (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
+        if (lane == 0 && err_u) atomicOr(&D.e_err[env], err_u);
+        return;
+    }
 #ifdef BP_PROF
     if (D.prof != nullptr) {
         if (lane == 0) { L.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0; L.prof[22] = total_sub; L.prof[15] = _t_ctrl; }
@@ -824,8 +868,9 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                         (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
     if (lane == 0) {
         D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
-        D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
+        D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + cycles_before;
         if (err_any) atomicOr(&D.e_err[env], err_any);
+        if (Q.straggler != nullptr && hit_limit) atomicAdd(&Q.straggler[1], 1u);
         double *o = Q.stepf + (size_t)env * 8;
         o[0] = L.ctl[3]; o[4] = (double)S.robot_hit; o[5] = (double)total_sub;
     }
@@ -848,6 +893,7 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
                                                   unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     const int env = tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
+    if (!tmpl && !init && B.sel_want >= 0 && (int)Q.unfin[env] != B.sel_want) return;   // two-pass step: the other group's env
     const int lane = lane_id();
     BdLds L;
     bd_carve(B, (char *)bp_smem, L);
@@ -1021,6 +1067,7 @@ __global__ __launch_bounds__(64) void k_ac_finish(const DevParams P, const DevPt
                                                   unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
     const int env = tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
+    if (!tmpl && !init && B.sel_want >= 0 && (int)Q.unfin[env] != B.sel_want) return;   // two-pass step: the other group's env
     const int lane = lane_id();
     BdLds L;
     bd_carve(B, (char *)bp_smem, L);
@@ -1137,6 +1184,7 @@ __global__ __launch_bounds__(64) void k_ac_finish(const DevParams P, const DevPt
 __global__ __launch_bounds__(BDR_THREADS) void k_bd_robot_map(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q, const int tmpl)
 {
     const int env = tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x;
+    if (!tmpl && B.sel_want >= 0 && (int)Q.unfin[env] != B.sel_want) return;   // two-pass step: the other group's env
     const int tid = threadIdx.x;
     const int NW = B.SH * B.SW, words = (NW + 31) / 32;
     unsigned *freeb = (unsigned *)bp_smem;                               // [words]
@@ -1306,6 +1354,7 @@ __global__ __launch_bounds__(BDO_THREADS) void k_bd_observe(const DevParams P, c
 {
     const int env = blockIdx.x;
     if (mask != nullptr && mask[env] == 0) return;
+    if (mask == nullptr && B.sel_want >= 0 && (int)Q.unfin[env] != B.sel_want) return;   // two-pass step: the other group's env
     const int tid = threadIdx.x;
     unsigned char *img = (unsigned char *)bp_smem;
     __shared__ long long spx[4], spy[4];

@@ -27,8 +27,10 @@ struct bp_handle {
     bool damp = false;     // bp_config.damping_pow != 0: k_physics_step_damp / k_physics_reset_damp (generic vertex loops, no scheduler)
     int pair_mode = 0;              // two envs per wavefront (bp_physics_pair.hpp): 1 = fixed pairs for the whole step (k_physics_step_pair), 2 = inside the scheduler
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
-    hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel; ship-ice: the solo kernel of a pairing launch
+    hipStream_t st_aux2 = nullptr;  // box-delivery / area-clearing: pass 1 of the two-pass step (the envs that ran out of pass 0's sim-step budget) and its tail kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    int bd_budget = 0;              // sim steps of pass 0 of the two-pass step, 0 = one pass (BP_BD_BUDGET)
     DevParams P;
     DevPtrs D;
     std::vector<void *> allocs;
@@ -171,6 +173,8 @@ int bp_destroy(bp_handle *h)
     if (!h) return BP_EINVAL;
     DevGuard _dg(h->device);
     if (h->st_aux) { hipStreamSynchronize(h->st_aux); hipStreamDestroy(h->st_aux); }
+    if (h->st_aux2) { hipStreamSynchronize(h->st_aux2); hipStreamDestroy(h->st_aux2); }
+    if (h->ev_join2) hipEventDestroy(h->ev_join2);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
     for (void *p : h->allocs) hipFree(p);
@@ -635,26 +639,70 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 h->steps_done = true;
                 hipLaunchKernelGGL(k_bd_plan, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, actions);
                 HIPCHK(h, hipGetLastError());
+                if (!h->st_aux) {
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux, hipStreamNonBlocking));
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux2, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+                }
+                auto finish = [&](const BdParams &Bx, hipStream_t s_) {
+                    if (h->B.task == 1) hipLaunchKernelGGL(k_ac_finish, dim3(E), dim3(64), h->bd_lds, s_, h->P, h->D, Bx, h->Q, 0, 0, reward, term, trunc, info);
+                    else hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, s_, h->P, h->D, Bx, h->Q, 0, 0, reward, term, trunc, info);
+                };
+                if (h->bd_budget > 0) {
+                    // Two-pass step: a launch of k_bd_physics lasts as long as its slowest env, and the slowest are single wavefronts inside the reference's own
+                    // 10 001-step loops.  Pass 0 gives every env `bd_budget` sim steps; the envs that are done -- all but a handful -- go through
+                    // finish / robot map / observation on the caller's stream while pass 1 carries the others to their end on a third stream, followed by the
+                    // same kernels for that group.  Results are those of the single pass (the loop state travels through Q.rs_*, bodies and arbiters through the
+                    // ordinary store / load of a step boundary).
+                    BdParams B0 = h->B, B1 = h->B, Bs0 = h->B, Bs1 = h->B;
+                    B0.budget = h->bd_budget; B0.pass = 0; B1.pass = 1; Bs0.sel_want = 0; Bs1.sel_want = 1;
+                    if (h->damp) hipLaunchKernelGGL(k_bd_physics_damp, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, B0, h->Q);
+                    else hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, B0, h->Q);
+                    HIPCHK(h, hipGetLastError());
+                    HIPCHK(h, hipEventRecord(h->ev_fork, st));
+                    // group 1 (unfinished): third stream
+                    HIPCHK(h, hipStreamWaitEvent(h->st_aux2, h->ev_fork, 0));
+                    if (h->damp) hipLaunchKernelGGL(k_bd_physics_damp, dim3(E), dim3(64), h->lds_bytes, h->st_aux2, h->P, h->D, B1, h->Q);
+                    else hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, h->st_aux2, h->P, h->D, B1, h->Q);
+                    HIPCHK(h, hipGetLastError());
+                    hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_aux2, h->P, h->D, Bs1, h->Q, 0);
+                    finish(Bs1, h->st_aux2);
+                    HIPCHK(h, hipGetLastError());
+                    if (raster && obs) {
+                        hipLaunchKernelGGL(k_bd_observe, dim3(E), dim3(BDO_THREADS), h->bd_obs_lds, h->st_aux2, h->P, h->D, Bs1, h->Q, (const unsigned char *)nullptr, obs);
+                        HIPCHK(h, hipGetLastError());
+                    }
+                    HIPCHK(h, hipEventRecord(h->ev_join2, h->st_aux2));
+                    // group 0 (done in pass 0): the caller's stream, the robot map beside the finish kernel as before
+                    HIPCHK(h, hipStreamWaitEvent(h->st_aux, h->ev_fork, 0));
+                    hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_aux, h->P, h->D, Bs0, h->Q, 0);
+                    HIPCHK(h, hipGetLastError());
+                    HIPCHK(h, hipEventRecord(h->ev_join, h->st_aux));
+                    finish(Bs0, st);
+                    HIPCHK(h, hipGetLastError());
+                    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+                    if (raster && obs) {
+                        hipLaunchKernelGGL(k_bd_observe, dim3(E), dim3(BDO_THREADS), h->bd_obs_lds, st, h->P, h->D, Bs0, h->Q, (const unsigned char *)nullptr, obs);
+                        HIPCHK(h, hipGetLastError());
+                        raster = false;   // both groups' observations are on their way
+                    }
+                    HIPCHK(h, hipStreamWaitEvent(st, h->ev_join2, 0));
+                } else {
                 if (h->damp) hipLaunchKernelGGL(k_bd_physics_damp, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
                 else hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, st, h->P, h->D, h->B, h->Q);
                 HIPCHK(h, hipGetLastError());
                 // the robot's spfa map needs only the robot pose: it runs beside the finish kernel on a second stream
-                if (!h->st_aux) {
-                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux, hipStreamNonBlocking));
-                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
-                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
-                }
                 HIPCHK(h, hipEventRecord(h->ev_fork, st));
                 HIPCHK(h, hipStreamWaitEvent(h->st_aux, h->ev_fork, 0));
                 hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_aux, h->P, h->D, h->B, h->Q, 0);
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipEventRecord(h->ev_join, h->st_aux));
-                if (h->B.task == 1)
-                    hipLaunchKernelGGL(k_ac_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
-                else
-                    hipLaunchKernelGGL(k_bd_finish, dim3(E), dim3(64), h->bd_lds, st, h->P, h->D, h->B, h->Q, 0, 0, reward, term, trunc, info);
+                finish(h->B, st);
                 HIPCHK(h, hipGetLastError());
                 HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+                }
             } else {
                 hipLaunchKernelGGL(k_reset_copy, dim3(E), dim3(256), 0, st, h->P, h->D, mask, (double *)nullptr);
                 HIPCHK(h, hipGetLastError());
@@ -1161,6 +1209,9 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     const BdMaps &M0 = h->bd_maps[0];
     B.H = M0.H; B.W = M0.W; B.SH = M0.SH; B.SW = M0.SW; B.si0 = M0.si0; B.sj0 = M0.sj0;
     B.nbox = nbox; B.nrecept = 1; B.out_r = M0.out_r;
+    B.budget = 0; B.pass = 0; B.sel_want = -1;
+    // two-pass step: sim steps every env gets in pass 0 (the mean env needs ~750, the 99th percentile ~3 000; the reference's loops stop at 10 001); BP_BD_BUDGET=0: one pass
+    h->bd_budget = getenv("BP_BD_BUDGET") ? atoi(getenv("BP_BD_BUDGET")) : 3000;
     const int NW = B.SH * B.SW, words = (NW + 31) / 32, nm = (int)h->bd_maps.size();
     BdPtrs &Q = h->Q;
     int *d_mot; unsigned *d_free, *d_thin; unsigned short *d_edt; float *d_rec; unsigned char *d_small, *d_rchan; d2 *d_rp, *d_rn;
@@ -1220,6 +1271,10 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if ((rc = dalloc(h, &Q.wp, E * BD_MAXWP * 3))) return rc;
     if ((rc = dalloc(h, &Q.nwp, E))) return rc;
     if ((rc = dalloc(h, &Q.stepf, E * 8))) return rc;
+    if ((rc = dalloc(h, &Q.unfin, E))) return rc;
+    if ((rc = dalloc(h, &Q.rs_i, E * 16))) return rc;
+    if ((rc = dalloc(h, &Q.rs_d, E * 132))) return rc;
+    if ((rc = dalloc(h, &Q.straggler, (size_t)2))) return rc;
     if ((rc = dalloc(h, &Q.dist, E * NW))) return rc;
     if ((rc = dalloc(h, &Q.rmap, E * NW))) return rc;
     if ((rc = dalloc(h, &Q.cleared, E * BD_MAXBOX))) return rc;
@@ -1344,6 +1399,16 @@ int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
 }
 
 int32_t bp_pair_mode(bp_handle *h) { return h ? h->pair_mode : 0; }
+
+int bp_bd_get_stragglers(bp_handle *h, uint32_t *out2_host)
+{
+    if (!h || !out2_host) return BP_EINVAL;
+    if (!h->loaded || h->P.env_kind != BP_ENV_BOX || h->Q.straggler == nullptr) return fail(h, BP_ESTATE, "not a loaded box-delivery / area-clearing handle");
+    BP_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out2_host, h->Q.straggler, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BP_OK;
+}
 
 int bp_get_pair_stats(bp_handle *h, int32_t *out16_host)
 {

@@ -89,6 +89,12 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
                                                  _ptr(self.truncated), _ptr(self.info), self._stream()), "bp_step")
         return self.obs, self.reward, self.terminated, self.truncated, self.info
 
+    def stragglers(self):
+        """(env steps finished by the second pass of the two-pass step, env steps whose path / until-still loop ran into STEP_LIMIT), cumulative since load."""
+        out = np.zeros(2, np.uint32)
+        _lib.check(self.L, self.h, self.L.bp_bd_get_stragglers(self.h, out.ctypes.data_as(C.c_void_p)), "bp_bd_get_stragglers")
+        return int(out[0]), int(out[1])
+
     def maps(self, trial=0):
         dims = np.zeros(6, np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)

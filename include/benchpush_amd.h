@@ -324,6 +324,11 @@ int32_t bp_bd_sizeof_config(void);
  * cspace / cspace_thin uint8 [SH][SW]; edt uint16 [SH][SW][2]; recept float [SH][SW]; small_free uint8 [SH][SW] */
 int bp_bd_get_maps(bp_handle *h, int32_t trial, int32_t *dims, uint8_t *cspace, uint8_t *cspace_thin, uint16_t *edt, float *recept,
                    uint8_t *small_free);
+/* Two-pass step of box-delivery / area-clearing handles (ABI 9): out2_host[0] = env steps whose sim-step loop ran past the budget of the first pass and was
+ * finished by the second one (beside the finish / map / observation kernels of all other envs), out2_host[1] = env steps whose execute_robot_path or
+ * step_simulation_until_still loop ran into STEP_LIMIT (box_delivery_env.py:62,891-1023) -- cumulative since load (host uint32 [2], synchronises).
+ * BP_BD_BUDGET=<sim steps> sets the budget of the first pass at load time (default 3000; 0 = one pass). */
+int bp_bd_get_stragglers(bp_handle *h, uint32_t *out2_host);
 /* tests: per-env box bookkeeping, host buffers: alive uint8 [E][24], waypoints double [E][64][3], nwp int32 [E] (synchronises) */
 int bp_bd_get_state(bp_handle *h, uint8_t *alive, double *waypoints, int32_t *nwp);
 

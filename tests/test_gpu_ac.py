@@ -128,6 +128,15 @@ def test_layout_whose_wall_cuts_the_clearance_boundary_matches_oracle():
     env.close()
 
 
+def test_area_clearing_two_pass_step_matches_oracle(monkeypatch):
+    """area-clearing through the two-pass step with a budget that stops most env steps mid-path (BP_BD_BUDGET=200; an env step is ~950 sim steps): the
+    resumed group and the group that finished in pass 0 against the oracle, bit for bit."""
+    monkeypatch.setenv("BP_BD_BUDGET", "200")
+    test_area_clearing_matches_oracle("clear_env", "heading")
+    monkeypatch.setenv("BP_BD_BUDGET", "1000")
+    test_area_clearing_matches_oracle("walled_env_with_columns", "position")
+
+
 def test_deep_episodes_through_clearing_and_time_truncation():
     """30 env steps of 4 envs against the oracle with auto-reset (every step: bodies, info, reward, flags, observation; every reset: first
     observation): a hand-placed box next to the clearance boundary is pushed out (cleared reward, box_count; area_clearing.py:611-780) and the

@@ -189,6 +189,30 @@ def test_forced_step_limit_steps_match_oracle():
     assert seen["max_substeps"] >= 500, seen
 
 
+@pytest.mark.parametrize("budget", ["120", "700", "0"])
+def test_two_pass_step_matches_oracle(monkeypatch, budget):
+    """The two-pass step (k_bd_physics with a sim-step budget, the unfinished envs resumed by a second launch on another stream while the finished ones go
+    through finish / robot map / observation): a budget of 120 sim steps stops nearly every env step inside execute_robot_path, 700 mostly inside
+    step_simulation_until_still or not at all -- mixed groups in every step --, 0 is the single pass.  20 env steps of 4 envs with deliveries, resets and
+    forced STEP_LIMIT steps against the oracle: bodies, info, rewards, flags and all four observation channels, bit for bit."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    monkeypatch.setenv("BP_BD_BUDGET", budget)
+    cfg = default_cfg("box_delivery")
+    gen = S.generate_trials(cfg, 3)
+    tr = dict(gen[0])
+    tr["start"] = np.array([1.5, 1.75, 0.0])
+    tr["boxes"] = np.array(gen[0]["boxes"])
+    tr["boxes"][0] = [2.6, 1.75, 0.3]
+    trials = [tr, gen[1], gen[2]]
+    env = BatchedBoxDeliveryEnv(4, trials=trials, bd_overrides={"step_limit": 900})
+    seen = _deep_run(env, cfg, trials, 20, [[1.0], [1.0], [1.0], [1.0]], seed=5, step_limit=900)
+    resumed, limited = env.stragglers()
+    env.close()
+    assert seen["delivered"] >= 1 and seen["max_substeps"] >= 900, seen
+    assert limited >= 1
+    assert (resumed == 0) if budget == "0" else (resumed >= (40 if budget == "120" else 5)), (budget, resumed)
+
+
 def test_large_divider_20_boxes_soak_at_full_size():
     """4096 envs x the 10 x 10 m room with 20 boxes and the divider: the in-kernel capacities of the box-delivery step (pre_solve events BP_EVCAP,
     manifold mailbox BP_MBOX, arbiter and velocity slots, query buffers) are never hit -- check_errors() after every step."""
