@@ -612,7 +612,11 @@ def main():
                                               "what": "cumulative over warm-up and timed steps: env steps whose execute_robot_path / step_simulation_until_still loop hit the "
                                                       "reference's STEP_LIMIT (10 000 sim steps: single wavefronts that set the launch time), and env steps that ran past the "
                                                       "sim-step budget of the first pass and were finished by the second one beside the other envs' finish / map / observation kernels"}
-            out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish in physics_ms)"
+            if int(os.environ.get("BP_BD_BUDGET", "3000")) > 0:   # two-pass step: both groups' observation kernels run inside the physics window (other streams)
+                out["roofline"]["raster_kernel"].update(ms=None, achieved=None, frac=None,
+                                                        note="two-pass step (DESIGN.md 4c): k_bd_observe runs once per group on two streams inside physics_ms; "
+                                                             "3.8-3.9 ms for 4 096 envs in the kernel trace (profiles/r05_box/)")
+            out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish / k_bd_robot_map / k_bd_observe in physics_ms)"
             out["roofline"]["note"] = "persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c)"
             out["substeps_per_s"] = None
         if world == 1 and not args.no_cpu_baseline and args.env == "ship-ice":
