@@ -28,6 +28,8 @@ struct bp_handle {
     int pair_mode = 0;              // two envs per wavefront (bp_physics_pair.hpp): 1 = fixed pairs for the whole step (k_physics_step_pair), 2 = inside the scheduler
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
     hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel; ship-ice: the solo kernel of a pairing launch
+    std::vector<hipStream_t> st_parts;   // ship-ice: the scheduled launch split over several hardware queues (BP_SCHED_PARTS)
+    std::vector<hipEvent_t> ev_parts;
     hipStream_t st_aux2 = nullptr;  // box-delivery / area-clearing: pass 1 of the two-pass step (the envs that ran out of pass 0's sim-step budget) and its tail kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     int bd_budget = 0;              // sim steps of pass 0 of the two-pass step, 0 = one pass (BP_BD_BUDGET)
@@ -174,6 +176,8 @@ int bp_destroy(bp_handle *h)
     DevGuard _dg(h->device);
     if (h->st_aux) { hipStreamSynchronize(h->st_aux); hipStreamDestroy(h->st_aux); }
     if (h->st_aux2) { hipStreamSynchronize(h->st_aux2); hipStreamDestroy(h->st_aux2); }
+    for (hipStream_t s_ : h->st_parts) { hipStreamSynchronize(s_); hipStreamDestroy(s_); }
+    for (hipEvent_t e_ : h->ev_parts) hipEventDestroy(e_);
     if (h->ev_join2) hipEventDestroy(h->ev_join2);
     if (h->ev_fork) hipEventDestroy(h->ev_fork);
     if (h->ev_join) hipEventDestroy(h->ev_join);
@@ -347,6 +351,12 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch;
             h->P.sq_hold = getenv("BP_SCHED_HOLD") ? atoi(getenv("BP_SCHED_HOLD")) : 0;
+            h->P.sq_lrpt = getenv("BP_SCHED_LRPT") ? atoi(getenv("BP_SCHED_LRPT")) : 0;
+            h->P.sq_bw = std::max(1, getenv("BP_SCHED_BW") ? atoi(getenv("BP_SCHED_BW")) : 9000);     // ~1 ms of a wavefront at 2.4 GHz
+            h->P.sq_hyst = std::max(0, getenv("BP_SCHED_HYST") ? atoi(getenv("BP_SCHED_HYST")) : 1);
+            h->P.sq_floor = std::max(0, getenv("BP_SCHED_FLOOR") ? atoi(getenv("BP_SCHED_FLOOR")) : 150);
+            h->P.sq_parts = std::min(8, std::max(1, getenv("BP_SCHED_PARTS") ? atoi(getenv("BP_SCHED_PARTS")) : 1));
+            h->P.sq_part = 0;
             h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
             if ((rc = dalloc(h, &d_items, (size_t)SQ_NX * SQ_MAXLEV * h->P.sq_cap))) return rc;
@@ -751,6 +761,25 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 hipLaunchKernelGGL(k_physics_step_schedp, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
                 HIPCHK(h, hipGetLastError());
                 if (h->P.pair_solo > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
+            } else if (h->P.sq_parts > 1) {
+                // the scheduled launch as several kernels on several streams (hardware queues)
+                const int np = h->P.sq_parts;
+                if (h->st_parts.empty()) {
+                    for (int k = 0; k < 7; k++) { hipStream_t s_; HIPCHK(h, hipStreamCreateWithFlags(&s_, hipStreamNonBlocking)); h->st_parts.push_back(s_); }
+                    for (int k = 0; k < 8; k++) { hipEvent_t e_; HIPCHK(h, hipEventCreateWithFlags(&e_, hipEventDisableTiming)); h->ev_parts.push_back(e_); }
+                }
+                HIPCHK(h, hipEventRecord(h->ev_parts[7], st));
+                for (int k = 0; k < np; k++) {
+                    DevParams Pk = h->P;
+                    Pk.sq_part = k;
+                    hipStream_t sk = (k == 0) ? st : h->st_parts[k - 1];
+                    if (k > 0) HIPCHK(h, hipStreamWaitEvent(sk, h->ev_parts[7], 0));
+                    const int grid = (h->num_envs * h->P.sq_levels + np - 1) / np;
+                    hipLaunchKernelGGL(k_physics_step_sched, dim3(grid), dim3(64), h->lds_bytes, sk, Pk, h->D, actions, reward, term, trunc, info);
+                    HIPCHK(h, hipGetLastError());
+                    if (k > 0) { HIPCHK(h, hipEventRecord(h->ev_parts[k - 1], sk)); }
+                }
+                for (int k = 1; k < np; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_parts[k - 1], 0));
             } else
                 hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             HIPCHK(h, hipGetLastError());

@@ -33,6 +33,9 @@ struct DevParams {
     double ship_head[2], ship_tail[2];
     int obs_h, obs_w, grid_h, grid_w;
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
+    int sq_parts, sq_part;                     // the scheduled launch as sq_parts kernels on as many streams; this kernel's index
+    int sq_floor;                              // longest-remaining-first: lower bound of the estimated cost per sub-step left (wave cycles >> 8)
+    int sq_lrpt, sq_bw, sq_hyst;               // longest-remaining-first scheduling: on / row width in wave cycles >> 8 / rows a waiting env must be ahead by
     int sq_hold;                               // 1: envs of the top priority class do not yield to envs that have not started yet (BP_SCHED_HOLD)
     int sq_mode;                               // 0 = scheduled launch, 1 = completion launch: workgroup b finishes env b if the scheduled launch left it unfinished
     int sq_debug;                              // test hook (BP_SCHED_DEBUG_DROP=1): env 1 is parked after its first chunk and never queued, the watchdog is short

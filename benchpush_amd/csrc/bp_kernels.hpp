@@ -249,7 +249,8 @@ __device__ __forceinline__ int sq_pop(const DevParams &P, const DevPtrs &D, cons
 {
     const bool any0 = sq_ld(sq_waiting(D, x)) > 0, any1 = P.pair_mode == 2 && sq_ld(sq_waiting(D, x + 8)) > 0;
     if (!any0 && !any1) return -1;
-    for (int l = 0; l < P.sq_levels; l++) {
+    const int nrows = P.sq_lrpt ? SQ_MAXLEV : P.sq_levels;
+    for (int l = 0; l < nrows; l++) {
         if (any0) { const int e = sq_pop_level(P, D, x, l); if (e >= 0) { lev = l; kind = 0; return e; } }
         if (any1) { const int e = sq_pop_level(P, D, x + 8, l); if (e >= 0) { lev = l; kind = 1; return e; } }
     }
@@ -262,6 +263,25 @@ __device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, co
     atomicAdd(sq_waiting(D, xk), 1);
 }
 // lane 0: is some env behind one that has completed `lev` chunks?  Envs whose first chunk has not been dispatched yet are behind everybody.
+// Longest-remaining-first keys (P.sq_lrpt): a queue row is not "chunks completed" but 15 - (estimated remaining run time of the env's step / P.sq_bw), so the
+// ascending scan of sq_pop takes the env with the MOST work left, and a running wave yields only to a waiting env that has at least P.sq_hyst rows more left
+// than itself (or to a not-yet-started env whose previous step cost more than that).  The estimate is the env's own pace in this step: cycles so far / sub-steps
+// so far x sub-steps left.  With least-advanced-first every env advances at the same pace and the launch ends when the heaviest env does, which then has
+// waited its fair share (3-5 ms of 17: tools/sched_trace.py); with longest-remaining-first the heavy envs run through and the light ones fill the slots.
+__device__ __forceinline__ int sq_lrpt_key(const DevParams &P, const unsigned long long rem_units) { return 15 - (int)min(15ull, rem_units / (unsigned long long)P.sq_bw); }
+__device__ __forceinline__ bool sq_someone_heavier(const DevParams &P, const DevPtrs &D, const int x, const int my_key, const unsigned long long my_rem)
+{
+    bool any = false;
+    const int started = sq_ld(sq_started(D));
+    if (started < P.num_envs) {   // the next first task of the dispatch order (heaviest first): what its env cost in the previous step
+        if (D.order == nullptr) any = true;
+        else any = (unsigned long long)D.e_cost[D.order[started]] > my_rem + (unsigned long long)P.sq_bw * (unsigned)P.sq_hyst;
+    }
+    const int upto = my_key - P.sq_hyst;   // rows 0 .. upto hold envs with at least sq_hyst rows more left
+    if (!any && sq_ld(sq_waiting(D, x)) > 0)
+        for (int l = 0; l <= upto; l++) { const int *ctr = sq_row(D, x, l); any = any || (sq_ld(ctr) < sq_ld(ctr + 1)); }
+    return any;
+}
 // `hold`: the caller keeps its slot against envs that merely have not started yet (it still yields to envs that wait in the queues)
 __device__ __forceinline__ bool sq_someone_behind(const DevParams &P, const DevPtrs &D, const int x, const int lev, const bool hold = false)
 {
@@ -427,6 +447,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     const unsigned costp_resume = S.costp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     const int it_first = CHUNKED ? c_sub : 0;
+    const unsigned carry_units = (CHUNKED && c_sub > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u;   // wave cycles >> 8 of the step's earlier runs
     int c_it_parked = 0;
     bool step_done = true;
     int to_boundary = CHUNKED ? P.sq_chunk : 0x7FFFFFFF;   // sub-steps until the next chunk boundary
@@ -440,9 +461,18 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     for (int it = it_first; it < nsub; it++) {
         if (CHUNKED) {
             if (to_boundary == 0) { // chunk boundary: yield to an env that is further behind, otherwise carry on without a context switch
-                int yield = 0;
-                if (lane == 0 && !c_noyield) yield = (sq_someone_behind(P, D, c_x, it / P.sq_chunk, c_hold) || (P.sq_debug && c_env == 1 && it == P.sq_chunk)) ? 1 : 0;
-                if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = it / P.sq_chunk; c_it_parked = it; break; }
+                int yield = 0, key = it / P.sq_chunk;
+                if (lane == 0 && !c_noyield) {
+                    if (P.sq_lrpt) {
+                        const unsigned long long el = (unsigned long long)carry_units + ((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
+                        // (no env is taken for lighter than P.sq_floor per sub-step left: an env's pace so far says little about a cluster it has yet to run into)
+                        const unsigned long long rem = max(el * (unsigned)(nsub - it) / (unsigned)max(it, 1), (unsigned long long)P.sq_floor * (unsigned)(nsub - it));
+                        key = sq_lrpt_key(P, rem);
+                        yield = sq_someone_heavier(P, D, c_x, key, rem) ? 1 : 0;
+                    } else yield = sq_someone_behind(P, D, c_x, key, c_hold) ? 1 : 0;
+                    if (P.sq_debug && c_env == 1 && it == P.sq_chunk) yield = 1;
+                }
+                if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = __builtin_amdgcn_readfirstlane(key); c_it_parked = it; break; }
                 to_boundary = P.sq_chunk;
             }
             to_boundary--;
@@ -744,6 +774,10 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
 {
     const int lane = lane_id();
     const int home = sq_xcc_id();
+#ifdef BP_SCHED_TRACE
+    const unsigned long long _trw = __builtin_amdgcn_s_memrealtime();   // the workgroup's own start
+    int _tr_idle = 0;
+#endif
     int item = -1, lev = 0, x = home;
     int pe0 = -1, pe1 = -1;          // a paired task: two envs for one wavefront
     const bool completion = P.sq_mode == 1;
@@ -757,7 +791,13 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     const int npairs = pairing ? (P.num_envs - P.pair_solo + 1) / 2 : 0;
     // workgroups that start envs without touching a queue: ROLE 1 numbers its workgroups from P.pair_solo on (the first P.pair_solo positions of the dispatch
     // order are the ROLE 0 kernel's, launched beside it)
-    const int bid = (int)blockIdx.x + (ROLE == 1 ? P.pair_solo : 0);
+    // (P.sq_parts > 1, ROLE 0: the launch is split into that many kernels on as many streams -- hardware queues dispatch their workgroups in order, and a
+    // queue whose next workgroup is bound for a full shader engine leaves free slots elsewhere idle; part k starts the envs at positions k, k + parts, ...
+    // of the dispatch order with its first num_envs / parts workgroups)
+    const int nfirst_part = (ROLE == 0 && P.sq_parts > 1) ? (P.num_envs - P.sq_part + P.sq_parts - 1) / P.sq_parts : 0;
+    const int bid = (ROLE == 1) ? (int)blockIdx.x + P.pair_solo
+                  : (P.sq_parts > 1) ? (((int)blockIdx.x < nfirst_part) ? (int)blockIdx.x * P.sq_parts + P.sq_part : P.num_envs + (int)blockIdx.x)
+                  : (int)blockIdx.x;
     const int nfirst = pairing ? P.pair_solo + npairs : P.num_envs;
     if (completion) {
         // Completion launch (always follows the scheduled one and k_sched_scan, SQ_RESCUE workgroups): workgroup b takes the b-th env of the list of
@@ -787,6 +827,9 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
                 item = sq_pop(P, D, home, lev, kind);
                 if (item < 0 && (idle & 3) == 3)
                     for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev, kind); if (item >= 0) x = y; }
+#ifdef BP_SCHED_TRACE
+                _tr_idle = idle;
+#endif
                 if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs || sq_ld(sq_abort(D)) != 0) break;
                 // watchdog: ~20 s of empty polls can only mean a scheduler fault -- raise the abort flag (every poller leaves on it) and leave rather
                 // than hold the GPU; the completion launch finishes the envs that are still parked
@@ -854,6 +897,9 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
     else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
+#ifdef BP_SCHED_TRACE   // diagnostic build (tools/sched_trace.py): every task's (env, levels, XCD, start, end) in the 100 MHz reference clock, into D.prof
+    const unsigned long long _tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int lev_out = lev + 1, light_out = 0;
     // P.sq_hold: the envs of the top issue-priority class -- the heaviest quarter of the dispatch order, and envs that left a pair as heavy -- keep their slot
     // while other envs merely have not started yet: their chain is what the launch waits for at the end, and a first chunk that waits costs it a round
@@ -861,6 +907,19 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
                                                           &light_out, P.sq_hold != 0 && (item >> 24) == 3);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifdef BP_SCHED_TRACE
+    if (lane == 0 && D.prof != nullptr) {
+        const unsigned long long _tr1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long idx = atomicAdd(&D.prof[0], 1ull);
+        unsigned long long *o = D.prof + 8 + 4 * idx;
+        o[0] = (unsigned long long)(unsigned)env | ((unsigned long long)(unsigned)lev << 32) | ((unsigned long long)(unsigned)(done ? 255 : lev_out) << 40) | ((unsigned long long)(unsigned)home << 48) |
+               ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)(((int)blockIdx.x < P.num_envs) ? 1u : 0u) << 56);
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));   // wave slot, SIMD, CU, SE of this wave: which slot the task ran in
+        o[1] = _tr0; o[2] = _tr1;
+        o[3] = ((_tr0 - _trw) << 32) | ((unsigned long long)(hwid & 0xFFFFu) << 16) | (unsigned long long)(unsigned)min(_tr_idle, 65535);   // workgroup start -> task start, slot id, empty polls
+    }
+#endif
     if (lane == 0) {
         if (done) { D.sq_done[env] = 1; if (!completion) atomicAdd(sq_finished(D), 1); }
         else {
