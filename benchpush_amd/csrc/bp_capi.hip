@@ -26,6 +26,8 @@ struct bp_handle {
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
     bool damp = false;     // bp_config.damping_pow != 0: k_physics_step_damp / k_physics_reset_damp (generic vertex loops, no scheduler)
     int pair_mode = 0;              // two envs per wavefront (bp_physics_pair.hpp): 1 = fixed pairs for the whole step (k_physics_step_pair), 2 = inside the scheduler
+    int sched_persist = 0;          // > 0: the scheduled launch is k_physics_step_schedl with this many resident workgroups (BP_SCHED_PERSIST)
+    void *pd_buf = nullptr;         // its launch constants in device memory (DevParams, DevPtrs)
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
     hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel; ship-ice: the solo kernel of a pairing launch
     std::vector<hipStream_t> st_parts;   // ship-ice: the scheduled launch split over several hardware queues (BP_SCHED_PARTS)
@@ -99,6 +101,18 @@ static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
 #endif
 static size_t lds_bytes_for(int nbcap, bool box) { return bp_lds_map(nbcap, mvcap_for(nbcap), box, BP_PROF_HOST).total; }
 
+// Resident wavefronts for a scheduled launch without pairing (k_physics_step_schedl*): one workgroup per wave slot of the device, BP_SCHED_PERSIST=0 goes back to
+// one workgroup per task from the hardware dispatcher, BP_SCHED_PERSIST=n > 1 launches n workgroups per slot (the surplus waits for the end and leaves)
+static int sched_persist_setup(bp_handle *h)
+{
+    hipDeviceProp_t prop;
+    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+    const int slots = prop.multiProcessorCount * 8;   // 4 SIMDs x 2 wavefronts of 256 VGPRs
+    const int pers = getenv("BP_SCHED_PERSIST") ? atoi(getenv("BP_SCHED_PERSIST")) : 1;
+    h->sched_persist = pers > 0 ? std::min(h->num_envs, slots * pers) : 0;
+    if (h->sched_persist && !h->pd_buf) HIPCHK(h, hipMalloc(&h->pd_buf, sizeof(DevParams) + sizeof(DevPtrs)));
+    return BP_OK;
+}
 extern "C" {
 
 int32_t bp_abi_version(void) { return BP_ABI_VERSION; }
@@ -175,6 +189,7 @@ int bp_destroy(bp_handle *h)
     if (!h) return BP_EINVAL;
     DevGuard _dg(h->device);
     if (h->st_aux) { hipStreamSynchronize(h->st_aux); hipStreamDestroy(h->st_aux); }
+    if (h->pd_buf) hipFree(h->pd_buf);
     if (h->st_aux2) { hipStreamSynchronize(h->st_aux2); hipStreamDestroy(h->st_aux2); }
     for (hipStream_t s_ : h->st_parts) { hipStreamSynchronize(s_); hipStreamDestroy(s_); }
     for (hipEvent_t e_ : h->ev_parts) hipEventDestroy(e_);
@@ -355,6 +370,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->P.sq_bw = std::max(1, getenv("BP_SCHED_BW") ? atoi(getenv("BP_SCHED_BW")) : 9000);     // ~1 ms of a wavefront at 2.4 GHz
             h->P.sq_hyst = std::max(0, getenv("BP_SCHED_HYST") ? atoi(getenv("BP_SCHED_HYST")) : 1);
             h->P.sq_floor = std::max(0, getenv("BP_SCHED_FLOOR") ? atoi(getenv("BP_SCHED_FLOOR")) : 150);
+            h->P.sq_cls = getenv("BP_SCHED_CLS") ? atoi(getenv("BP_SCHED_CLS")) : 0;
             h->P.sq_parts = std::min(8, std::max(1, getenv("BP_SCHED_PARTS") ? atoi(getenv("BP_SCHED_PARTS")) : 1));
             h->P.sq_part = 0;
             h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
@@ -401,6 +417,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             }
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            if (h->P.pair_mode != 2 && h->P.sq_parts == 1) { int rc2 = sched_persist_setup(h); if (rc2) return rc2; }
         }
     }
     if (h->pair_mode == 2 && h->P.pair_mode != 2) h->pair_mode = 0;   // pairing inside the scheduler needs the scheduler
@@ -434,6 +452,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
 #endif
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            if ((rc = sched_persist_setup(h))) return rc;
         }
         HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
         HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_reset_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -741,7 +761,17 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             // preemptive scheduler: one workgroup per (env, chunk) task (most leave at once: only parked envs need a second workgroup)
             hipLaunchKernelGGL(k_sched_init, dim3(16), dim3(1024), 0, st, h->P, h->D);
             HIPCHK(h, hipGetLastError());
-            if (h->maze8)
+            if (h->sched_persist) {
+                // resident wavefronts: one workgroup per wave slot for the whole launch; the launch constants go through device memory (see sched_persist_body)
+                DevParams *Pg = (DevParams *)h->pd_buf;
+                DevPtrs *Dg = (DevPtrs *)((char *)h->pd_buf + sizeof(DevParams));
+                hipLaunchKernelGGL(k_store_params, dim3(1), dim3(64), 0, st, h->P, h->D, Pg, Dg);
+                HIPCHK(h, hipGetLastError());
+                if (h->maze8)
+                    hipLaunchKernelGGL(k_physics_step_schedl_maze, dim3(h->sched_persist), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
+                else
+                    hipLaunchKernelGGL(k_physics_step_schedl, dim3(h->sched_persist), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
+            } else if (h->maze8)
                 hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             else if (h->P.pair_mode == 2) {
                 // a pairing launch is two kernels side by side: the envs that start alone on the lean solo code (second stream), everything else -- paired

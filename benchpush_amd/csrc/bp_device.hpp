@@ -33,6 +33,7 @@ struct DevParams {
     double ship_head[2], ship_tail[2];
     int obs_h, obs_w, grid_h, grid_w;
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
+    int sq_cls;                                // issue-priority classes of the dispatch order: 0 = quarter / quarter / half -> 3 / 1 / 0, 1 = 1/16, 3/16, 1/4, 1/2 -> 3 / 2 / 1 / 0
     int sq_parts, sq_part;                     // the scheduled launch as sq_parts kernels on as many streams; this kernel's index
     int sq_floor;                              // longest-remaining-first: lower bound of the estimated cost per sub-step left (wave cycles >> 8)
     int sq_lrpt, sq_bw, sq_hyst;               // longest-remaining-first scheduling: on / row width in wave cycles >> 8 / rows a waiting env must be ahead by

@@ -928,6 +928,116 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         }
     }
 }
+// ---- the same scheduler with resident wavefronts (P.sq_persist, k_physics_step_schedl) ----------------------------------------------------------------------
+// What the hardware dispatcher costs the launch above (tools/micro/wg_turnover.hip, tools/sched_trace.py): workgroup i goes to XCD i % 8, and inside an XCD the
+// workgroups go round-robin to its four shader engines IN ORDER -- the dispatcher waits while the next engine in turn has no free wave slot, whatever is free
+// in the other three.  With tasks that end one by one at random times that leaves ~6 % of the slot-time empty (mean 90 us between a task's end and the next
+// workgroup's start in the same slot).  Here one workgroup per wave slot stays for the whole launch and takes task after task itself: first chunks in dispatch
+// order from a counter (the "first chunks started" counter, one atomicAdd each), then the least-advanced waiting env of its XCD, exactly as the pollers above.
+// Every pass of the loop re-reads the launch constants through a pointer the compiler cannot see through (params_of): kept loop-invariant they would be hoisted out of the
+// loop into ~200 SGPRs that live across the whole step body -- the register allocation that sank the first resident version (1 332 spill reloads).
+template <int KIND>
+__device__ __forceinline__ void sched_persist_body(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                   double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                   unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    const int lane = lane_id();
+    const int home = sq_xcc_id();
+    for (;;) {
+        unsigned long long pa = (unsigned long long)Pg, da = (unsigned long long)Dg;
+        asm volatile("" : "+s"(pa), "+s"(da));
+        const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)pa;
+        const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)da;
+        int item = -1, lev = 0, x = home;
+#ifdef BP_SCHED_TRACE
+        const unsigned long long _trw = __builtin_amdgcn_s_memrealtime();
+        int _tr_idle = 0, _tr_first = 0;
+#endif
+        if (lane == 0) {
+            const int limit = P.sq_debug ? 64 : (1 << 20);
+            for (int idle = 0;; idle++) {
+#ifdef BP_SCHED_TRACE
+                _tr_idle = idle;
+#endif
+                if (sq_ld(sq_started(D)) < P.num_envs) {
+                    const int pos = atomicAdd(sq_started(D), 1);
+                    if (pos < P.num_envs) {
+                        const int cls = P.sq_cls ? ((pos < P.num_envs / 16) ? 3 : (pos < P.num_envs / 4) ? 2 : (pos < P.num_envs / 2) ? 1 : 0)
+                                                 : ((pos < P.num_envs / 4) ? 3 : (pos < P.num_envs / 2) ? 1 : 0);
+                        item = (D.order != nullptr ? D.order[pos] : pos) | (cls << 24);
+#ifdef BP_SCHED_TRACE
+                        _tr_first = 1;
+#endif
+                        break;
+                    }
+                }
+                int kind = 0;
+                item = sq_pop(P, D, home, lev, kind);
+                if (item < 0 && (idle & 3) == 3)
+                    for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev, kind); if (item >= 0) x = y; }
+                if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs || sq_ld(sq_abort(D)) != 0) break;
+                if (idle > limit) { if (atomicExch(sq_abort(D), 1) == 0) atomicAdd(&D.sq_warn[0], 1); break; }
+                for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
+            }
+        }
+        item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
+        if (item < 0) return;
+        const int env = item & 0xFFFFFF;
+        if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
+        else if ((item >> 24) == 2) __builtin_amdgcn_s_setprio(2);
+        else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        int lev_out = lev + 1, light_out = 0;
+#ifdef BP_SCHED_TRACE
+        const unsigned long long _tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+        const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, false,
+                                                              &light_out, false);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifdef BP_SCHED_TRACE   // the record of sched_body's trace; "workgroup start" is the end of the wave's previous task
+        if (lane == 0 && D.prof != nullptr) {
+            const unsigned long long _tr1 = __builtin_amdgcn_s_memrealtime();
+            const unsigned long long idx = atomicAdd(&D.prof[0], 1ull);
+            unsigned long long *o = D.prof + 8 + 4 * idx;
+            o[0] = (unsigned long long)(unsigned)env | ((unsigned long long)(unsigned)lev << 32) | ((unsigned long long)(unsigned)(done ? 255 : lev_out) << 40) | ((unsigned long long)(unsigned)home << 48) |
+                   ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(_tr_first) << 56);
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            o[1] = _tr0; o[2] = _tr1;
+            o[3] = ((_tr0 - _trw) << 32) | ((unsigned long long)(hwid & 0xFFFFu) << 16) | (unsigned long long)(unsigned)min(__builtin_amdgcn_readfirstlane(_tr_idle), 65535);
+        }
+#endif
+        if (lane == 0) {
+            if (done) { D.sq_done[env] = 1; atomicAdd(sq_finished(D), 1); }
+            else {
+                D.sq_lev[env] = lev_out;
+                if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x, lev_out, item);
+            }
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_store_params(const DevParams P, const DevPtrs D, DevParams *Pg, DevPtrs *Dg)
+{
+    static_assert(sizeof(DevParams) % 4 == 0 && sizeof(DevPtrs) % 4 == 0, "copied as 32-bit words");
+    const unsigned *sp = (const unsigned *)&P, *sd = (const unsigned *)&D;
+    for (unsigned i = threadIdx.x; i < sizeof(DevParams) / 4; i += blockDim.x) ((unsigned *)Pg)[i] = sp[i];
+    for (unsigned i = threadIdx.x; i < sizeof(DevPtrs) / 4; i += blockDim.x) ((unsigned *)Dg)[i] = sd[i];
+}
+__global__ __launch_bounds__(64, 2) void k_physics_step_schedl(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_persist_body<0>(Pg, Dg, actions, reward, terminated, truncated, info);
+}
+__global__ __launch_bounds__(64, 2) void k_physics_step_schedl_maze(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                                 double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                                 unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_persist_body<BP_ENV_MAZE>(Pg, Dg, actions, reward, terminated, truncated, info);
+}
 #ifndef BP_SCHED_WAVES
 #define BP_SCHED_WAVES 2
 #endif

@@ -22,6 +22,8 @@ g = torch.Generator(device=env.device); g.manual_seed(1234)
 SLOTS = 2048
 for t in range(STEPS):
     a = (torch.rand(E, generator=g, device=env.device, dtype=torch.float64) * 2 - 1).float().double()
+    if os.environ.get("BP_TRACE_DET"):   # actions that depend on (env id, step) only: the first envs of runs with different E see the same episode
+        a = torch.remainder(torch.arange(E, device=env.device, dtype=torch.float64) * 0.37 + t * 0.11, 2.0) - 1.0
     prof.zero_()
     _, _, term, _, _ = env.step(a)
     torch.cuda.synchronize()
@@ -44,7 +46,7 @@ for t in range(STEPS):
         print("step %d: %d tasks (%.2f per env), launch %.2f ms, slot-time %.1f slot-ms = %.1f %% of %d slots x launch; work bound %.2f ms" % (
             t, n, n / E, end / 1e3, busy / 1e3, 100 * busy / (SLOTS * end), SLOTS, busy / SLOTS / 1e3))
         q = first == 0
-        print("   tasks taken from the queues: %d; workgroup start -> task start: mean %.1f us, p50 %.1f, p90 %.1f, p99 %.1f, sum %.1f slot-ms; with no empty poll: %d tasks, mean %.1f us" % (
+        if q.any(): print("   tasks taken from the queues: %d; workgroup start -> task start: mean %.1f us, p50 %.1f, p90 %.1f, p99 %.1f, sum %.1f slot-ms; with no empty poll: %d tasks, mean %.1f us" % (
             q.sum(), pre[q].mean(), np.percentile(pre[q], 50), np.percentile(pre[q], 90), np.percentile(pre[q], 99), pre[q].sum() / 1e3, (q & (idle == 0)).sum(),
             pre[q & (idle == 0)].mean() if (q & (idle == 0)).any() else 0))
         # per hardware slot (XCD, SE / CU / SIMD / wave id): the gap between the end of a task and the start of the next one in the same slot
@@ -53,7 +55,7 @@ for t in range(STEPS):
         ss, a0, a1, pr = slot[o_], t0[o_], t1[o_], pre[o_]
         same = ss[1:] == ss[:-1]
         gaps = (a0[1:] - pr[1:] - a1[:-1])[same]          # next workgroup's own start minus this task's end
-        print("   %d distinct slots seen; gap end-of-task -> start of the next workgroup in the same slot: n %d mean %.1f us p50 %.1f p90 %.1f p99 %.1f max %.1f, sum %.1f slot-ms" % (
+        if same.any(): print("   %d distinct slots seen; gap end-of-task -> start of the next workgroup in the same slot: n %d mean %.1f us p50 %.1f p90 %.1f p99 %.1f max %.1f, sum %.1f slot-ms" % (
             len(np.unique(slot)), same.sum(), gaps.mean(), np.percentile(gaps, 50), np.percentile(gaps, 90), np.percentile(gaps, 99), gaps.max(), gaps.sum() / 1e3))
         # utilisation over time in 0.5 ms bins
         edges = np.arange(0, end + 500, 500.0)
@@ -78,4 +80,6 @@ for t in range(STEPS):
         print("   run time per env (ms): mean %.2f p50 %.2f p90 %.2f p99 %.2f max %.2f;  end time: p50 %.2f p90 %.2f p99 %.2f max %.2f" % (
             run.mean() / 1e3, np.percentile(run, 50) / 1e3, np.percentile(run, 90) / 1e3, np.percentile(run, 99) / 1e3, run.max() / 1e3,
             np.percentile(endt, 50) / 1e3, np.percentile(endt, 90) / 1e3, np.percentile(endt, 99) / 1e3, endt.max() / 1e3))
+        if os.environ.get("BP_TRACE_DUMP") and t == STEPS - 1:
+            np.save(os.environ["BP_TRACE_DUMP"], run)
     env.reset(term)
