@@ -370,6 +370,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->P.sq_bw = std::max(1, getenv("BP_SCHED_BW") ? atoi(getenv("BP_SCHED_BW")) : 9000);     // ~1 ms of a wavefront at 2.4 GHz
             h->P.sq_hyst = std::max(0, getenv("BP_SCHED_HYST") ? atoi(getenv("BP_SCHED_HYST")) : 1);
             h->P.sq_floor = std::max(0, getenv("BP_SCHED_FLOOR") ? atoi(getenv("BP_SCHED_FLOOR")) : 150);
+            // pace-based issue priorities (physics_body: pace_prio), per cent of the reference cost for priority 3: +1.5 ... +2.4 % at 4096 envs, flat from 100 to 130
+            h->P.sq_dynprio = getenv("BP_SCHED_DYNPRIO") ? atoi(getenv("BP_SCHED_DYNPRIO")) : 115;
             h->P.sq_cls = getenv("BP_SCHED_CLS") ? atoi(getenv("BP_SCHED_CLS")) : 0;
             h->P.sq_parts = std::min(8, std::max(1, getenv("BP_SCHED_PARTS") ? atoi(getenv("BP_SCHED_PARTS")) : 1));
             h->P.sq_part = 0;
@@ -388,6 +390,10 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
               h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn;
+              unsigned *d_thr;
+              if ((rc = dalloc(h, &d_thr, (size_t)1))) return rc;
+              HIPCHK(h, hipMemset(d_thr, 0xFF, sizeof(unsigned)));
+              h->D.sq_thr = d_thr;
               int *d_sub, *d_pst;
               if ((rc = dalloc(h, &d_sub, (size_t)h->num_envs))) return rc;
               if ((rc = dalloc(h, &d_pst, (size_t)8))) return rc;
@@ -400,6 +406,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 // two environments per wavefront inside the scheduler: who starts alone, and when a half leaves its pair (pair_should_leave)
                 auto envint = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
                 h->P.pair_mode = 2;
+                if (!getenv("BP_SCHED_DYNPRIO")) h->P.sq_dynprio = 0;   // a pairing launch is throughput, not a chain: the static classes stay
                 // Up to ~6 000 envs per GPU the launch is within a few per cent of the chain of its heaviest env: only envs that are light right now run
                 // paired (a medium env beside a mate would become the longest chain), and the eighth of the dispatch order that was heaviest in the previous
                 // step starts alone.  Above, the launch is throughput: everything that fits a half-wave runs paired (same-box sweeps in profiles/r05_pair/).
@@ -445,6 +452,10 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
               if ((rc = dalloc(h, &d_warn, (size_t)2))) return rc;
               HIPCHK(h, hipMemset(d_warn, 0, 2 * sizeof(int)));
               h->D.sq_done = d_done; h->D.sq_lev = d_lev; h->D.sq_warn = d_warn;
+              unsigned *d_thr;
+              if ((rc = dalloc(h, &d_thr, (size_t)1))) return rc;
+              HIPCHK(h, hipMemset(d_thr, 0xFF, sizeof(unsigned)));
+              h->D.sq_thr = d_thr;
               int *d_sub;
               if ((rc = dalloc(h, &d_sub, (size_t)h->num_envs))) return rc;
               h->D.sq_sub = d_sub; }
@@ -662,7 +673,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         if (physics) {
             if (mode == MODE_STEP) {
                 if (h->steps_done) {
-                    hipLaunchKernelGGL(k_make_order, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->order_buf, E);
+                    hipLaunchKernelGGL(k_make_order, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->order_buf, E, (unsigned *)nullptr);
                     HIPCHK(h, hipGetLastError());
                     h->D.order = h->order_buf;
                 }
@@ -750,7 +761,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
     }
     if (physics) {
         if (mode == MODE_STEP && h->steps_done) { // heaviest-first dispatch order from the previous step's per-env cycles
-            hipLaunchKernelGGL(k_make_order, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->order_buf, h->num_envs);
+            hipLaunchKernelGGL(k_make_order, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->order_buf, h->num_envs, h->D.sq_thr);
             HIPCHK(h, hipGetLastError());
             h->D.order = h->order_buf;
         }

@@ -34,6 +34,7 @@ struct DevParams {
     int obs_h, obs_w, grid_h, grid_w;
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
     int sq_cls;                                // issue-priority classes of the dispatch order: 0 = quarter / quarter / half -> 3 / 1 / 0, 1 = 1/16, 3/16, 1/4, 1/2 -> 3 / 2 / 1 / 0
+    int sq_dynprio;                            // > 0: issue priority re-set at every chunk boundary from the env's projected step length (per cent of *sq_thr for priority 3)
     int sq_parts, sq_part;                     // the scheduled launch as sq_parts kernels on as many streams; this kernel's index
     int sq_floor;                              // longest-remaining-first: lower bound of the estimated cost per sub-step left (wave cycles >> 8)
     int sq_lrpt, sq_bw, sq_hyst;               // longest-remaining-first scheduling: on / row width in wave cycles >> 8 / rows a waiting env must be ahead by
@@ -84,6 +85,7 @@ struct DevPtrs {
     unsigned char *sq_moved; // [E][nbcap] shape moved in an earlier chunk of this step
     int *sq_done;            // [E] the env's step is complete (cleared by k_sched_init)
     int *sq_lev;             // [E] chunks completed when the env was last parked
+    unsigned *sq_thr;        // [1] cost (256-cycle units) of the previous step's env at rank E / 256 from the top: k_make_order; 0xFFFFFFFF before the first step
     int *sq_sub;             // [E] sub-steps of the current step completed when the env was last parked (0: not parked in this step); cleared by k_sched_init
     int *sq_pairstat;        // [8] cumulative: paired first tasks, paired tasks taken from the queues, halves that finished their step in a pair, halves that left as
                              //     heavy (carried on alone in the same slot), heavy halves queued, light halves queued (split mates + yields), tasks declined at load, -

@@ -448,6 +448,20 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
     const int it_first = CHUNKED ? c_sub : 0;
     const unsigned carry_units = (CHUNKED && c_sub > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u;   // wave cycles >> 8 of the step's earlier runs
+    // P.sq_dynprio: issue priority by the env's own pace.  An env that runs on at a chunk boundary is behind the others, and the envs whose step projects
+    // longest are the chain the launch ends with: they get the SIMD ahead of the wave they share it with (an env alone on its SIMD runs 1.2-1.4 x faster than
+    // beside a second wave: tools/sched_trace.py with 512 envs).  Priority 3 from P.sq_dynprio per cent of the previous step's 99.6th-percentile env cost
+    // (k_make_order), 2 from 5/6 and 1 from 2/3 of that; the projection is cycles so far / sub-steps so far x sub-steps of the step, at the start of a step
+    // the env's previous cost.  Replaces the three static classes of the dispatch order for the launch (they are what a task starts with otherwise).
+    auto pace_prio = [&](const unsigned long long el, const int done) {
+        const unsigned long long proj = done > 0 ? el * (unsigned)nsub / (unsigned)done : el;
+        const unsigned long long t3 = D.sq_thr != nullptr ? (unsigned long long)D.sq_thr[0] * (unsigned)P.sq_dynprio / 100ull : ~0ull >> 8;
+        if (proj >= t3) __builtin_amdgcn_s_setprio(3);
+        else if (proj * 6 >= t3 * 5) __builtin_amdgcn_s_setprio(2);
+        else if (proj * 3 >= t3 * 2) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+    };
+    if (CHUNKED && P.sq_dynprio) pace_prio(c_sub > 0 ? carry_units : (D.order != nullptr ? D.e_cost[env] : 0u), c_sub);
     int c_it_parked = 0;
     bool step_done = true;
     int to_boundary = CHUNKED ? P.sq_chunk : 0x7FFFFFFF;   // sub-steps until the next chunk boundary
@@ -473,6 +487,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                     if (P.sq_debug && c_env == 1 && it == P.sq_chunk) yield = 1;
                 }
                 if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = __builtin_amdgcn_readfirstlane(key); c_it_parked = it; break; }
+                if (P.sq_dynprio) pace_prio((unsigned long long)carry_units + ((__builtin_amdgcn_s_memtime() - t_begin) >> 8), it);
                 to_boundary = P.sq_chunk;
             }
             to_boundary--;
@@ -1107,7 +1122,9 @@ __global__ __launch_bounds__(64, 2) void k_bd_settle_damp(const DevParams P, con
 // Dispatch order for the next step: envs sorted by the cycles their last step took, heaviest first (bucket sort).
 // Workgroups start in index order, so the long-running environments start first and the launch tail shrinks.
 // The order only permutes independent environments: results do not depend on it.
-__global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict__ cost, int *__restrict__ order, int n)
+// thr (may be null): [0] = the cost of the env at rank n / 256 from the top (the reference of the scheduler's pace-based issue priorities), to the resolution of
+// the 256 buckets
+__global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict__ cost, int *__restrict__ order, int n, unsigned *__restrict__ thr)
 {
     __shared__ unsigned hist[257];
     __shared__ unsigned smax;
@@ -1127,7 +1144,10 @@ __global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict_
     __syncthreads();
     if (tid == 0) {
         unsigned acc = 0;
-        for (int b = 0; b < 256; b++) { const unsigned c = hist[b]; hist[b] = acc; acc += c; }
+        const unsigned rank = (unsigned)max(1, n / 256);
+        int tb = -1;
+        for (int b = 0; b < 256; b++) { const unsigned c = hist[b]; hist[b] = acc; acc += c; if (tb < 0 && acc >= rank) tb = b; }
+        if (thr != nullptr) thr[0] = (unsigned)((m * (unsigned long long)(255 - max(tb, 0))) / 255ull);
     }
     __syncthreads();
     for (int i = tid; i < n; i += blockDim.x) {
