@@ -425,6 +425,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            // (resident wavefronts for the kernel that holds both step bodies lost 4 % at 8192 envs to its register allocation -- 266 spilled VGPRs in the loop
+            // against 203: pairing launches keep one workgroup per task from the hardware dispatcher)
             if (h->P.pair_mode != 2 && h->P.sq_parts == 1) { int rc2 = sched_persist_setup(h); if (rc2) return rc2; }
         }
     }
@@ -773,7 +775,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             hipLaunchKernelGGL(k_sched_init, dim3(16), dim3(1024), 0, st, h->P, h->D);
             HIPCHK(h, hipGetLastError());
             if (h->sched_persist) {
-                // resident wavefronts: one workgroup per wave slot for the whole launch; the launch constants go through device memory (see sched_persist_body)
+                // resident wavefronts: one workgroup per wave slot for the whole launch; the launch constants go through device memory (see sched_resident)
                 DevParams *Pg = (DevParams *)h->pd_buf;
                 DevPtrs *Dg = (DevPtrs *)((char *)h->pd_buf + sizeof(DevParams));
                 hipLaunchKernelGGL(k_store_params, dim3(1), dim3(64), 0, st, h->P, h->D, Pg, Dg);

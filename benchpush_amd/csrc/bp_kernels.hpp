@@ -783,10 +783,12 @@ __global__ __launch_bounds__(256) void k_sched_scan(const DevParams P, const Dev
 // 245 k env-steps/s with pairing switched off, same box) -- and the solo body is the chain of the heaviest envs.  A pairing launch runs both kernels side by
 // side on two streams: ROLE 0 with exactly P.pair_solo workgroups (the envs that start alone, on the lean code), ROLE 1 with the rest.
 template <int KIND, int ROLE = 0>
-__device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
+__device__ __forceinline__ bool sched_body(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions,
                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                           unsigned char *__restrict__ truncated, double *__restrict__ info)
+                                           unsigned char *__restrict__ truncated, double *__restrict__ info, const int bid_in = -1)
 {
+    // bid_in >= 0 (sched_resident): the position in the dispatch order that this pass of a resident workgroup serves (>= the number of first tasks: it serves
+    // the queues); the return value tells it to leave (every env has finished, or the watchdog has fired)
     const int lane = lane_id();
     const int home = sq_xcc_id();
 #ifdef BP_SCHED_TRACE
@@ -810,7 +812,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
     // queue whose next workgroup is bound for a full shader engine leaves free slots elsewhere idle; part k starts the envs at positions k, k + parts, ...
     // of the dispatch order with its first num_envs / parts workgroups)
     const int nfirst_part = (ROLE == 0 && P.sq_parts > 1) ? (P.num_envs - P.sq_part + P.sq_parts - 1) / P.sq_parts : 0;
-    const int bid = (ROLE == 1) ? (int)blockIdx.x + P.pair_solo
+    const int bid = (bid_in >= 0) ? bid_in : (ROLE == 1) ? (int)blockIdx.x + P.pair_solo
                   : (P.sq_parts > 1) ? (((int)blockIdx.x < nfirst_part) ? (int)blockIdx.x * P.sq_parts + P.sq_part : P.num_envs + (int)blockIdx.x)
                   : (int)blockIdx.x;
     const int nfirst = pairing ? P.pair_solo + npairs : P.num_envs;
@@ -818,7 +820,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         // Completion launch (always follows the scheduled one and k_sched_scan, SQ_RESCUE workgroups): workgroup b takes the b-th env of the list of
         // unfinished envs and leaves at once if the list is shorter -- the normal case: it is empty.  After a scheduler fault (watchdog) such an env's
         // state is that of its last chunk boundary: the step is resumed there and run to its end.
-        if ((int)blockIdx.x >= D.sq_rescue[0]) return;
+        if ((int)blockIdx.x >= D.sq_rescue[0]) return true;
         item = D.sq_rescue[1 + blockIdx.x]; lev = D.sq_lev[item];
         if (lane == 0) atomicAdd(&D.sq_warn[1], 1);
     } else if (pairing && bid >= P.pair_solo && bid < nfirst) {
@@ -857,7 +859,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         }
         item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
         mate = __builtin_amdgcn_readfirstlane(mate);
-        if (item < 0) return;
+        if (item < 0) return true;
         if (mate >= 0) { pe0 = item & 0xFFFFFF; pe1 = mate & 0xFFFFFF; item = -1; }
     }
     if (ROLE == 1 && pe0 >= 0) {
@@ -890,7 +892,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
             atomicAdd(&D.sq_pairstat[bid < nfirst ? 0 : 1], 1);
             if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
         }
-        if (!pk0 && !pk1) return;
+        if (!pk0 && !pk1) return false;
         // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
         const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
         if (lane == 0) {
@@ -903,7 +905,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
                 if (ql) atomicAdd(&D.sq_pairstat[5], ql);
             }
         }
-        if (!c0 && !c1) return;
+        if (!c0 && !c1) return false;
         item = (c0 ? pe0 : pe1) | (3 << 24);   // top issue priority: it left its pair because it is heavy
         lev = (c0 ? it0 : it1) / P.sq_chunk;
         __syncthreads();
@@ -928,7 +930,7 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
         const unsigned long long idx = atomicAdd(&D.prof[0], 1ull);
         unsigned long long *o = D.prof + 8 + 4 * idx;
         o[0] = (unsigned long long)(unsigned)env | ((unsigned long long)(unsigned)lev << 32) | ((unsigned long long)(unsigned)(done ? 255 : lev_out) << 40) | ((unsigned long long)(unsigned)home << 48) |
-               ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)(((int)blockIdx.x < P.num_envs) ? 1u : 0u) << 56);
+               ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)((bid < nfirst) ? 1u : 0u) << 56);
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));   // wave slot, SIMD, CU, SE of this wave: which slot the task ran in
         o[1] = _tr0; o[2] = _tr1;
@@ -942,97 +944,51 @@ __device__ __forceinline__ void sched_body(const DevParams &P, const DevPtrs &D,
             if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((P.pair_mode == 2 && !completion && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
         }
     }
+    return false;
 }
-// ---- the same scheduler with resident wavefronts (P.sq_persist, k_physics_step_schedl) ----------------------------------------------------------------------
+// ---- the same scheduler with resident wavefronts (k_physics_step_schedl*, the default of a scheduled launch without pairing) -----------------------------------
 // What the hardware dispatcher costs the launch above (tools/micro/wg_turnover.hip, tools/sched_trace.py): workgroup i goes to XCD i % 8, and inside an XCD the
-// workgroups go round-robin to its four shader engines IN ORDER -- the dispatcher waits while the next engine in turn has no free wave slot, whatever is free
-// in the other three.  With tasks that end one by one at random times that leaves ~6 % of the slot-time empty (mean 90 us between a task's end and the next
-// workgroup's start in the same slot).  Here one workgroup per wave slot stays for the whole launch and takes task after task itself: first chunks in dispatch
-// order from a counter (the "first chunks started" counter, one atomicAdd each), then the least-advanced waiting env of its XCD, exactly as the pollers above.
-// Every pass of the loop re-reads the launch constants through a pointer the compiler cannot see through (params_of): kept loop-invariant they would be hoisted out of the
-// loop into ~200 SGPRs that live across the whole step body -- the register allocation that sank the first resident version (1 332 spill reloads).
-template <int KIND>
-__device__ __forceinline__ void sched_persist_body(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
-                                                   double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                   unsigned char *__restrict__ truncated, double *__restrict__ info)
+// workgroups go round-robin to its four shader engines IN ORDER -- the dispatcher waits while the engine whose turn it is has no free wave slot, whatever is free
+// in the other three (a model that reproduces the microbenchmark's launch times to three digits).  With tasks that end one by one at random times that leaves
+// ~6 % of the slot-time empty: mean 90 us, p99 0.9 ms between a task's end and the next workgroup's start in the same slot.  Here one workgroup per wave slot
+// stays for the whole launch and takes task after task itself (1.1 us between tasks): positions of the dispatch order from a counter while there are first
+// tasks, then the least-advanced waiting env of its XCD -- sched_body with the position handed in.
+// Every pass of the loop reads the launch constants from device memory (k_store_params) through a pointer the compiler cannot follow out of the loop: as
+// kernel arguments they are loop invariants that get hoisted into ~200 SGPRs living across the whole step body -- the register allocation that sank the
+// first resident version (127 k against 193 k env-steps/s, 1 332 spill reloads).  Read this way they are scalar loads next to their uses: 296 v_readlane
+// and 118 spilled SGPRs against 877 / 268 in k_physics_step_sched.  (The same constants by pointer WITHOUT the loop: -14 %; DevParams by value inside the loop: -1 %.)
+__device__ __forceinline__ int *sq_nextpos(const DevPtrs &D) { return sq_row(D, 2, SQ_MAXLEV + 1); }
+template <int KIND, int ROLE>
+__device__ __forceinline__ void sched_resident(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                               double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                               unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
-    const int lane = lane_id();
-    const int home = sq_xcc_id();
     for (;;) {
         unsigned long long pa = (unsigned long long)Pg, da = (unsigned long long)Dg;
         asm volatile("" : "+s"(pa), "+s"(da));
         const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)pa;
         const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)da;
-        int item = -1, lev = 0, x = home;
-#ifdef BP_SCHED_TRACE
-        const unsigned long long _trw = __builtin_amdgcn_s_memrealtime();
-        int _tr_idle = 0, _tr_first = 0;
-#endif
-        if (lane == 0) {
-            const int limit = P.sq_debug ? 64 : (1 << 20);
-            for (int idle = 0;; idle++) {
-#ifdef BP_SCHED_TRACE
-                _tr_idle = idle;
-#endif
-                if (sq_ld(sq_started(D)) < P.num_envs) {
-                    const int pos = atomicAdd(sq_started(D), 1);
-                    if (pos < P.num_envs) {
-                        const int cls = P.sq_cls ? ((pos < P.num_envs / 16) ? 3 : (pos < P.num_envs / 4) ? 2 : (pos < P.num_envs / 2) ? 1 : 0)
-                                                 : ((pos < P.num_envs / 4) ? 3 : (pos < P.num_envs / 2) ? 1 : 0);
-                        item = (D.order != nullptr ? D.order[pos] : pos) | (cls << 24);
-#ifdef BP_SCHED_TRACE
-                        _tr_first = 1;
-#endif
-                        break;
-                    }
-                }
-                int kind = 0;
-                item = sq_pop(P, D, home, lev, kind);
-                if (item < 0 && (idle & 3) == 3)
-                    for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev, kind); if (item >= 0) x = y; }
-                if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs || sq_ld(sq_abort(D)) != 0) break;
-                if (idle > limit) { if (atomicExch(sq_abort(D), 1) == 0) atomicAdd(&D.sq_warn[0], 1); break; }
-                for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
-            }
-        }
-        item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
-        if (item < 0) return;
-        const int env = item & 0xFFFFFF;
-        if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
-        else if ((item >> 24) == 2) __builtin_amdgcn_s_setprio(2);
-        else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
-        else __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        int lev_out = lev + 1, light_out = 0;
-#ifdef BP_SCHED_TRACE
-        const unsigned long long _tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-        const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, false,
-                                                              &light_out, false);
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#ifdef BP_SCHED_TRACE   // the record of sched_body's trace; "workgroup start" is the end of the wave's previous task
-        if (lane == 0 && D.prof != nullptr) {
-            const unsigned long long _tr1 = __builtin_amdgcn_s_memrealtime();
-            const unsigned long long idx = atomicAdd(&D.prof[0], 1ull);
-            unsigned long long *o = D.prof + 8 + 4 * idx;
-            o[0] = (unsigned long long)(unsigned)env | ((unsigned long long)(unsigned)lev << 32) | ((unsigned long long)(unsigned)(done ? 255 : lev_out) << 40) | ((unsigned long long)(unsigned)home << 48) |
-                   ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(_tr_first) << 56);
-            unsigned hwid;
-            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-            o[1] = _tr0; o[2] = _tr1;
-            o[3] = ((_tr0 - _trw) << 32) | ((unsigned long long)(hwid & 0xFFFFu) << 16) | (unsigned long long)(unsigned)min(__builtin_amdgcn_readfirstlane(_tr_idle), 65535);
-        }
-#endif
-        if (lane == 0) {
-            if (done) { D.sq_done[env] = 1; atomicAdd(sq_finished(D), 1); }
-            else {
-                D.sq_lev[env] = lev_out;
-                if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x, lev_out, item);
-            }
-        }
+        __builtin_amdgcn_s_setprio(0);
+        const bool pairing = ROLE == 1 && KIND == BP_ENV_SHIP_ICE && P.pair_mode == 2;
+        const int nfirst = pairing ? P.pair_solo + (P.num_envs - P.pair_solo + 1) / 2 : P.num_envs;
+        int bid = nfirst;
+        if (lane_id() == 0 && sq_ld(sq_nextpos(D)) < nfirst) bid = min(atomicAdd(sq_nextpos(D), 1), nfirst);
+        bid = __builtin_amdgcn_readfirstlane(bid);
+        if (sched_body<KIND, ROLE>(P, D, actions, reward, terminated, truncated, info, bid)) return;
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(64, 2) void k_physics_step_schedl(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                             double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                             unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_resident<0, 0>(Pg, Dg, actions, reward, terminated, truncated, info);
+}
+__global__ __launch_bounds__(64, 2) void k_physics_step_schedl_maze(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                                 double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                                 unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_resident<BP_ENV_MAZE, 0>(Pg, Dg, actions, reward, terminated, truncated, info);
 }
 __global__ void k_store_params(const DevParams P, const DevPtrs D, DevParams *Pg, DevPtrs *Dg)
 {
@@ -1040,18 +996,6 @@ __global__ void k_store_params(const DevParams P, const DevPtrs D, DevParams *Pg
     const unsigned *sp = (const unsigned *)&P, *sd = (const unsigned *)&D;
     for (unsigned i = threadIdx.x; i < sizeof(DevParams) / 4; i += blockDim.x) ((unsigned *)Pg)[i] = sp[i];
     for (unsigned i = threadIdx.x; i < sizeof(DevPtrs) / 4; i += blockDim.x) ((unsigned *)Dg)[i] = sd[i];
-}
-__global__ __launch_bounds__(64, 2) void k_physics_step_schedl(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
-                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
-{
-    sched_persist_body<0>(Pg, Dg, actions, reward, terminated, truncated, info);
-}
-__global__ __launch_bounds__(64, 2) void k_physics_step_schedl_maze(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
-                                                                 double *__restrict__ reward, unsigned char *__restrict__ terminated,
-                                                                 unsigned char *__restrict__ truncated, double *__restrict__ info)
-{
-    sched_persist_body<BP_ENV_MAZE>(Pg, Dg, actions, reward, terminated, truncated, info);
 }
 #ifndef BP_SCHED_WAVES
 #define BP_SCHED_WAVES 2
