@@ -510,6 +510,7 @@ def main():
                                     "heavy ones alone; counters are cumulative since load (warm-up, timed and steady-state steps); BP_PAIR=0 turns it off")
     if rank == 0:
         sched_chunk = int(env.L.bp_sched_chunk(env.h)) if hasattr(env, "L") and hasattr(env.L, "bp_sched_chunk") else 0
+        resident = int(env.L.bp_sched_resident(env.h)) if hasattr(env, "L") and hasattr(env.L, "bp_sched_resident") else 0
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
@@ -523,11 +524,14 @@ def main():
             "clock_mhz": (clock_hz / 1e6) if clock_hz else None,
             "clock_source": ("s_memtime / s_memrealtime stamps of XCD %d around the timed launches" % clock_xcd) if clock_hz else
                             "no stamp pair from one XCD: issue.frac uses the nominal 2.1 GHz",
-            "kernel": (("k_physics_step_sched_maze" if args.env == "maze" else "k_physics_step_sched") if sched_chunk > 0 else
-                       ("k_physics_step_maze" if args.env == "maze" else "k_physics_step")),
+            "kernel": (("k_physics_step_sched" + ("l" if resident > 0 else "p" if pairing and pairing.get("mode") == 2 else "") + ("_maze" if args.env == "maze" else ""))
+                       if sched_chunk > 0 else ("k_physics_step_maze" if args.env == "maze" else "k_physics_step")),
             "pairing": pairing,
-            "scheduler": ({"chunk_substeps": sched_chunk, "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
-                           "least-advanced waiting env first (DESIGN.md 4a); BP_SCHED=0 selects one wavefront per env for the whole step"}
+            "scheduler": ({"chunk_substeps": sched_chunk, "resident_workgroups": resident,
+                           "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
+                           "least-advanced waiting env first (DESIGN.md 4a); resident_workgroups > 0: one workgroup per wave slot takes task after task itself "
+                           "(k_physics_step_schedl) instead of one workgroup per task from the hardware dispatcher, BP_SCHED_PERSIST=0 turns that off; "
+                           "BP_SCHED=0 selects one wavefront per env for the whole step"}
                           if sched_chunk > 0 else None),
             "achieved": a_phys * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,

@@ -22,7 +22,7 @@ INFO_KEYS = ["x", "y", "theta", "total_work", "work", "collision_reward", "scale
 ERRORS = {0: "BP_OK", -1: "BP_EINVAL", -2: "BP_ENOMEM", -3: "BP_EHIP", -4: "BP_ENODEVICE", -5: "BP_ESTATE", -6: "BP_ECAPACITY"}
 EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp_load_maze", "bp_get_goal_map", "bp_reset", "bp_step", "bp_step_physics",
            "bp_observe", "bp_observe_global", "bp_set_resettle", "bp_sizeof_config", "bp_get_world_polys", "bp_get_body_state", "bp_get_low_dim_obs", "bp_costmap_update", "bp_nb_cap", "bp_obs_height",
-           "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_set_step_cost_hint", "bp_sched_chunk", "bp_sched_warnings", "bp_get_clock_stamps", "bp_last_error",
+           "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_set_step_cost_hint", "bp_sched_chunk", "bp_sched_resident", "bp_sched_warnings", "bp_get_clock_stamps", "bp_last_error",
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
            "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2", "bp_debug_scramble_hints",
            "bp_copy_rows_masked", "bp_pair_mode", "bp_get_pair_stats", "bp_bd_get_stragglers"]
@@ -132,10 +132,12 @@ def load():
     L.bp_get_step_cycles.argtypes = [vp, vp]
     L.bp_set_step_cost_hint.argtypes = [vp, vp]
     L.bp_sched_chunk.argtypes = [vp]
+    L.bp_sched_resident.argtypes = [vp]
     L.bp_pair_mode.argtypes = [vp]
     L.bp_get_pair_stats.argtypes = [vp, vp]
     L.bp_bd_get_stragglers.argtypes = [vp, vp]
     L.bp_sched_chunk.restype = C.c_int32
+    L.bp_sched_resident.restype = C.c_int32
     if hasattr(L, "bp_get_clock_stamps"):
         L.bp_get_clock_stamps.argtypes = [vp, vp]
     if hasattr(L, "bp_sched_warnings"):   # absent from libraries of ABI 6 (tools/ab_bench.sh loads older builds for same-box comparisons)

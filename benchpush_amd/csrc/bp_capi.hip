@@ -1458,6 +1458,7 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 }
 
 int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
+int32_t bp_sched_resident(bp_handle *h) { return (h && h->sched_chunk > 0) ? h->sched_persist : 0; }
 
 int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
 {

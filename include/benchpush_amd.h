@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 9
+#define BP_ABI_VERSION 10
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -237,6 +237,10 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
  * behind, and resumed by another workgroup; results are identical), 0 = one wavefront per env for the whole step.  Default 40 for ship-ice and
  * maze handles of up to 8192 envs; environment variable BP_SCHED=<chunk> (0 = off) overrides it at load time. */
 int32_t bp_sched_chunk(bp_handle *h);
+/* Resident wavefronts of the step scheduler (k_physics_step_schedl: one workgroup per wave slot of the device takes task after task itself instead of one
+ * workgroup per task from the hardware dispatcher; results are identical): the number of resident workgroups of a scheduled launch, 0 = one workgroup per
+ * task.  Default: 8 x the device's compute units for scheduled launches without pairing; environment variable BP_SCHED_PERSIST=0 turns it off.  (ABI 10) */
+int32_t bp_sched_resident(bp_handle *h);
 /* Two environments per wavefront (ship-ice handles with space.damping == 0 and at most 272 body slots; lanes 0..31 one env, lanes 32..63 another, results
  * identical): 0 = off, 1 = fixed pairs of the dispatch order for the whole step (test kernel), 2 = inside the step scheduler: the heaviest envs of the
  * dispatch order start alone, the others in pairs, and an env that outgrows the half-wave capacities or turns heavy is parked at a sub-step boundary and

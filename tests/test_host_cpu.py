@@ -21,7 +21,7 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"bp_create", "bp_step", "bp_reset", "bp_load_scenarios", "bp_get_world_polys"} <= declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bp_abi_version() == 9
+    assert L.bp_abi_version() == 10
     assert set(_lib.EXPORTS) <= declared | {"bp_debug_trace"}
 
 
