@@ -8,6 +8,9 @@ cp -r $REPO/gpurun_out/prof_r05_final/summary.txt $REPO/gpurun_out/prof_r05_fina
 python bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 # same box, pairing off (two environments per wavefront): the A/B of the round
 BP_PAIR=0 python bench.py --no-cpu-baseline > $OUT/bench_pairing_off.json 2> $OUT/bench_pairing_off.err
+# same box, the scheduler as it was before resident wavefronts and pace priorities (one workgroup per task from the hardware dispatcher, static priority classes)
+BP_SCHED_PERSIST=0 BP_SCHED_DYNPRIO=0 python bench.py --no-cpu-baseline > $OUT/bench_dispatcher_driven.json 2> $OUT/bench_dispatcher_driven.err
+BP_SCHED_PERSIST=1 BP_SCHED_DYNPRIO=0 python bench.py --no-cpu-baseline > $OUT/bench_resident_static_classes.json 2> $OUT/bench_resident_static_classes.err
 for E in 1024 2048 3072 4096 6144 8192; do
   echo -n "E=$E: "; python bench.py --steps 30 --warmup 5 --envs-per-gpu $E --no-cpu-baseline --no-steady-state 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],3), round(d['roofline']['physics_ms'],3))"
 done > $OUT/launch_vs_envs.txt
