@@ -4,7 +4,8 @@ AreaClearingEnv.init_area_clearing_env / generate_obstacles / generate_walls / g
 ``random``; here trial t uses ``random.Random(base_seed + t)`` with the same draw order (start x, then box centres).
 shapely pieces are restated for the shipped layouts: ``create_polygon_from_line`` = the flat-capped 0.2 m wide rectangle around
 the segment, boundary goal lines = the boundary edges minus the walls' 0.1 m buffers (``cut_edge_by_wall``: exact where a wall crosses an
-edge; none of the shipped walls does), ``interpolate`` = linear.
+edge, GEOS' polygon of the round cap where a wall's end reaches one -- ``segment_buffer_ring``, restated from GEOS' published offset-curve algorithm, unpinned; none of the
+shipped walls does either), ``interpolate`` = linear.
 """
 import math
 import random as _random
@@ -45,12 +46,94 @@ def _dist_to_segment(px, py, a, b):
     return math.hypot(px - (ax + t * dx), py - (ay + t * dy))
 
 
+def segment_buffer_ring(wall, r=0.1, quad_segs=16):
+    """The outline of ``LineString(wall).buffer(r)`` as GEOS builds it for a two-point line with round caps (shapely's defaults: 16 segments per quadrant,
+    area_clearing.py:237-238), restated from the published algorithm of GEOS' OffsetCurveBuilder / OffsetSegmentGenerator (computeLineBufferCurve,
+    computeOffsetSegment, addLineEndCap, addDirectedFillet) -- the library is not in this image, so this is unpinned:
+    left offset of a -> b at b; the cap at b as a clockwise fan of ``quad_segs * 2`` chords from angle + pi/2 to angle - pi/2 (fan point i at
+    b + r (cos, sin)(angle + pi/2 - i * pi / (2 quad_segs)); the fan's first point coincides with the offset point and is dropped as GEOS drops vertices closer
+    than r * 1e-6 to their predecessor); right offset at b; then the same from b -> a.  Vertices in ring order, not closed."""
+    (ax, ay), (bx, by) = wall
+    ring = []
+
+    def add(pt):
+        if ring and math.hypot(pt[0] - ring[-1][0], pt[1] - ring[-1][1]) < r * 1.0e-6:
+            return
+        ring.append(pt)
+
+    def offset_p1(p0_, p1_, side_sign):           # computeOffsetSegment(...).p1
+        dx, dy = p1_[0] - p0_[0], p1_[1] - p0_[1]
+        ln = math.sqrt(dx * dx + dy * dy)
+        ux, uy = side_sign * r * dx / ln, side_sign * r * dy / ln
+        return (p1_[0] - uy, p1_[1] + ux)
+
+    for p0_, p1_ in (((ax, ay), (bx, by)), ((bx, by), (ax, ay))):
+        add(offset_p1(p0_, p1_, 1.0))                                            # addLastSegment
+        angle = math.atan2(p1_[1] - p0_[1], p1_[0] - p0_[0])                      # addLineEndCap, CAP_ROUND
+        add(offset_p1(p0_, p1_, 1.0))
+        start, total = angle + math.pi / 2.0, math.pi
+        nseg = int(total / (math.pi / 2.0 / quad_segs) + 0.5)
+        inc = total / nseg
+        for i in range(nseg):                                                    # addDirectedFillet, clockwise
+            a_ = start - i * inc
+            add((p1_[0] + r * math.cos(a_), p1_[1] + r * math.sin(a_)))
+        add(offset_p1(p0_, p1_, -1.0))
+    if math.hypot(ring[0][0] - ring[-1][0], ring[0][1] - ring[-1][1]) < r * 1.0e-6:
+        ring.pop()
+    return ring
+
+
+def _cut_edge_by_ring(p0, p1, ring):
+    """``LineString([p0, p1]).difference(Polygon(ring))`` for a convex ring: the pieces of the edge outside it, in the direction of the edge.  Crossing points are
+    the exact rational intersections of the edge with the ring's segments rounded to the nearest double (GEOS intersects in double-double arithmetic, which
+    rounds the same way except in contrived cases); a coordinate along which the edge does not move stays the edge's own."""
+    from fractions import Fraction as F
+    x0, y0, x1, y1 = F(p0[0]), F(p0[1]), F(p1[0]), F(p1[1])
+    ex, ey = x1 - x0, y1 - y0
+    n = len(ring)
+    # orientation of the ring, then "inside" = on the inner side of every edge (convex)
+    area2 = sum(F(ring[i][0]) * F(ring[(i + 1) % n][1]) - F(ring[(i + 1) % n][0]) * F(ring[i][1]) for i in range(n))
+    sgn = 1 if area2 > 0 else -1
+
+    def inside(px, py):
+        for i in range(n):
+            qx, qy, sx, sy = F(ring[i][0]), F(ring[i][1]), F(ring[(i + 1) % n][0]), F(ring[(i + 1) % n][1])
+            if sgn * ((sx - qx) * (py - qy) - (sy - qy) * (px - qx)) < 0:
+                return False
+        return True
+
+    ts = []
+    for i in range(n):
+        qx, qy, sx, sy = F(ring[i][0]), F(ring[i][1]), F(ring[(i + 1) % n][0]), F(ring[(i + 1) % n][1])
+        dx, dy = sx - qx, sy - qy
+        den = ex * dy - ey * dx
+        if den == 0:
+            continue
+        t = ((qx - x0) * dy - (qy - y0) * dx) / den
+        u = ((qx - x0) * ey - (qy - y0) * ex) / den
+        if 0 <= t <= 1 and 0 <= u <= 1:
+            ts.append(t)
+    in0, in1 = inside(x0, y0), inside(x1, y1)
+    if not ts:
+        return [] if (in0 and in1) else [(list(p0), list(p1))]
+
+    def point(t):
+        return [p0[0] if ex == 0 else float(x0 + t * ex), p0[1] if ey == 0 else float(y0 + t * ey)]
+
+    out = []
+    if not in0 and min(ts) > 0:
+        out.append((list(p0), point(min(ts))))
+    if not in1 and max(ts) < 1:
+        out.append((point(max(ts)), list(p1)))
+    return out
+
+
 def cut_edge_by_wall(p0, p1, wall, r=0.1):
     """``LineString([p0, p1]).difference(LineString(wall).buffer(r))`` (area_clearing.py:236-240) for one boundary edge and one wall: the parts of the
     edge outside the wall's 0.1 m buffer, in the direction of the edge.  The buffer of a segment is convex (a stadium), so it covers one interval of
     the edge.  Where the interval ends on a *straight side* of the buffer (a wall that crosses the edge) the end point is the exact intersection with
-    the offset line; where it ends on a round cap, shapely's answer depends on its 16-segments-per-quadrant polygon of the cap, which is not restated
-    here: such a layout is refused (NotImplementedError) instead of being answered approximately."""
+    the offset line; where it ends on a round cap (a wall whose END reaches the edge, area_clearing.py:225-262) the buffer is the polygon GEOS makes of the cap
+    -- 16 chords per quadrant, ``segment_buffer_ring`` -- and the end point is the crossing with that polygon (up to 0.12 mm inside the circle)."""
     (ax, ay), (bx, by) = wall
     wx, wy = bx - ax, by - ay
     wl = math.hypot(wx, wy)
@@ -87,7 +170,7 @@ def cut_edge_by_wall(p0, p1, wall, r=0.1):
     if inside0 and inside1 and not ts:
         return []   # the whole edge lies inside the buffer (convex: both ends inside, no crossing): LineString.difference is empty, the length filter drops it
     if any(k == "cap" for _, k, _ in ts):
-        raise NotImplementedError("a wall whose rounded end (buffer cap) reaches the clearance boundary needs shapely's polygon of the cap")
+        return _cut_edge_by_ring(p0, p1, segment_buffer_ring(wall, r))
     first = None if inside0 else min(ts, key=lambda c: c[0])
     last = None if inside1 else max(ts, key=lambda c: c[0])
     out = []

@@ -1,4 +1,6 @@
 """area-clearing-v0 oracle: layouts, shapely-predicate restatements against brute force, goal map rules, env-level known answers."""
+import math
+
 import numpy as np
 import pytest
 
@@ -104,7 +106,7 @@ def _wall_cut_cfg():
 def test_walls_that_cut_the_clearance_boundary():
     """_compute_boundary_goals with a wall across an edge: the edge is split at the wall's buffer, pieces keep the edge's
     direction and place, 10 goal points per piece; an oblique wall cuts at the exact intersection with its offset lines; a wall whose rounded
-    end reaches an edge is refused (shapely's cap polygon is not restated); pieces of 0.1 m or less are dropped."""
+    end reaches an edge cuts it where the edge crosses GEOS' 16-chords-per-quadrant polygon of the cap; pieces of 0.1 m or less are dropped."""
     cfg = _wall_cut_cfg()
     lines = A.boundary_goal_lines(cfg)
     assert lines[0] == ([-5.0, -5.0], [-5.0, -0.1]) and lines[1] == ([-5.0, 0.1], [-5.0, 5.0]) and len(lines) == 5
@@ -118,8 +120,31 @@ def test_walls_that_cut_the_clearance_boundary():
     assert l0 == [-5.0, 5.0] and r1 == [5.0, 5.0] and l1[0] < 1.0 < r0[0]
     # wall that does not reach the edge: untouched; wall along the edge: the covered part disappears (one end inside the buffer)
     assert A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], ((0.0, 0.0), (0.0, 4.0))) == [([-5.0, 5.0], [5.0, 5.0])]
-    with pytest.raises(NotImplementedError):
-        A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], ((0.0, 0.0), (0.0, 4.95)))      # the cap, not a straight side, reaches the edge
+    # the cap, not a straight side, reaches the edge: the cut is where the edge crosses GEOS' polygon of the cap (16 chords per quadrant),
+    # at most r (1 - cos(pi / 64)) = 0.12 mm inside the circle of radius 0.1 around the wall's end, and on the edge exactly
+    wall = ((0.0, 0.0), (0.0, 4.95))
+    (l0, l1), (r0, r1) = A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], wall)
+    half = math.sqrt(0.1 ** 2 - 0.05 ** 2)
+    assert l0 == [-5.0, 5.0] and r1 == [5.0, 5.0] and l1[1] == 5.0 and r0[1] == 5.0
+    for q, want in ((l1, -half), (r0, half)):
+        assert 0.0 <= abs(want) - abs(q[0]) <= 2.5e-4        # along the edge; the radial bound is the next line
+        assert 0.1 - 1.3e-4 <= A._dist_to_segment(q[0], q[1], *wall) <= 0.1
+    # the polygon itself: offset point, 31 fan points and offset point per end, all on the circle / the offset lines
+    ring = A.segment_buffer_ring(wall)
+    assert len(ring) == 66 and ring[0] == (-0.1, 4.95) and ring[32] == (0.1, 4.95) and ring[33] == (0.1, 0.0) and ring[65] == (-0.1, 0.0)
+    assert all(abs(A._dist_to_segment(x, y, *wall) - 0.1) < 1e-15 for x, y in ring)
+    assert abs(ring[16][0]) < 1e-16 and abs(ring[16][1] - 5.05) < 1e-15                      # the fan's middle point: straight beyond the wall's end
+    # an oblique wall whose end lies 0.07 below the edge: both cuts on the cap polygon, symmetric about the foot of the end point only in the circle limit
+    (ol0, ol1), (or0, or1) = A.cut_edge_by_wall([-5.0, 5.0], [5.0, 5.0], ((1.0, 3.0), (2.0, 4.93)))
+    assert ol1[1] == 5.0 and or0[1] == 5.0 and ol1[0] < 2.0 < or0[0]
+    for q in (ol1, or0):
+        assert 0.1 - 1.3e-4 <= math.hypot(q[0] - 2.0, q[1] - 4.93) <= 0.1 + 1e-15
+    cfg3 = default_cfg("area_clearing")
+    cfg3.env = "walled_env"
+    cfg3.envs.walled_env.walls = list(cfg3.envs.walled_env.walls) + [[[-4.95, 0.0], [-3.0, 0.0]]]
+    lines3 = A.boundary_goal_lines(cfg3)
+    assert len(lines3) == 5 and lines3[0][0] == [-5.0, -5.0] and lines3[0][1][0] == -5.0 and lines3[1][0][0] == -5.0 and lines3[1][1] == [-5.0, 5.0]
+    assert abs(lines3[0][1][1] + half) < 1.3e-4 and abs(lines3[1][0][1] - half) < 1.3e-4 and A.goal_points(cfg3).shape == (50, 2)
     # two walls close together leave a piece of 0.05 m between their buffers: dropped (area_clearing.py:246-250)
     cfg2 = default_cfg("area_clearing")
     cfg2.env = "walled_env"

@@ -89,12 +89,14 @@ def test_area_clearing_nonzero_damping_matches_oracle():
     env.close()
 
 
-def test_layout_whose_wall_cuts_the_clearance_boundary_matches_oracle():
-    """VERDICT r3 item 9 (area_clearing.py:225-262,1122-1140): walled_env plus a wall across the left boundary edge -- five boundary goal lines, 50 goal
-    points; maps, first observation and five steps (goal-distance rewards, channel 3) against the oracle."""
+@pytest.mark.parametrize("extra_wall", [[[-7.0, 0.0], [-3.0, 0.0]], [[-4.95, 0.0], [-3.0, 0.0]]], ids=["wall_across_the_edge", "wall_end_cap_reaches_the_edge"])
+def test_layout_whose_wall_cuts_the_clearance_boundary_matches_oracle(extra_wall):
+    """VERDICT r3 item 9 / r4 item 9 (area_clearing.py:225-262,1122-1140): walled_env plus a wall across the left boundary edge, or one whose rounded end (the
+    cap of its 0.1 m buffer) reaches it -- five boundary goal lines, 50 goal points; maps, first observation and five steps (goal-distance rewards, channel 3)
+    against the oracle."""
     from benchpush_amd.envs.area_clearing import BatchedAreaClearingEnv
     from oracle.oracle_bd import AC_INFO_KEYS, OracleAreaClearing
-    walls = [[[-6.0, -6.0], [-6.0, 6.0]], [[6.0, 6.0], [6.0, -6.0]], [[-7.0, 0.0], [-3.0, 0.0]]]
+    walls = [[[-6.0, -6.0], [-6.0, 6.0]], [[6.0, 6.0], [6.0, -6.0]], extra_wall]
     cfg = default_cfg("area_clearing")
     cfg.env = "walled_env"
     cfg.envs.walled_env.walls = walls
