@@ -383,7 +383,7 @@ def test_full_size_properties_4096_envs():
 
 def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     """4096 envs x 40 steps with auto-reset (deep enough for the cost-sorted dispatch order and for thousands of parked envs): the preemptive
-    scheduler (the default, and a ragged chunk size) leaves every env in exactly the state of the one-env-per-wavefront kernel (BP_SCHED=0) --
+    scheduler (the default on resident wavefronts, a ragged chunk size, and the dispatcher-driven kernel) leaves every env in exactly the state of the one-env-per-wavefront kernel (BP_SCHED=0) --
     body state, rewards, termination, observations, episode metrics."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
     trials = default_trials(0.3, 24, base_seed=3)
@@ -393,11 +393,14 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     acts = (torch.rand((steps, E), generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1).float().double()
 
     def run(env_vars):
-        for k in ("BP_SCHED",):
+        for k in ("BP_SCHED", "BP_SCHED_PERSIST", "BP_SCHED_DYNPRIO"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env_vars.items():
             monkeypatch.setenv(k, v)
         env = BatchedShipIceEnv(E, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+        # the default runs on resident wavefronts (one workgroup per wave slot), BP_SCHED_PERSIST=0 on one workgroup per task from the hardware dispatcher
+        if env_vars.get("BP_SCHED") != "0":
+            assert (int(env.L.bp_sched_resident(env.h)) > 0) == (env_vars.get("BP_SCHED_PERSIST") != "0")
         env.reset()
         rsum = torch.zeros(E, dtype=torch.float64, device="cuda:0")
         nterm = 0
@@ -414,7 +417,8 @@ def test_step_kernel_variants_agree_at_full_size(monkeypatch):
     ref = run({"BP_SCHED": "0"})                               # one env per wavefront for the whole step
     assert ref[5] > 1000                                       # episodes did end and restart inside the window
     # {} = the default: the preemptive scheduler (k_physics_step_sched), here with thousands of envs parked and resumed on other CUs / XCDs
-    for variant in ({}, {"BP_SCHED": "37"}):
+    # ... on resident wavefronts with pace-based issue priorities; the same without either (the dispatcher-driven kernel, static priority classes)
+    for variant in ({}, {"BP_SCHED": "37"}, {"BP_SCHED_PERSIST": "0", "BP_SCHED_DYNPRIO": "0"}):
         got = run(variant)
         for a, b in zip(ref[:5], got[:5]):
             assert torch.equal(a, b), variant
