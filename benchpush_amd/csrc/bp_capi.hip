@@ -347,12 +347,12 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         const bool can_pair = plain && nbcap <= PP_NBCAP &&
                               ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_MAXV * sizeof(d2) < (size_t)0xFFFFFFFF &&   // 32-bit byte offsets (gA)
                               ((size_t)h->num_envs + (size_t)T) * (size_t)nbcap * BP_KADJ * sizeof(unsigned long long) < (size_t)0xFFFFFFFF;
-        // Default: inside the scheduler (mode 2) from 6 144 envs per GPU up, where a launch is throughput (+8 % at 6 144, +34 % at 8 192, +30 % at 16 384
-        // env-steps/s, same box).  Below, the launch follows the chains of its heaviest envs and the scheduler's rotation, not the sum of the work: pairing
+        // Default: inside the scheduler (mode 2) from 5 120 envs per GPU up, where a launch is throughput (+3.7 % at 5 120, +12 % at 6 144, +19 % at 8 192 and
+        // +31 % at 16 384 env-steps/s over the resident solo scheduler, same box).  Below, the launch follows the chains of its heaviest envs and the scheduler's rotation, not the sum of the work: pairing
         // the light envs saves a tenth of the wave-instructions and moves the launch by 0 ... +2.5 % at 4 096 envs (profiles/r05_pair/), -2 % at 2 048 --
         // and the kernel that holds both step bodies runs the solo body 6 % slower -- so those handles keep the lean one-env-per-wavefront scheduler kernel.
         // BP_PAIR=0 / 1 / 2 overrides.
-        if (can_pair && h->num_envs >= 6144) h->pair_mode = 2;
+        if (can_pair && h->num_envs >= 5120) h->pair_mode = 2;
         if (const char *evp = getenv("BP_PAIR")) h->pair_mode = can_pair ? atoi(evp) : 0;
         if (h->pair_mode == 1) {
             h->P.pair_mode = 1;
@@ -360,7 +360,9 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * PL_HALF)));
         }
         // (with paired first tasks the scheduler is what lets an env leave its pair, so it stays on at every batch size: chunks of 100 sub-steps above 8192 envs)
-        int ch = (h->num_envs <= 8192) ? 40 : (h->pair_mode == 2 ? 100 : 0);
+        // (pairing launches are dispatcher-driven, where every task switch leaves the slot empty for a while: chunks of 60 from 6144 envs -- 8192 envs: 315.6 k /
+        // 320.6 k / 315.6 k / 312.9 k env-steps/s at 40 / 60 / 80 / 100 --, of 100 above 8192)
+        int ch = (h->num_envs <= 8192) ? ((h->pair_mode == 2 && h->num_envs >= 6144) ? 60 : 40) : (h->pair_mode == 2 ? 100 : 0);
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
@@ -409,15 +411,17 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 if (!getenv("BP_SCHED_DYNPRIO")) h->P.sq_dynprio = 0;   // a pairing launch is throughput, not a chain: the static classes stay
                 // Up to ~6 000 envs per GPU the launch is within a few per cent of the chain of its heaviest env: only envs that are light right now run
                 // paired (a medium env beside a mate would become the longest chain), and the eighth of the dispatch order that was heaviest in the previous
-                // step starts alone.  Above, the launch is throughput: everything that fits a half-wave runs paired (same-box sweeps in profiles/r05_pair/).
+                // step starts alone.  Above, the launch is throughput: every env starts in a pair and leaves it at 20 active arbiters or 40 work units per sub-step
+                // (same-box sweeps in profiles/r05_pair/, profiles/r05_sched/pairing_limits_by_batch.txt: at 6144 envs 295 k / 284 k steady state against 274 k / 255 k
+                // with the looser 30 / 100 of the first version, at 7168 313 k / 314 k against 301 k / 291 k, the same from 12 288 envs up).
                 const bool tight = h->num_envs < 6144;
                 h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", tight ? h->num_envs / 8 : 0)));
                 h->P.pp_max_keys = std::min(30, envint("BP_PP_KEYS", 26));
                 h->P.pp_max_slots = std::min(PP_NSLOT - 4, envint("BP_PP_SLOTS", 34));
                 h->P.pp_max_mv = std::min(PP_MVCAP - 4, envint("BP_PP_MV", 40));
-                h->P.pp_max_act = envint("BP_PP_ACT", tight ? 16 : 30);
-                h->P.pp_max_work = envint("BP_PP_WORK", tight ? 9 : 100);
-                h->P.pp_rate = envint("BP_PP_RATE", tight ? 70 : 1000);
+                h->P.pp_max_act = envint("BP_PP_ACT", tight ? 16 : 20);
+                h->P.pp_max_work = envint("BP_PP_WORK", tight ? 9 : 40);
+                h->P.pp_rate = envint("BP_PP_RATE", tight ? 70 : 200);
                 h->P.pp_snake = envint("BP_PP_SNAKE", 0);
                 h->P.pp_heavy_only = envint("BP_PP_HEAVY_ONLY", 0);
                 h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));

@@ -103,9 +103,10 @@ def test_pairs_inside_the_scheduler_equal_the_solo_kernel_at_full_size(monkeypat
             assert torch.equal(a, b), variant
 
 
-def test_default_from_6144_envs_is_paired_and_equals_the_solo_kernel(monkeypatch):
-    """Handles of 6144 envs and more pair by default (loose limits: everything that fits a half-wave; the launch is one kernel, every first task a pair);
-    below, the lean one-env-per-wavefront scheduler kernel stays.  6144 envs x 14 steps with auto-reset against BP_PAIR=0: torch.equal."""
+def test_default_from_5120_envs_is_paired_and_equals_the_solo_kernel(monkeypatch):
+    """Handles of 5120 envs and more pair by default (from 6144 up every first task is a pair and an env leaves at 20 active arbiters / 40 work units per sub-step; 5120 ... 6143:
+    the tight limits, the heaviest eighth starts alone); below, the lean one-env-per-wavefront scheduler kernel stays, on resident wavefronts.  6144 envs x 14 steps with auto-reset
+    against BP_PAIR=0: torch.equal."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
     trials = default_trials(0.3, 32, base_seed=9)
     for k in ("BP_PAIR", "BP_SCHED"):
@@ -123,5 +124,13 @@ def test_default_from_6144_envs_is_paired_and_equals_the_solo_kernel(monkeypatch
         monkeypatch.delenv(k, raising=False)
     big = BatchedShipIceEnv(6144, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
     ps = big.pair_stats()
-    assert ps["mode"] == 2 and ps["solo_first"] == 0 and ps["max_warm_x_colours"] == 100
+    assert ps["mode"] == 2 and ps["solo_first"] == 0 and ps["max_warm_x_colours"] == 40
+    assert int(big.L.bp_sched_resident(big.h)) == 0          # pairing launches are dispatcher-driven
     big.close()
+    mid = BatchedShipIceEnv(5120, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+    ps = mid.pair_stats()
+    assert ps["mode"] == 2 and ps["solo_first"] == 640 and ps["max_warm_x_colours"] == 9
+    mid.close()
+    below = BatchedShipIceEnv(4096, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+    assert int(below.L.bp_pair_mode(below.h)) == 0 and int(below.L.bp_sched_resident(below.h)) > 0
+    below.close()
