@@ -524,13 +524,13 @@ def main():
             "clock_mhz": (clock_hz / 1e6) if clock_hz else None,
             "clock_source": ("s_memtime / s_memrealtime stamps of XCD %d around the timed launches" % clock_xcd) if clock_hz else
                             "no stamp pair from one XCD: issue.frac uses the nominal 2.1 GHz",
-            "kernel": (("k_physics_step_sched" + ("l" if resident > 0 else "p" if pairing and pairing.get("mode") == 2 else "") + ("_maze" if args.env == "maze" else ""))
+            "kernel": (("k_physics_step_sched" + (("r" if resident > 0 else "p") if pairing and pairing.get("mode") == 2 else "l" if resident > 0 else "") + ("_maze" if args.env == "maze" else ""))
                        if sched_chunk > 0 else ("k_physics_step_maze" if args.env == "maze" else "k_physics_step")),
             "pairing": pairing,
             "scheduler": ({"chunk_substeps": sched_chunk, "resident_workgroups": resident,
                            "what": "preemptive: envs parked at chunk boundaries while another is further behind, "
                            "least-advanced waiting env first (DESIGN.md 4a); resident_workgroups > 0: one workgroup per wave slot takes task after task itself "
-                           "(k_physics_step_schedl) instead of one workgroup per task from the hardware dispatcher, BP_SCHED_PERSIST=0 turns that off; "
+                           "(k_physics_step_schedl; k_physics_step_schedr in pairing launches) instead of one workgroup per task from the hardware dispatcher, BP_SCHED_PERSIST=0 / BP_PAIR_RESIDENT=0 turn that off; "
                            "BP_SCHED=0 selects one wavefront per env for the whole step"}
                           if sched_chunk > 0 else None),
             "achieved": a_phys * E / (phys_ms * 1e-3) / 1e9 if phys_ms > 0 else None,

@@ -26,6 +26,7 @@ struct bp_handle {
     bool maze8 = false;    // maze whose hulls all have <= 8 vertices: kernels instantiated with 8-vertex loops
     bool damp = false;     // bp_config.damping_pow != 0: k_physics_step_damp / k_physics_reset_damp (generic vertex loops, no scheduler)
     int pair_mode = 0;              // two envs per wavefront (bp_physics_pair.hpp): 1 = fixed pairs for the whole step (k_physics_step_pair), 2 = inside the scheduler
+    int pair_resident = 0;          // > 0: pairing launches run k_physics_step_schedr with this many resident workgroups (BP_PAIR_RESIDENT)
     int sched_persist = 0;          // > 0: the scheduled launch is k_physics_step_schedl with this many resident workgroups (BP_SCHED_PERSIST)
     void *pd_buf = nullptr;         // its launch constants in device memory (DevParams, DevPtrs)
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
@@ -360,9 +361,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * PL_HALF)));
         }
         // (with paired first tasks the scheduler is what lets an env leave its pair, so it stays on at every batch size: chunks of 100 sub-steps above 8192 envs)
-        // (pairing launches are dispatcher-driven, where every task switch leaves the slot empty for a while: chunks of 60 from 6144 envs -- 8192 envs: 315.6 k /
-        // 320.6 k / 315.6 k / 312.9 k env-steps/s at 40 / 60 / 80 / 100 --, of 100 above 8192)
-        int ch = (h->num_envs <= 8192) ? ((h->pair_mode == 2 && h->num_envs >= 6144) ? 60 : 40) : (h->pair_mode == 2 ? 100 : 0);
+        int ch = (h->num_envs <= 8192) ? 40 : (h->pair_mode == 2 ? 100 : 0);
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
@@ -408,13 +407,13 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 // two environments per wavefront inside the scheduler: who starts alone, and when a half leaves its pair (pair_should_leave)
                 auto envint = [](const char *name, int dflt) { const char *v = getenv(name); return v ? atoi(v) : dflt; };
                 h->P.pair_mode = 2;
-                if (!getenv("BP_SCHED_DYNPRIO")) h->P.sq_dynprio = 0;   // a pairing launch is throughput, not a chain: the static classes stay
+                // (pace priorities stay on: +0.4 ... +0.9 % in pairing launches)
                 // Up to ~6 000 envs per GPU the launch is within a few per cent of the chain of its heaviest env: only envs that are light right now run
                 // paired (a medium env beside a mate would become the longest chain), and the eighth of the dispatch order that was heaviest in the previous
-                // step starts alone.  Above, the launch is throughput: every env starts in a pair and leaves it at 20 active arbiters or 40 work units per sub-step
-                // (same-box sweeps in profiles/r05_pair/, profiles/r05_sched/pairing_limits_by_batch.txt: at 6144 envs 295 k / 284 k steady state against 274 k / 255 k
-                // with the looser 30 / 100 of the first version, at 7168 313 k / 314 k against 301 k / 291 k, the same from 12 288 envs up).
-                const bool tight = h->num_envs < 6144;
+                // step starts alone.  From ~7 000 envs the launch is throughput: every env starts in a pair and leaves it at 20 active arbiters or 40 work units per
+                // sub-step (same-box sweeps in profiles/r05_pair/ and profiles/r05_sched/pairing_limits_by_batch.txt; on the resident kernel, fresh / steady state:
+                // 6144 envs tight 294 k / 306 k against 294 k / 285 k, 7168 envs 300 k / 308 k against 314 k / 310 k, 8192 envs 303 k / 313 k against 323 k / 324 k).
+                const bool tight = h->num_envs < 7168;
                 h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", tight ? h->num_envs / 8 : 0)));
                 h->P.pp_max_keys = std::min(30, envint("BP_PP_KEYS", 26));
                 h->P.pp_max_slots = std::min(PP_NSLOT - 4, envint("BP_PP_SLOTS", 34));
@@ -429,9 +428,19 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-            // (resident wavefronts for the kernel that holds both step bodies lost 4 % at 8192 envs to its register allocation -- 266 spilled VGPRs in the loop
-            // against 203: pairing launches keep one workgroup per task from the hardware dispatcher)
+            // (pairing launches have a resident kernel of their own, k_physics_step_schedr: the kernel that holds both step bodies INLINE lost 4 % at 8192 envs as a
+            // resident loop -- 266 spilled VGPRs against 203)
             if (h->P.pair_mode != 2 && h->P.sq_parts == 1) { int rc2 = sched_persist_setup(h); if (rc2) return rc2; }
+            if (h->P.pair_mode == 2) {
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+                const int pr = getenv("BP_PAIR_RESIDENT") ? atoi(getenv("BP_PAIR_RESIDENT")) : 1;   // 0: the dispatcher-driven pair of kernels
+                if (pr > 0) {
+                    hipDeviceProp_t prop;
+                    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+                    h->pair_resident = std::min(h->num_envs, prop.multiProcessorCount * 8 * pr);
+                    if (!h->pd_buf) HIPCHK(h, hipMalloc(&h->pd_buf, sizeof(DevParams) + sizeof(DevPtrs)));
+                }
+            }
         }
     }
     if (h->pair_mode == 2 && h->P.pair_mode != 2) h->pair_mode = 0;   // pairing inside the scheduler needs the scheduler
@@ -788,6 +797,13 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                     hipLaunchKernelGGL(k_physics_step_schedl_maze, dim3(h->sched_persist), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
                 else
                     hipLaunchKernelGGL(k_physics_step_schedl, dim3(h->sched_persist), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
+            } else if (h->pair_resident > 0 && h->P.pair_mode == 2) {
+                // a pairing launch on resident wavefronts: one kernel, the two step bodies as functions of their own (k_physics_step_schedr)
+                DevParams *Pg = (DevParams *)h->pd_buf;
+                DevPtrs *Dg = (DevPtrs *)((char *)h->pd_buf + sizeof(DevParams));
+                hipLaunchKernelGGL(k_store_params, dim3(1), dim3(64), 0, st, h->P, h->D, Pg, Dg);
+                HIPCHK(h, hipGetLastError());
+                hipLaunchKernelGGL(k_physics_step_schedr, dim3(h->pair_resident), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
             } else if (h->maze8)
                 hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             else if (h->P.pair_mode == 2) {
@@ -1462,7 +1478,7 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 }
 
 int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
-int32_t bp_sched_resident(bp_handle *h) { return (h && h->sched_chunk > 0) ? h->sched_persist : 0; }
+int32_t bp_sched_resident(bp_handle *h) { return (h && h->sched_chunk > 0) ? (h->P.pair_mode == 2 ? h->pair_resident : h->sched_persist) : 0; }
 
 int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
 {

@@ -990,6 +990,170 @@ __global__ __launch_bounds__(64, 2) void k_physics_step_schedl_maze(const DevPar
 {
     sched_resident<BP_ENV_MAZE, 0>(Pg, Dg, actions, reward, terminated, truncated, info);
 }
+// ---- a pairing launch on resident wavefronts (k_physics_step_schedr): the two step bodies as separate FUNCTIONS ---------------------------------------------------
+// One kernel that holds both bodies inline pays for it in its register allocation (the solo body 6 % slower, 203 spilled VGPRs in the paired one, 266 with the
+// resident loop around them).  Here each body is a function of its own -- its own allocation -- called from a small resident loop that picks the tasks; the launch
+// constants reach them as two pointers (a by-value DevParams / DevPtrs argument of a non-inlined function is a 1.7 KB copy on the stack of every lane).  Arguments
+// of a device function arrive in VGPRs: the functions make them wave-uniform again first.
+#define BP_UNIFORM_PTR(T, p) ((T)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned long long)(p) >> 32)) << 32) | \
+                                  (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long long)(p))))
+template <int KIND>
+__device__ __attribute__((noinline)) int sched_fn_pair(const DevParams *Pg_, const DevPtrs *Dg_, const double *actions_, double *reward_, unsigned char *terminated_,
+                                                       unsigned char *truncated_, double *info_, int pe0, int pe1, int x, int first)
+{
+    const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)BP_UNIFORM_PTR(unsigned long long, Pg_);
+    const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)BP_UNIFORM_PTR(unsigned long long, Dg_);
+    const double *__restrict__ actions = BP_UNIFORM_PTR(const double *, actions_);
+    double *__restrict__ reward = BP_UNIFORM_PTR(double *, reward_);
+    unsigned char *__restrict__ terminated = BP_UNIFORM_PTR(unsigned char *, terminated_);
+    unsigned char *__restrict__ truncated = BP_UNIFORM_PTR(unsigned char *, truncated_);
+    double *__restrict__ info = BP_UNIFORM_PTR(double *, info_);
+    pe0 = __builtin_amdgcn_readfirstlane(pe0); pe1 = __builtin_amdgcn_readfirstlane(pe1); x = __builtin_amdgcn_readfirstlane(x); first = __builtin_amdgcn_readfirstlane(first);
+    const int lane = lane_id();
+    {
+        // ---- a paired task (sched_body, ROLE 1) ----
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the envs' arrays as the waves that parked them left them
+        PairLimits Q;
+        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work;
+        Q.gc_slots = P.pp_max_slots - 6; Q.max_rate = P.pp_rate;
+        int it_half = 0, score_half = 0, heavy_half = 0;
+        auto behind = [&](const int level) -> bool {
+            int y = 0;
+            if (lane == 0) y = sq_someone_behind(P, D, x, level) ? 1 : 0;
+            return __builtin_amdgcn_readfirstlane(y) != 0;
+        };
+        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, Q, it_half, score_half, heavy_half, behind);
+        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
+        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
+        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
+        const int hv0 = __builtin_amdgcn_readlane(heavy_half, 0), hv1 = __builtin_amdgcn_readlane(heavy_half, 32);
+        pair_gsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
+        if (lane == 0) {
+            if (st0 == 1) D.sq_done[pe0] = 1;
+            if (st1 == 1) D.sq_done[pe1] = 1;
+            if (nfin) atomicAdd(sq_finished(D), nfin);
+        }
+        const bool pk0 = st0 == 2, pk1 = st1 == 2;
+        if (lane == 0 && D.sq_pairstat != nullptr) {
+            atomicAdd(&D.sq_pairstat[first ? 0 : 1], 1);
+            if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
+        }
+        if (!pk0 && !pk1) return -1;
+        // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
+        const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
+        if (lane == 0) {
+            if (pk0 && !c0) { D.sq_lev[pe0] = it0 / P.sq_chunk; sq_push(P, D, x + (hv0 ? 0 : 8), it0 / P.sq_chunk, pe0); }
+            if (pk1 && !c1) { D.sq_lev[pe1] = it1 / P.sq_chunk; sq_push(P, D, x + (hv1 ? 0 : 8), it1 / P.sq_chunk, pe1); }
+            if (D.sq_pairstat != nullptr) {
+                if (c0 || c1) atomicAdd(&D.sq_pairstat[3], 1);
+                const int qh = ((pk0 && !c0 && hv0) ? 1 : 0) + ((pk1 && !c1 && hv1) ? 1 : 0), ql = ((pk0 && !c0 && !hv0) ? 1 : 0) + ((pk1 && !c1 && !hv1) ? 1 : 0);
+                if (qh) atomicAdd(&D.sq_pairstat[4], qh);
+                if (ql) atomicAdd(&D.sq_pairstat[5], ql);
+            }
+        }
+        if (!c0 && !c1) return -1;
+        __syncthreads();
+        return ((c0 ? pe0 : pe1) | (3 << 24)) | (((c0 ? it0 : it1) / P.sq_chunk) << 26);   // top issue priority: it left its pair because it is heavy
+    }
+}
+template <int KIND>
+__device__ __attribute__((noinline)) void sched_fn_solo(const DevParams *Pg_, const DevPtrs *Dg_, const double *actions_, double *reward_, unsigned char *terminated_,
+                                                        unsigned char *truncated_, double *info_, int item, int lev, int x)
+{
+    const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)BP_UNIFORM_PTR(unsigned long long, Pg_);
+    const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)BP_UNIFORM_PTR(unsigned long long, Dg_);
+    const double *__restrict__ actions = BP_UNIFORM_PTR(const double *, actions_);
+    double *__restrict__ reward = BP_UNIFORM_PTR(double *, reward_);
+    unsigned char *__restrict__ terminated = BP_UNIFORM_PTR(unsigned char *, terminated_);
+    unsigned char *__restrict__ truncated = BP_UNIFORM_PTR(unsigned char *, truncated_);
+    double *__restrict__ info = BP_UNIFORM_PTR(double *, info_);
+    item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
+    const int lane = lane_id();
+    const int env = item & 0xFFFFFF;
+    if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
+    else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
+    int lev_out = lev + 1, light_out = 0;
+    // P.sq_hold: the envs of the top issue-priority class -- the heaviest quarter of the dispatch order, and envs that left a pair as heavy -- keep their slot
+    // while other envs merely have not started yet: their chain is what the launch waits for at the end, and a first chunk that waits costs it a round
+    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, false,
+                                                          &light_out, P.sq_hold != 0 && (item >> 24) == 3);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (lane == 0) {
+        if (done) { D.sq_done[env] = 1; atomicAdd(sq_finished(D), 1); }
+        else {
+            D.sq_lev[env] = lev_out;
+            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((P.pair_mode == 2 && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
+        }
+    }
+}
+
+// the resident loop of a pairing launch: what sched_body<KIND, 1> does before its task (first tasks by position, then the queues of either kind), then the functions
+template <int KIND>
+__device__ __forceinline__ void sched_resident_pairing(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                       double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                       unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    const int lane = lane_id();
+    const int home = sq_xcc_id();
+    for (;;) {
+        unsigned long long pa = (unsigned long long)Pg, da = (unsigned long long)Dg;
+        asm volatile("" : "+s"(pa), "+s"(da));
+        const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)pa;
+        const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)da;
+        __builtin_amdgcn_s_setprio(0);
+        const int npairs = (P.num_envs - P.pair_solo + 1) / 2, nfirst = P.pair_solo + npairs;
+        int bid = nfirst;
+        if (lane == 0 && sq_ld(sq_nextpos(D)) < nfirst) bid = min(atomicAdd(sq_nextpos(D), 1), nfirst);
+        bid = __builtin_amdgcn_readfirstlane(bid);
+        int item = -1, lev = 0, x = home, pe0 = -1, pe1 = -1;
+        if (bid >= P.pair_solo && bid < nfirst) {
+            const int p0 = P.pp_snake ? bid : P.pair_solo + 2 * (bid - P.pair_solo), p1 = P.pp_snake ? P.num_envs - 1 - (bid - P.pair_solo) : p0 + 1;
+            pe0 = D.order != nullptr ? D.order[p0] : p0;
+            pe1 = (p1 < P.num_envs && p1 != p0) ? (D.order != nullptr ? D.order[p1] : p1) : -1;
+            if (lane == 0) atomicAdd(sq_started(D), pe1 >= 0 ? 2 : 1);
+        } else if (bid < nfirst) {
+            const int cls = (bid < P.num_envs / 4) ? 3 : (bid < P.num_envs / 2) ? 1 : 0;
+            item = (D.order != nullptr ? D.order[bid] : bid) | (cls << 24);
+            if (lane == 0) atomicAdd(sq_started(D), 1);
+        } else {
+            int kind = 0, mate = -1;
+            if (lane == 0) {
+                const int limit = P.sq_debug ? 64 : (1 << 20);
+                for (int idle = 0;; idle++) {
+                    item = sq_pop(P, D, home, lev, kind);
+                    if (item < 0 && (idle & 3) == 3)
+                        for (int o = 1; o < 8 && item < 0; o++) { const int y = (home + o) & 7; item = sq_pop(P, D, y, lev, kind); if (item >= 0) x = y; }
+                    if (item >= 0 || sq_ld(sq_finished(D)) >= P.num_envs || sq_ld(sq_abort(D)) != 0) break;
+                    if (idle > limit) { if (atomicExch(sq_abort(D), 1) == 0) atomicAdd(&D.sq_warn[0], 1); break; }
+                    for (int q = 0; q < 4; q++) __builtin_amdgcn_s_sleep(127);
+                }
+                if (item >= 0 && kind == 1 && sq_ld(sq_waiting(D, x + 8)) > 0)
+                    for (int l = lev; l < P.sq_levels && mate < 0; l++) mate = sq_pop_level(P, D, x + 8, l);
+            }
+            item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
+            mate = __builtin_amdgcn_readfirstlane(mate);
+            if (item < 0) return;
+            if (mate >= 0) { pe0 = item & 0xFFFFFF; pe1 = mate & 0xFFFFFF; item = -1; }
+        }
+        if (pe0 >= 0) {
+            const int r = sched_fn_pair<KIND>(Pg, Dg, actions, reward, terminated, truncated, info, pe0, pe1, x, bid < nfirst ? 1 : 0);
+            if (r < 0) { __syncthreads(); continue; }
+            item = r & 0x3FFFFFF; lev = (int)((unsigned)r >> 26);
+        }
+        sched_fn_solo<KIND>(Pg, Dg, actions, reward, terminated, truncated, info, item, lev, x);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64, 2) void k_physics_step_schedr(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
+                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
+{
+    sched_resident_pairing<0>(Pg, Dg, actions, reward, terminated, truncated, info);
+}
 __global__ void k_store_params(const DevParams P, const DevPtrs D, DevParams *Pg, DevPtrs *Dg)
 {
     static_assert(sizeof(DevParams) % 4 == 0 && sizeof(DevPtrs) % 4 == 0, "copied as 32-bit words");

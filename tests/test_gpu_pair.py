@@ -33,7 +33,7 @@ def test_fixed_pairs_boundary_and_yaw_edges(monkeypatch):
 
 def _run_batch(E, steps, conc, env_vars, monkeypatch, trials):
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv
-    for k in ("BP_PAIR", "BP_SCHED", "BP_PP_ACT", "BP_PP_WORK", "BP_PAIR_SOLO", "BP_PP_KEYS", "BP_PP_SLOTS", "BP_PP_MV"):
+    for k in ("BP_PAIR", "BP_SCHED", "BP_PP_ACT", "BP_PP_WORK", "BP_PAIR_SOLO", "BP_PP_KEYS", "BP_PP_SLOTS", "BP_PP_MV", "BP_PAIR_RESIDENT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in env_vars.items():
         monkeypatch.setenv(k, v)
@@ -73,9 +73,12 @@ def test_fixed_pairs_equal_the_solo_kernel_on_512_envs(monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_pairs_inside_the_scheduler_match_the_oracle(monkeypatch):
+@pytest.mark.parametrize("resident", ["1", "0"], ids=["resident_kernel_with_function_bodies", "dispatcher_driven_pair_of_kernels"])
+def test_pairs_inside_the_scheduler_match_the_oracle(monkeypatch, resident):
     """BP_PAIR=2, the product path: paired first tasks, envs leaving their pair at a sub-step boundary (tight limits force it within every step), the
-    heavier one carrying on alone in the same wavefront, the other resumed from the queues by another workgroup -- bit-identical to the oracle."""
+    heavier one carrying on alone in the same wavefront, the other resumed from the queues by another workgroup -- bit-identical to the oracle.  Both launch
+    forms: k_physics_step_schedr (default: resident workgroups, the two step bodies as functions) and k_physics_step_sched + k_physics_step_schedp (BP_PAIR_RESIDENT=0)."""
+    monkeypatch.setenv("BP_PAIR_RESIDENT", resident)
     monkeypatch.setenv("BP_PAIR", "2")
     monkeypatch.setenv("BP_PAIR_SOLO", "2")
     assert _run_parity(E=9, conc=0.3, T=3, steps=30, seed=5) > 500
@@ -95,7 +98,7 @@ def test_pairs_inside_the_scheduler_equal_the_solo_kernel_at_full_size(monkeypat
     trials = default_trials(0.3, 48, base_seed=1)
     ref = _run_batch(4096, 40, 0.3, {"BP_SCHED": "0"}, monkeypatch, trials)
     assert ref[6] is None and ref[5] > 500
-    for variant in ({"BP_PAIR": "2"}, {"BP_PAIR": "2", "BP_PP_ACT": "6", "BP_PP_WORK": "6", "BP_PAIR_SOLO": "1000"}):
+    for variant in ({"BP_PAIR": "2"}, {"BP_PAIR": "2", "BP_PP_ACT": "6", "BP_PP_WORK": "6", "BP_PAIR_SOLO": "1000"}, {"BP_PAIR": "2", "BP_PAIR_RESIDENT": "0"}):
         got = _run_batch(4096, 40, 0.3, variant, monkeypatch, trials)
         assert got[6] is None, got[6]
         assert got[5] == ref[5]
@@ -104,8 +107,8 @@ def test_pairs_inside_the_scheduler_equal_the_solo_kernel_at_full_size(monkeypat
 
 
 def test_default_from_5120_envs_is_paired_and_equals_the_solo_kernel(monkeypatch):
-    """Handles of 5120 envs and more pair by default (from 6144 up every first task is a pair and an env leaves at 20 active arbiters / 40 work units per sub-step; 5120 ... 6143:
-    the tight limits, the heaviest eighth starts alone); below, the lean one-env-per-wavefront scheduler kernel stays, on resident wavefronts.  6144 envs x 14 steps with auto-reset
+    """Handles of 5120 envs and more pair by default (from 7168 up every first task is a pair and an env leaves at 20 active arbiters / 40 work units per sub-step; 5120 ... 7167:
+    the tight limits, the heaviest eighth starts alone; on resident wavefronts, the two step bodies as functions of one kernel); below, the lean one-env-per-wavefront scheduler kernel stays, on resident wavefronts.  6144 envs x 14 steps with auto-reset
     against BP_PAIR=0: torch.equal."""
     from benchpush_amd.envs.ship_ice import BatchedShipIceEnv, default_trials
     trials = default_trials(0.3, 32, base_seed=9)
@@ -124,9 +127,13 @@ def test_default_from_5120_envs_is_paired_and_equals_the_solo_kernel(monkeypatch
         monkeypatch.delenv(k, raising=False)
     big = BatchedShipIceEnv(6144, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
     ps = big.pair_stats()
-    assert ps["mode"] == 2 and ps["solo_first"] == 0 and ps["max_warm_x_colours"] == 40
-    assert int(big.L.bp_sched_resident(big.h)) == 0          # pairing launches are dispatcher-driven
+    assert ps["mode"] == 2 and ps["solo_first"] == 768 and ps["max_warm_x_colours"] == 9
+    assert int(big.L.bp_sched_resident(big.h)) > 0           # pairing launches run on resident wavefronts too (k_physics_step_schedr)
     big.close()
+    bigger = BatchedShipIceEnv(7168, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
+    ps = bigger.pair_stats()
+    assert ps["mode"] == 2 and ps["solo_first"] == 0 and ps["max_warm_x_colours"] == 40
+    bigger.close()
     mid = BatchedShipIceEnv(5120, cfg={"concentration": 0.3}, trials=trials, device="cuda:0")
     ps = mid.pair_stats()
     assert ps["mode"] == 2 and ps["solo_first"] == 640 and ps["max_warm_x_colours"] == 9
