@@ -239,7 +239,8 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
 int32_t bp_sched_chunk(bp_handle *h);
 /* Resident wavefronts of the step scheduler (k_physics_step_schedl: one workgroup per wave slot of the device takes task after task itself instead of one
  * workgroup per task from the hardware dispatcher; results are identical): the number of resident workgroups of a scheduled launch, 0 = one workgroup per
- * task.  Default: 8 x the device's compute units for scheduled launches without pairing; environment variable BP_SCHED_PERSIST=0 turns it off.  (ABI 10) */
+ * task.  Default: 8 x the device's compute units for scheduled launches (k_physics_step_schedr in pairing launches); environment variables BP_SCHED_PERSIST=0 /
+ * BP_PAIR_RESIDENT=0 turn it off.  (ABI 10) */
 int32_t bp_sched_resident(bp_handle *h);
 /* Two environments per wavefront (ship-ice handles with space.damping == 0 and at most 272 body slots; lanes 0..31 one env, lanes 32..63 another, results
  * identical): 0 = off, 1 = fixed pairs of the dispatch order for the whole step (test kernel), 2 = inside the step scheduler: the heaviest envs of the
