@@ -453,6 +453,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         if (ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) { // preemptive scheduler, as for ship-ice
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch; h->P.sq_cap = h->num_envs;
+            h->P.sq_dynprio = getenv("BP_SCHED_DYNPRIO") ? atoi(getenv("BP_SCHED_DYNPRIO")) : 115;   // pace priorities as for ship-ice: +1.6 % at 4096 envs
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
             if ((rc = dalloc(h, &d_items, (size_t)SQ_NX * SQ_MAXLEV * h->P.sq_cap))) return rc;
             if ((rc = dalloc(h, &d_ctr, (size_t)SQ_NX * (SQ_MAXLEV + 2) * 2))) return rc;
