@@ -808,7 +808,7 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             } else if (h->maze8)
                 hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
             else if (h->P.pair_mode == 2) {
-                // a pairing launch is two kernels side by side: the envs that start alone on the lean solo code (second stream), everything else -- paired
+                // (BP_PAIR_RESIDENT=0) a pairing launch as two kernels side by side: the envs that start alone on the lean solo code (second stream), everything else -- paired
                 // first tasks, the workgroups that serve the queues -- in the kernel that holds both step bodies
                 if (!h->st_aux) {
                     HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux, hipStreamNonBlocking));
