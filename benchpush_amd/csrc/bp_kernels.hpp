@@ -772,6 +772,105 @@ __global__ __launch_bounds__(256) void k_sched_scan(const DevParams P, const Dev
         if (cnt > SQ_RESCUE) atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT);
     }
 }
+// what a scheduler workgroup knows about itself for the -DBP_SCHED_TRACE record of its task
+struct SchedTraceCtx { unsigned long long trw; int idle, first, home; };
+// A paired task of the scheduler: envs pe0 / pe1 (pe1 = -1: an idle half) resumed in one wavefront until they finish, yield or split.  Returns -1, or -- a heavy env
+// that left its pair carries on alone in this wave slot -- its queue item (env | priority class << 24) | chunks completed << 26.
+template <int KIND>
+__device__ __forceinline__ int sched_paired_block(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions, double *__restrict__ reward,
+                                                  unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated, double *__restrict__ info,
+                                                  const int pe0, const int pe1, const int x, const bool first)
+{
+    const int lane = lane_id();
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the envs' arrays as the waves that parked them left them
+        PairLimits Q;
+        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work;
+        Q.gc_slots = P.pp_max_slots - 6; Q.max_rate = P.pp_rate;
+        int it_half = 0, score_half = 0, heavy_half = 0;
+        auto behind = [&](const int level) -> bool {
+            int y = 0;
+            if (lane == 0) y = sq_someone_behind(P, D, x, level) ? 1 : 0;
+            return __builtin_amdgcn_readfirstlane(y) != 0;
+        };
+        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, Q, it_half, score_half, heavy_half, behind);
+        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
+        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
+        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
+        const int hv0 = __builtin_amdgcn_readlane(heavy_half, 0), hv1 = __builtin_amdgcn_readlane(heavy_half, 32);
+        pair_gsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
+        if (lane == 0) {
+            if (st0 == 1) D.sq_done[pe0] = 1;
+            if (st1 == 1) D.sq_done[pe1] = 1;
+            if (nfin) atomicAdd(sq_finished(D), nfin);
+        }
+        const bool pk0 = st0 == 2, pk1 = st1 == 2;
+        if (lane == 0 && D.sq_pairstat != nullptr) {
+            atomicAdd(&D.sq_pairstat[first ? 0 : 1], 1);
+            if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
+        }
+        if (!pk0 && !pk1) return -1;
+        // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
+        const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
+        if (lane == 0) {
+            if (pk0 && !c0) { D.sq_lev[pe0] = it0 / P.sq_chunk; sq_push(P, D, x + (hv0 ? 0 : 8), it0 / P.sq_chunk, pe0); }
+            if (pk1 && !c1) { D.sq_lev[pe1] = it1 / P.sq_chunk; sq_push(P, D, x + (hv1 ? 0 : 8), it1 / P.sq_chunk, pe1); }
+            if (D.sq_pairstat != nullptr) {
+                if (c0 || c1) atomicAdd(&D.sq_pairstat[3], 1);
+                const int qh = ((pk0 && !c0 && hv0) ? 1 : 0) + ((pk1 && !c1 && hv1) ? 1 : 0), ql = ((pk0 && !c0 && !hv0) ? 1 : 0) + ((pk1 && !c1 && !hv1) ? 1 : 0);
+                if (qh) atomicAdd(&D.sq_pairstat[4], qh);
+                if (ql) atomicAdd(&D.sq_pairstat[5], ql);
+            }
+        }
+        if (!c0 && !c1) return -1;
+        __syncthreads();
+        return ((c0 ? pe0 : pe1) | (3 << 24)) | (((c0 ? it0 : it1) / P.sq_chunk) << 26);   // top issue priority: it left its pair because it is heavy
+    }
+}
+// A solo task of the scheduler: env `item` resumed after `lev` chunks until it finishes or yields at a chunk boundary (then it goes back to the queue of its kind).
+template <int KIND>
+__device__ __forceinline__ void sched_solo_block(const DevParams &P, const DevPtrs &D, const double *__restrict__ actions, double *__restrict__ reward,
+                                                 unsigned char *__restrict__ terminated, unsigned char *__restrict__ truncated, double *__restrict__ info,
+                                                 const int item, const int lev, const int x, const bool completion, const SchedTraceCtx &T)
+{
+    const int lane = lane_id();
+    const int env = item & 0xFFFFFF;
+    if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
+    else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
+#ifdef BP_SCHED_TRACE   // diagnostic build (tools/sched_trace.py): every task's (env, levels, XCD, start, end) in the 100 MHz reference clock, into D.prof
+    const unsigned long long _tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    int lev_out = lev + 1, light_out = 0;
+    // P.sq_hold: the envs of the top issue-priority class -- the heaviest quarter of the dispatch order, and envs that left a pair as heavy -- keep their slot
+    // while other envs merely have not started yet: their chain is what the launch waits for at the end, and a first chunk that waits costs it a round
+    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, completion,
+                                                          &light_out, P.sq_hold != 0 && (item >> 24) == 3);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#ifdef BP_SCHED_TRACE
+    if (lane == 0 && D.prof != nullptr) {
+        const unsigned long long _tr1 = __builtin_amdgcn_s_memrealtime();
+        const unsigned long long idx = atomicAdd(&D.prof[0], 1ull);
+        unsigned long long *o = D.prof + 8 + 4 * idx;
+        o[0] = (unsigned long long)(unsigned)env | ((unsigned long long)(unsigned)lev << 32) | ((unsigned long long)(unsigned)(done ? 255 : lev_out) << 40) | ((unsigned long long)(unsigned)T.home << 48) |
+               ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)(T.first ? 1u : 0u) << 56);
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));   // wave slot, SIMD, CU, SE of this wave: which slot the task ran in
+        o[1] = _tr0; o[2] = _tr1;
+        o[3] = ((_tr0 - T.trw) << 32) | ((unsigned long long)(hwid & 0xFFFFu) << 16) | (unsigned long long)(unsigned)min(T.idle, 65535);   // workgroup start -> task start, slot id, empty polls
+    }
+#endif
+    if (lane == 0) {
+        if (done) { D.sq_done[env] = 1; if (!completion) atomicAdd(sq_finished(D), 1); }
+        else {
+            D.sq_lev[env] = lev_out;
+            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((P.pair_mode == 2 && !completion && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
+        }
+    }
+}
 // One workgroup per (env, chunk) task: the hardware dispatcher is the persistent loop, and the step code is compiled as in k_physics_step.
 // The first num_envs workgroups start the envs in the heaviest-first order without touching a queue (first chunks come before everything else under
 // the least-advanced-first rule anyway, and workgroups are dispatched in index order); every later workgroup takes the least-advanced waiting env of
@@ -862,88 +961,17 @@ __device__ __forceinline__ bool sched_body(const DevParams &P, const DevPtrs &D,
         if (item < 0) return true;
         if (mate >= 0) { pe0 = item & 0xFFFFFF; pe1 = mate & 0xFFFFFF; item = -1; }
     }
-    if (ROLE == 1 && pe0 >= 0) {
-        // ---- a paired task ----
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the envs' arrays as the waves that parked them left them
-        PairLimits Q;
-        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work;
-        Q.gc_slots = P.pp_max_slots - 6; Q.max_rate = P.pp_rate;
-        int it_half = 0, score_half = 0, heavy_half = 0;
-        auto behind = [&](const int level) -> bool {
-            int y = 0;
-            if (lane == 0) y = sq_someone_behind(P, D, x, level) ? 1 : 0;
-            return __builtin_amdgcn_readfirstlane(y) != 0;
-        };
-        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, Q, it_half, score_half, heavy_half, behind);
-        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
-        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
-        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
-        const int hv0 = __builtin_amdgcn_readlane(heavy_half, 0), hv1 = __builtin_amdgcn_readlane(heavy_half, 32);
-        pair_gsync();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
-        if (lane == 0) {
-            if (st0 == 1) D.sq_done[pe0] = 1;
-            if (st1 == 1) D.sq_done[pe1] = 1;
-            if (nfin) atomicAdd(sq_finished(D), nfin);
-        }
-        const bool pk0 = st0 == 2, pk1 = st1 == 2;
-        if (lane == 0 && D.sq_pairstat != nullptr) {
-            atomicAdd(&D.sq_pairstat[bid < nfirst ? 0 : 1], 1);
-            if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
-        }
-        if (!pk0 && !pk1) return false;
-        // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
-        const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
-        if (lane == 0) {
-            if (pk0 && !c0) { D.sq_lev[pe0] = it0 / P.sq_chunk; sq_push(P, D, x + (hv0 ? 0 : 8), it0 / P.sq_chunk, pe0); }
-            if (pk1 && !c1) { D.sq_lev[pe1] = it1 / P.sq_chunk; sq_push(P, D, x + (hv1 ? 0 : 8), it1 / P.sq_chunk, pe1); }
-            if (D.sq_pairstat != nullptr) {
-                if (c0 || c1) atomicAdd(&D.sq_pairstat[3], 1);
-                const int qh = ((pk0 && !c0 && hv0) ? 1 : 0) + ((pk1 && !c1 && hv1) ? 1 : 0), ql = ((pk0 && !c0 && !hv0) ? 1 : 0) + ((pk1 && !c1 && !hv1) ? 1 : 0);
-                if (qh) atomicAdd(&D.sq_pairstat[4], qh);
-                if (ql) atomicAdd(&D.sq_pairstat[5], ql);
-            }
-        }
-        if (!c0 && !c1) return false;
-        item = (c0 ? pe0 : pe1) | (3 << 24);   // top issue priority: it left its pair because it is heavy
-        lev = (c0 ? it0 : it1) / P.sq_chunk;
-        __syncthreads();
-    }
-    const int env = item & 0xFFFFFF;
-    if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
-    else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
-#ifdef BP_SCHED_TRACE   // diagnostic build (tools/sched_trace.py): every task's (env, levels, XCD, start, end) in the 100 MHz reference clock, into D.prof
-    const unsigned long long _tr0 = __builtin_amdgcn_s_memrealtime();
-#endif
-    int lev_out = lev + 1, light_out = 0;
-    // P.sq_hold: the envs of the top issue-priority class -- the heaviest quarter of the dispatch order, and envs that left a pair as heavy -- keep their slot
-    // while other envs merely have not started yet: their chain is what the launch waits for at the end, and a first chunk that waits costs it a round
-    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, completion,
-                                                          &light_out, P.sq_hold != 0 && (item >> 24) == 3);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    SchedTraceCtx T;
+    T.trw = 0ull; T.idle = 0; T.first = bid < nfirst ? 1 : 0; T.home = home;
 #ifdef BP_SCHED_TRACE
-    if (lane == 0 && D.prof != nullptr) {
-        const unsigned long long _tr1 = __builtin_amdgcn_s_memrealtime();
-        const unsigned long long idx = atomicAdd(&D.prof[0], 1ull);
-        unsigned long long *o = D.prof + 8 + 4 * idx;
-        o[0] = (unsigned long long)(unsigned)env | ((unsigned long long)(unsigned)lev << 32) | ((unsigned long long)(unsigned)(done ? 255 : lev_out) << 40) | ((unsigned long long)(unsigned)home << 48) |
-               ((unsigned long long)(unsigned)x << 52) | ((unsigned long long)((bid < nfirst) ? 1u : 0u) << 56);
-        unsigned hwid;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));   // wave slot, SIMD, CU, SE of this wave: which slot the task ran in
-        o[1] = _tr0; o[2] = _tr1;
-        o[3] = ((_tr0 - _trw) << 32) | ((unsigned long long)(hwid & 0xFFFFu) << 16) | (unsigned long long)(unsigned)min(_tr_idle, 65535);   // workgroup start -> task start, slot id, empty polls
-    }
+    T.trw = _trw; T.idle = _tr_idle;
 #endif
-    if (lane == 0) {
-        if (done) { D.sq_done[env] = 1; if (!completion) atomicAdd(sq_finished(D), 1); }
-        else {
-            D.sq_lev[env] = lev_out;
-            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((P.pair_mode == 2 && !completion && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
-        }
+    if (ROLE == 1 && pe0 >= 0) {
+        const int r = sched_paired_block<KIND>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, x, bid < nfirst);
+        if (r < 0) return false;
+        item = r & 0x3FFFFFF; lev = (int)((unsigned)r >> 26);
     }
+    sched_solo_block<KIND>(P, D, actions, reward, terminated, truncated, info, item, lev, x, completion, T);
     return false;
 }
 // ---- the same scheduler with resident wavefronts (k_physics_step_schedl*, the default of a scheduled launch without pairing) -----------------------------------
@@ -1003,60 +1031,9 @@ __device__ __attribute__((noinline)) int sched_fn_pair(const DevParams *Pg_, con
 {
     const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)BP_UNIFORM_PTR(unsigned long long, Pg_);
     const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)BP_UNIFORM_PTR(unsigned long long, Dg_);
-    const double *__restrict__ actions = BP_UNIFORM_PTR(const double *, actions_);
-    double *__restrict__ reward = BP_UNIFORM_PTR(double *, reward_);
-    unsigned char *__restrict__ terminated = BP_UNIFORM_PTR(unsigned char *, terminated_);
-    unsigned char *__restrict__ truncated = BP_UNIFORM_PTR(unsigned char *, truncated_);
-    double *__restrict__ info = BP_UNIFORM_PTR(double *, info_);
-    pe0 = __builtin_amdgcn_readfirstlane(pe0); pe1 = __builtin_amdgcn_readfirstlane(pe1); x = __builtin_amdgcn_readfirstlane(x); first = __builtin_amdgcn_readfirstlane(first);
-    const int lane = lane_id();
-    {
-        // ---- a paired task (sched_body, ROLE 1) ----
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the envs' arrays as the waves that parked them left them
-        PairLimits Q;
-        Q.max_keys = P.pp_max_keys; Q.max_slots = P.pp_max_slots; Q.max_mv = P.pp_max_mv; Q.max_act = P.pp_max_act; Q.max_work = P.pp_max_work;
-        Q.gc_slots = P.pp_max_slots - 6; Q.max_rate = P.pp_rate;
-        int it_half = 0, score_half = 0, heavy_half = 0;
-        auto behind = [&](const int level) -> bool {
-            int y = 0;
-            if (lane == 0) y = sq_someone_behind(P, D, x, level) ? 1 : 0;
-            return __builtin_amdgcn_readfirstlane(y) != 0;
-        };
-        const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, Q, it_half, score_half, heavy_half, behind);
-        const int st0 = __builtin_amdgcn_readlane(st_half, 0), st1 = __builtin_amdgcn_readlane(st_half, 32);
-        const int it0 = __builtin_amdgcn_readlane(it_half, 0), it1 = __builtin_amdgcn_readlane(it_half, 32);
-        const int sc0 = __builtin_amdgcn_readlane(score_half, 0), sc1 = __builtin_amdgcn_readlane(score_half, 32);
-        const int hv0 = __builtin_amdgcn_readlane(heavy_half, 0), hv1 = __builtin_amdgcn_readlane(heavy_half, 32);
-        pair_gsync();
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const int nfin = (st0 == 1 ? 1 : 0) + (st1 == 1 ? 1 : 0);
-        if (lane == 0) {
-            if (st0 == 1) D.sq_done[pe0] = 1;
-            if (st1 == 1) D.sq_done[pe1] = 1;
-            if (nfin) atomicAdd(sq_finished(D), nfin);
-        }
-        const bool pk0 = st0 == 2, pk1 = st1 == 2;
-        if (lane == 0 && D.sq_pairstat != nullptr) {
-            atomicAdd(&D.sq_pairstat[first ? 0 : 1], 1);
-            if (nfin) atomicAdd(&D.sq_pairstat[2], nfin);
-        }
-        if (!pk0 && !pk1) return -1;
-        // a heavy env carries on here, alone (the heavier of two); whatever else was parked goes to the queue of its kind and level
-        const bool c0 = pk0 && hv0 && (!(pk1 && hv1) || sc0 >= sc1), c1 = !c0 && pk1 && hv1;
-        if (lane == 0) {
-            if (pk0 && !c0) { D.sq_lev[pe0] = it0 / P.sq_chunk; sq_push(P, D, x + (hv0 ? 0 : 8), it0 / P.sq_chunk, pe0); }
-            if (pk1 && !c1) { D.sq_lev[pe1] = it1 / P.sq_chunk; sq_push(P, D, x + (hv1 ? 0 : 8), it1 / P.sq_chunk, pe1); }
-            if (D.sq_pairstat != nullptr) {
-                if (c0 || c1) atomicAdd(&D.sq_pairstat[3], 1);
-                const int qh = ((pk0 && !c0 && hv0) ? 1 : 0) + ((pk1 && !c1 && hv1) ? 1 : 0), ql = ((pk0 && !c0 && !hv0) ? 1 : 0) + ((pk1 && !c1 && !hv1) ? 1 : 0);
-                if (qh) atomicAdd(&D.sq_pairstat[4], qh);
-                if (ql) atomicAdd(&D.sq_pairstat[5], ql);
-            }
-        }
-        if (!c0 && !c1) return -1;
-        __syncthreads();
-        return ((c0 ? pe0 : pe1) | (3 << 24)) | (((c0 ? it0 : it1) / P.sq_chunk) << 26);   // top issue priority: it left its pair because it is heavy
-    }
+    return sched_paired_block<KIND>(P, D, BP_UNIFORM_PTR(const double *, actions_), BP_UNIFORM_PTR(double *, reward_), BP_UNIFORM_PTR(unsigned char *, terminated_),
+                                    BP_UNIFORM_PTR(unsigned char *, truncated_), BP_UNIFORM_PTR(double *, info_), __builtin_amdgcn_readfirstlane(pe0),
+                                    __builtin_amdgcn_readfirstlane(pe1), __builtin_amdgcn_readfirstlane(x), __builtin_amdgcn_readfirstlane(first) != 0);
 }
 template <int KIND>
 __device__ __attribute__((noinline)) void sched_fn_solo(const DevParams *Pg_, const DevPtrs *Dg_, const double *actions_, double *reward_, unsigned char *terminated_,
@@ -1064,33 +1041,12 @@ __device__ __attribute__((noinline)) void sched_fn_solo(const DevParams *Pg_, co
 {
     const DevParams &P = *(const DevParams *)(const __attribute__((address_space(4))) DevParams *)BP_UNIFORM_PTR(unsigned long long, Pg_);
     const DevPtrs &D = *(const DevPtrs *)(const __attribute__((address_space(4))) DevPtrs *)BP_UNIFORM_PTR(unsigned long long, Dg_);
-    const double *__restrict__ actions = BP_UNIFORM_PTR(const double *, actions_);
-    double *__restrict__ reward = BP_UNIFORM_PTR(double *, reward_);
-    unsigned char *__restrict__ terminated = BP_UNIFORM_PTR(unsigned char *, terminated_);
-    unsigned char *__restrict__ truncated = BP_UNIFORM_PTR(unsigned char *, truncated_);
-    double *__restrict__ info = BP_UNIFORM_PTR(double *, info_);
-    item = __builtin_amdgcn_readfirstlane(item); lev = __builtin_amdgcn_readfirstlane(lev); x = __builtin_amdgcn_readfirstlane(x);
-    const int lane = lane_id();
-    const int env = item & 0xFFFFFF;
-    if ((item >> 24) == 3) __builtin_amdgcn_s_setprio(3);
-    else if ((item >> 24) == 1) __builtin_amdgcn_s_setprio(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the env's arrays as the wave that parked it left them
-    int lev_out = lev + 1, light_out = 0;
-    // P.sq_hold: the envs of the top issue-priority class -- the heaviest quarter of the dispatch order, and envs that left a pair as heavy -- keep their slot
-    // while other envs merely have not started yet: their chain is what the launch waits for at the end, and a first chunk that waits costs it a round
-    const bool done = physics_body<MODE_STEP, KIND, true>(P, D, actions, nullptr, reward, terminated, truncated, info, 0, 0, env, lev, x, &lev_out, false,
-                                                          &light_out, P.sq_hold != 0 && (item >> 24) == 3);
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    if (lane == 0) {
-        if (done) { D.sq_done[env] = 1; atomicAdd(sq_finished(D), 1); }
-        else {
-            D.sq_lev[env] = lev_out;
-            if (!(P.sq_debug && env == 1 && lev_out == 1)) sq_push(P, D, x + ((P.pair_mode == 2 && light_out) ? 8 : 0), lev_out, item);   // test hook: the item is lost
-        }
-    }
+    SchedTraceCtx T;
+    T.trw = 0ull; T.idle = 0; T.first = 0; T.home = 0;   // (the trace build records the tasks of the kernels that inline sched_body)
+    sched_solo_block<KIND>(P, D, BP_UNIFORM_PTR(const double *, actions_), BP_UNIFORM_PTR(double *, reward_), BP_UNIFORM_PTR(unsigned char *, terminated_),
+                           BP_UNIFORM_PTR(unsigned char *, truncated_), BP_UNIFORM_PTR(double *, info_), __builtin_amdgcn_readfirstlane(item),
+                           __builtin_amdgcn_readfirstlane(lev), __builtin_amdgcn_readfirstlane(x), false, T);
 }
-
 // the resident loop of a pairing launch: what sched_body<KIND, 1> does before its task (first tasks by position, then the queues of either kind), then the functions
 template <int KIND>
 __device__ __forceinline__ void sched_resident_pairing(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
