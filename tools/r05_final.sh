@@ -26,5 +26,7 @@ for b in 0 3000; do BP_BD_BUDGET=$b tools/kt_box_timeline.sh > $REPO/gpurun_out/
 PMC_KERNELS=k_physics_step_schedr PMC_BENCH_ARGS="--steps 6 --warmup 24 --no-steady-state" tools/pmc_sq.sh 8192 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_INSTS_BRANCH > $OUT/pmc_paired_8192.txt 2>&1
 PMC_KERNELS=k_physics_step_schedr PMC_BENCH_ARGS="--steps 6 --warmup 24 --no-steady-state" tools/pmc_sq.sh 8192 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU FETCH_SIZE >> $OUT/pmc_paired_8192.txt 2>&1
 (python bench.py --env maze --steps 10 --warmup 3; python bench.py --env box --steps 10 --warmup 3; python bench.py --env area --steps 10 --warmup 3; python bench.py --config c5 --no-cpu-baseline) > $OUT/bench_other_envs.jsonl 2> $OUT/bench_other.err
-BP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-steady-state > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
+# (two ranks share the ONE device here: resident kernels of two processes can only alternate by wave save / restore -- 80 ms per launch in one run -- so the rehearsal
+# uses the dispatcher-driven kernels; on a real node every rank has its own GPU)
+BP_SCHED_PERSIST=0 BP_PAIR_RESIDENT=0 BP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline --no-steady-state > $OUT/bench_2rank_gloo.json 2> $OUT/bench_2rank_gloo.err
 echo done > $OUT/done
