@@ -550,10 +550,10 @@ __device__ __forceinline__ bool bd_point_in_shape(const d2 *wv, const d2 *wn, in
 // body.local_to_world(v) for hull vertex q of body i from its current pose (cpTransformPoint)
 __device__ __forceinline__ d2 bd_local_to_world(const EnvCtx &E, int i, int q)
 {
-    const d2 p = E.pxy[i], r = E.rot[i];
-    const double4 ms = E.mass[i];
+    const d2 p = gE(E.pxy, i), r = gE(E.rot, i);
+    const double4 ms = gE(E.mass, i);
     const double tx = p.x - (ms.z * r.x - ms.w * r.y), ty = p.y - (ms.z * r.y + ms.w * r.x);
-    const d2 lv = E.lv[i * BP_MAXV + q];
+    const d2 lv = gE(E.lv, i * BP_MAXV + q);
     return mk2((r.x * lv.x + (-r.y) * lv.y) + tx, (r.y * lv.x + r.x * lv.y) + ty);
 }
 
@@ -729,7 +729,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                         q = L.rf[c];
                         const int rem = it - c * 4 * nstat, vi = rem / nstat, s2 = first_static + (rem - vi * nstat);
                         const int body = B.first_box + order[q];
-                        hit = bd_point_in_shape(E.wv + s2 * BP_MAXV, E.wn + s2 * BP_MAXV, E.nv[s2], E.prop[s2].x, E.bb[s2], bd_local_to_world(E, body, vi));
+                        hit = bd_point_in_shape(E.wv + s2 * BP_MAXV, E.wn + s2 * BP_MAXV, gE(E.nv, s2), gE(E.prop, s2).x, gE(E.bb, s2), bd_local_to_world(E, body, vi));
                     }
                     unsigned long long hm = ballot(hit);
                     while (hm) { const int l = __ffsll((long long)hm) - 1; hm &= hm - 1; stuck |= 1ull << __shfl(q, l); }
@@ -744,9 +744,9 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                     const int q = L.rf[c];
                     const int rem = it - c * 4 * nstat, vi = rem / nstat, s2 = first_static + (rem - vi * nstat);
                     const int body = B.first_box + order[q];
-                    if (vi < E.nv[body]) {
+                    if (vi < gE(E.nv, body)) {
                         const d2 p = bd_local_to_world(E, body, vi);
-                        const double4 bb = E.bb[s2];
+                        const double4 bb = gE(E.bb, s2);
                         pre = bb.x <= p.x && p.x <= bb.z && bb.y <= p.y && p.y <= bb.w;   // the first test of bd_point_in_shape
                     }
                 }
@@ -765,7 +765,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                 const int q = __ffsll((long long)stuck) - 1;
                 stuck &= stuck - 1;
                 const int body = B.first_box + order[q];
-                const d2 p = E.pxy[body];
+                const d2 p = gE(E.pxy, body);
                 int wi_, wj_;
                 bd_pos_to_win(B, p.x, p.y, wi_, wj_);
                 const unsigned short *edt = Q.edt + ((size_t)map * B.SH * B.SW + (size_t)wi_ * B.SW + wj_) * 2;
@@ -773,7 +773,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                 bd_win_to_pos(B, edt[0], edt[1], nx, ny);
                 __syncthreads();
                 if (lane == 0) {
-                    E.pxy[body] = mk2(nx, ny);
+                    gE(E.pxy, body) = mk2(nx, ny);
                     const int sl = L.slot_of[body];
                     if (sl != 255) { L.sv[sl] = mk2(0.0, 0.0); L.sp[sl] = mk2(nx, ny); }
                 }
@@ -784,7 +784,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                 __syncthreads();
             }
             d2 cur = mk2(0.0, 0.0);
-            if (lane < nalive) cur = E.pxy[B.first_box + order[lane]];
+            if (lane < nalive) cur = gE(E.pxy, B.first_box + order[lane]);
             else if (lane == nalive) cur = L.sp[0];
             if (have_prev) {
                 // python loop with break: the comparison is pure, so "any" gives the same answer
@@ -798,7 +798,7 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
         if (BP_UNLIKELY2(BP_TRACE_ON(D) && env == D.dbg_env && total_sub < 10100u)) { // bp_debug_trace: (x, y, angle) of every body after each sim step
             for (int i = lane; i < E.nb; i += 64) {
                 double *o = D.dbg + ((size_t)total_sub * P.nbcap + i) * 3;
-                o[0] = E.pxy[i].x; o[1] = E.pxy[i].y; o[2] = E.ang[i];
+                o[0] = gE(E.pxy, i).x; o[1] = gE(E.pxy, i).y; o[2] = gE(E.ang, i);
             }
         }
         total_sub++;
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
     d2 *boxpos = Q.boxpos + (size_t)env * BD_MAXBOX;
     for (int q = 0; q < nalive; q++) {
         const int k = order[q], body = B.first_box + k;
-        const d2 p = E.pxy[body];
+        const d2 p = gE(E.pxy, body);
         // shortest_path_distance is a pure function of (position, layout): a box that did not move keeps its distance
         const d2 lastp = boxpos[k];
         const bool same = !init && lastp.x == p.x && lastp.y == p.y;
@@ -941,7 +941,7 @@ __global__ __launch_bounds__(64) void k_bd_finish(const DevParams P, const DevPt
             if (B.use_correct_direction_reward && moved > 0) moved *= B.correct_direction_reward_scale;
             robot_reward += B.partial_rewards_scale * moved;
             bool inside = true;
-            for (int vi = 0; vi < E.nv[body]; vi++) inside = inside && bd_point_in_shape(rp, rn, 4, 0.0, rbb, bd_local_to_world(E, body, vi));
+            for (int vi = 0; vi < gE(E.nv, body); vi++) inside = inside && bd_point_in_shape(rp, rn, 4, 0.0, rbb, bd_local_to_world(E, body, vi));
             if (inside) { remove_mask |= 1ull << q; robot_boxes += 1; robot_reward += B.goal_reward; }
         }
         __syncthreads();
@@ -1391,7 +1391,7 @@ __global__ __launch_bounds__(BDO_THREADS) void k_bd_observe(const DevParams P, c
                     w = mk2((tid == 0 || tid == 3) ? x - l / 2 : x + l / 2, (tid < 2) ? y - wd / 2 : y + wd / 2);
                 } else if (pidx < 4 + B.nbox) w = bd_local_to_world(E, B.first_box + (pidx - 4), tid);
                 else {
-                    const d2 p = E.pxy[0], r = E.rot[0];
+                    const d2 p = gE(E.pxy, 0), r = gE(E.rot, 0);
                     const double fx = B.footprint[tid][0], fy = B.footprint[tid][1];
                     w = mk2((r.x * fx + (-r.y) * fy) + p.x, (r.y * fx + r.x * fy) + p.y);
                 }

@@ -106,8 +106,8 @@ __device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &
         if (i < nbcap) { L.mvs[i] = 0u; L.slot_of[i] = (i < P.nkin) ? (unsigned char)i : 255; }
     }
     for (int i = lane; i < BP_NSLOT + 2; i += 64) { L.mvo[i] = 0u; L.sbody[i] = (unsigned short)i; }   // slots [0, nkin) belong to bodies [0, nkin)
-    if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; L.sp[lane] = E.pxy[lane]; }
-    if (lane == 0) { L.ag[0] = mk2(E.ang[0], 0.0); L.ag[1] = E.rot[0]; }
+    if (lane < P.nkin) { L.sv[lane] = D.velv[eb + lane]; L.sw[lane] = D.velw[eb + lane]; L.sb[lane] = D.velb[eb + lane]; L.sp[lane] = gE(E.pxy, lane); }
+    if (lane == 0) { L.ag[0] = mk2(gE(E.ang, 0), 0.0); L.ag[1] = gE(E.rot, 0); }
     S.nslots = P.nkin;
     S.wall_flag = (P.env_kind == BP_ENV_MAZE) ? (D.e_flags[env] & 1) : 0;
     const size_t ab = (size_t)env * BP_ACAP + lane;
@@ -120,9 +120,9 @@ __device__ __forceinline__ void load_state_a(const DevParams &P, const DevPtrs &
     A.r1_0 = mk2(ad[6], ad[7]); A.r2_0 = mk2(ad[8], ad[9]); A.r1_1 = mk2(ad[10], ad[11]); A.r2_1 = mk2(ad[12], ad[13]);
     A.slotA = A.slotB = 0;
     if (A.key != ARB_FREE_KEY) {
-        const double4 m1 = E.mass[A.key >> 16], m2 = E.mass[A.key & 0xFFFFu];
+        const double4 m1 = gE(E.mass, A.key >> 16), m2 = gE(E.mass, A.key & 0xFFFFu);
         A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
-        const double4 q1 = E.prop[A.key >> 16], q2 = E.prop[A.key & 0xFFFFu];
+        const double4 q1 = gE(E.prop, A.key >> 16), q2 = gE(E.prop, A.key & 0xFFFFu);
         A.e = q1.y * q2.y; A.u = q1.z * q2.z;
     }
     S.stamp = D.e_stamp[env]; S.curr_dt = D.e_currdt[env];
@@ -156,7 +156,7 @@ __device__ __forceinline__ void load_state_b(const DevParams &P, const DevPtrs &
             int sl = S.nslots + popc_below(ms, lane);
             if (sl >= BP_NSLOT) { S.err |= BP_ERR_ARB_OVERFLOW; sl = BP_NSLOT - 1; }
             L.slot_of[i] = (unsigned char)sl; L.sbody[sl] = (unsigned short)i;
-            L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb; L.sp[sl] = E.pxy[i];
+            L.sv[sl] = v; L.sw[sl] = w2; L.sb[sl] = vb; L.sp[sl] = gE(E.pxy, i);
         }
         n += __popcll(m);
         S.nslots = min(S.nslots + __popcll(ms), BP_NSLOT);
@@ -368,10 +368,10 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                     }
                     double sn, cs;
                     bp_sincos(ps.z, sn, cs);
-                    E.pxy[i] = mk2(ps.x, ps.y); E.ang[i] = ps.z; E.rot[i] = mk2(cs, sn);
+                    gE(E.pxy, i) = mk2(ps.x, ps.y); gE(E.ang, i) = ps.z; gE(E.rot, i) = mk2(cs, sn);
                     if (i < P.nkin) L.sp[i] = mk2(ps.x, ps.y);
                     if (i == 0) { L.ag[0] = mk2(ps.z, 0.0); L.ag[1] = mk2(cs, sn); }
-                    E.adjn[i] = 0;
+                    gE(E.adjn, i) = 0;
                 }
             }
         }
@@ -381,8 +381,8 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             const bool act = i < E.nb;
             double4 t; t.x = 1; t.y = 0; t.z = 0; t.w = 0;
             if (act) {
-                const d2 p = E.pxy[i], r = E.rot[i];
-                const double4 ms = E.mass[i];
+                const d2 p = gE(E.pxy, i), r = gE(E.rot, i);
+                const double4 ms = gE(E.mass, i);
                 t.x = r.x; t.y = r.y;
                 t.z = p.x - (ms.z * r.x - ms.w * r.y);
                 t.w = p.y - (ms.z * r.y + ms.w * r.x);
@@ -390,28 +390,28 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             double4 nbb;
             world_from_pose(P, E, act ? i : 0, act, lane & 31, t, nbb);
             if (act && (lane & 31) == 0) {
-                E.bb[i] = nbb;
+                gE(E.bb, i) = nbb;
                 double4 nf;
                 nf.x = nbb.x - P.skin; nf.y = nbb.y - P.skin; nf.z = nbb.z + P.skin; nf.w = nbb.w + P.skin;
-                E.fat[i] = nf;
+                gE(E.fat, i) = nf;
             }
         }
         __syncthreads();
         // neighbour lists for every body (all fat boxes are final here)
         for (int i = 0; i < E.nb; i++) {
-            if (kind_btype(E.kind[i]) == BODY_STATIC) { if (lane == 0) E.adjn[i] = 0; continue; } // never moves: list unused
-            const double4 fi = E.fat[i];
+            if (kind_btype(gE(E.kind, i)) == BODY_STATIC) { if (lane == 0) gE(E.adjn, i) = 0; continue; } // never moves: list unused
+            const double4 fi = gE(E.fat, i);
             int cnt = 0;
             for (int base = 0; base < E.nb; base += 64) {
                 const int j = base + lane;
-                const bool ov = (j < E.nb) && (j != i) && bb_overlap(fi, E.fat[j]);
+                const bool ov = (j < E.nb) && (j != i) && bb_overlap(fi, gE(E.fat, j));
                 const unsigned long long m = ballot(ov);
                 const int pos = cnt + popc_below(m, lane);
-                if (ov && pos < BP_KADJ) { E.adj[i * BP_KADJ + pos] = (unsigned short)j; E.hint[i * BP_KADJ + pos] = 0; }
+                if (ov && pos < BP_KADJ) { gE(E.adj, i * BP_KADJ + pos) = (unsigned short)j; gE(E.hint, i * BP_KADJ + pos) = 0; }
                 cnt += __popcll(m);
             }
             if (cnt > BP_KADJ) { S.err |= BP_ERR_ADJ_OVERFLOW; cnt = BP_KADJ; }
-            if (lane == 0) E.adjn[i] = (unsigned char)cnt;
+            if (lane == 0) gE(E.adjn, i) = (unsigned char)cnt;
         }
         A.key = ARB_FREE_KEY; A.stamp = 0; A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0;
         A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0;
@@ -435,7 +435,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         // ship control (ship_ice_env.py:265-274): set once per env step
         if ((!CHUNKED || c_sub == 0) && lane < P.nkin) { // every part of the kinematic agent carries the same velocity
             const double act = actions[env] * P.max_yaw_rate;
-            const d2 r = E.rot[0];
+            const d2 r = gE(E.rot, 0);
             L.sv[lane] = mk2(r.x * P.target_speed + -r.y * 0.0, r.y * P.target_speed + r.x * 0.0);
             L.sw[lane] = mk2(act, L.sw[lane].y);
         }
@@ -525,7 +525,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                 const int i = base + lane;
                 if (i < E.nb) {
                     double *o = D.dbg + ((size_t)it * nbcap + i) * 3;
-                    o[0] = E.pxy[i].x; o[1] = E.pxy[i].y; o[2] = E.ang[i];
+                    o[0] = gE(E.pxy, i).x; o[1] = gE(E.pxy, i).y; o[2] = gE(E.ang, i);
                 }
             }
         }
@@ -573,10 +573,10 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             const int i = base + lane;
             // shapes that did not move contribute exactly +0, so the test only saves work; across chunks the flag comes from D.sq_moved
             const bool mvd = (i < E.nb) && ((L.mvs[i] > stamp_start) || (CHUNKED && c_sub > 0 && D.sq_moved[(size_t)env * nbcap + i] != 0)) &&
-                             (kind_ctype(E.kind[i]) == 2); // floes / boxes only
+                             (kind_ctype(gE(E.kind, i)) == 2); // floes / boxes only
             double contrib = 0.0;
             if (mvd) {
-                const int n = E.nv[i];
+                const int n = gE(E.nv, i);
                 d2 *prev = E.pv + (size_t)i * BP_MAXV;
                 const d2 *nowv = E.wv + (size_t)i * BP_MAXV;
                 const double area = poly_area_seq(prev, n);
@@ -596,7 +596,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     } else {
         for (int base = 0; base < E.nb * BP_MAXV; base += 64) {
             const int q = base + lane;
-            if (q < E.nb * BP_MAXV) E.pv[q] = E.wv[q];
+            if (q < E.nb * BP_MAXV) gE(E.pv, q) = gE(E.wv, q);
         }
     }
     __syncthreads();
@@ -621,8 +621,8 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
                         (ballot((S.err & BP_ERR_ARB_OVERFLOW) != 0) ? BP_ERR_ARB_OVERFLOW : 0) |
                         (ballot((S.err & BP_ERR_LEVEL_OVERFLOW) != 0) ? BP_ERR_LEVEL_OVERFLOW : 0);
     if (lane == 0) {
-        const d2 sp = E.pxy[0];
-        const double sa = E.ang[0];
+        const d2 sp = gE(E.pxy, 0);
+        const double sa = gE(E.ang, 0);
         D.e_stamp[env] = S.stamp; D.e_currdt[env] = S.curr_dt;
         if (mode == MODE_STEP) D.e_cost[env] = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + ((CHUNKED && c_sub > 0) ? D.sq_carry[(size_t)env * 4 + 3] : 0u);
         D.e_ke[env] = S.total_ke; D.e_imp[env] = S.total_imp;
@@ -690,7 +690,7 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             else if (boundary_terminal) term = 1;
             double dist_reward = 0.0;
             if (sp.y < P.goal_y) {
-                const d2 r = E.rot[0];
+                const d2 r = gE(E.rot, 0);
                 dist_reward = 1.0 * (r.x * 0.0 + r.y * 1.0);
             }
             const double coll = -work;

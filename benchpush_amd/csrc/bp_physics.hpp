@@ -69,6 +69,11 @@ struct EnvCtx {
     unsigned long long *hint;
 };
 
+// Element idx of a per-env array: the env's base pointer is wave-uniform (an SGPR pair) and the arrays of one env are far below 4 GB, so the byte offset is formed
+// in 32 bits and the access takes the scalar-base form (global_load v, v_offset, s[base]) -- one VALU instruction per address instead of a sign extension and a
+// 64-bit shift-and-add, and one VGPR per live address instead of two.  Indices are non-negative.
+template <typename T> __device__ __forceinline__ T &gE(T *const base, const int idx) { return *(T *)((char *)base + (size_t)((unsigned)idx * (unsigned)sizeof(T))); }
+
 struct LdsCtx {
     d2 *sv, *sw, *sb;          // [BP_NSLOT] (vx,vy) (w,w_bias) (vbx,vby) of the bodies that hold a velocity slot
     d2 *ag;                    // agent (body 0): (angle, -), (cos, sin), kept current by the integrate phase
@@ -158,52 +163,52 @@ __device__ __forceinline__ bool bb_overlap(double4 a, double4 b)
 __device__ __forceinline__ void refresh_body(const DevParams &P, const EnvCtx &E, int i, int &err)
 {
     const int lane = lane_id();
-    const double4 b = E.bb[i];
+    const double4 b = gE(E.bb, i);
     double4 nf;
     nf.x = b.x - P.skin; nf.y = b.y - P.skin; nf.z = b.z + P.skin; nf.w = b.w + P.skin;
-    if (lane == 0) E.fat[i] = nf;
+    if (lane == 0) gE(E.fat, i) = nf;
     __syncthreads();
     int cnt = 0;
     for (int base = 0; base < E.nb; base += 64) {
         const int j = base + lane;
         const bool valid = (j < E.nb) && (j != i);
-        const double4 fj = valid ? E.fat[j] : nf;
+        const double4 fj = valid ? gE(E.fat, j) : nf;
         const bool ov = valid && bb_overlap(nf, fj);
         const unsigned long long m = ballot(ov);
         const int pos = cnt + popc_below(m, lane);
-        if (ov && pos < BP_KADJ) { E.adj[i * BP_KADJ + pos] = (unsigned short)j; E.hint[i * BP_KADJ + pos] = 0; }
+        if (ov && pos < BP_KADJ) { gE(E.adj, i * BP_KADJ + pos) = (unsigned short)j; gE(E.hint, i * BP_KADJ + pos) = 0; }
         cnt += __popcll(m);
-        if (ov && kind_btype(E.kind[j]) != BODY_STATIC) { // static shapes never move: their own lists are never read
-            int nj = E.adjn[j];
+        if (ov && kind_btype(gE(E.kind, j)) != BODY_STATIC) { // static shapes never move: their own lists are never read
+            int nj = gE(E.adjn, j);
             bool found = false;
-            for (int s2 = 0; s2 < nj; s2++) found = found || (E.adj[j * BP_KADJ + s2] == (unsigned short)i);
+            for (int s2 = 0; s2 < nj; s2++) found = found || (gE(E.adj, j * BP_KADJ + s2) == (unsigned short)i);
             if (!found) {
                 if (nj >= BP_KADJ) { // purge entries of j that no longer fat-overlap j
                     int w = 0;
                     for (int s2 = 0; s2 < nj; s2++) {
-                        const int k = E.adj[j * BP_KADJ + s2];
-                        const double4 fk = (k == i) ? nf : E.fat[k];
+                        const int k = gE(E.adj, j * BP_KADJ + s2);
+                        const double4 fk = (k == i) ? nf : gE(E.fat, k);
                         if (bb_overlap(fj, fk)) {
-                            E.adj[j * BP_KADJ + w] = (unsigned short)k;
-                            E.hint[j * BP_KADJ + w] = E.hint[j * BP_KADJ + s2];
+                            gE(E.adj, j * BP_KADJ + w) = (unsigned short)k;
+                            gE(E.hint, j * BP_KADJ + w) = gE(E.hint, j * BP_KADJ + s2);
                             w++;
                         }
                     }
                     nj = w;
                 }
                 if (nj < BP_KADJ) {
-                    E.adj[j * BP_KADJ + nj] = (unsigned short)i;
-                    E.hint[j * BP_KADJ + nj] = 0;
-                    E.adjn[j] = (unsigned char)(nj + 1);
+                    gE(E.adj, j * BP_KADJ + nj) = (unsigned short)i;
+                    gE(E.hint, j * BP_KADJ + nj) = 0;
+                    gE(E.adjn, j) = (unsigned char)(nj + 1);
                 } else {
-                    E.adjn[j] = (unsigned char)nj;
+                    gE(E.adjn, j) = (unsigned char)nj;
                     err |= BP_ERR_ADJ_OVERFLOW;
                 }
             }
         }
     }
     if (cnt > BP_KADJ) { err |= BP_ERR_ADJ_OVERFLOW; cnt = BP_KADJ; }
-    if (lane == 0) E.adjn[i] = (unsigned char)cnt;
+    if (lane == 0) gE(E.adjn, i) = (unsigned char)cnt;
     __syncthreads();
 }
 
@@ -211,24 +216,24 @@ __device__ __forceinline__ void refresh_body(const DevParams &P, const EnvCtx &E
 __device__ __forceinline__ void world_from_pose(const DevParams &P, const EnvCtx &E, int i, bool active, int q, double4 t,
                                                 double4 &outbb)
 {
-    const int n = active ? E.nv[i] : 0;
+    const int n = active ? gE(E.nv, i) : 0;
     const bool valid = active && (q < n);
     double vx = 0, vy = 0;
     if (valid) {
-        const d2 lv = E.lv[i * BP_MAXV + q], ln = E.ln[i * BP_MAXV + q];
+        const d2 lv = gE(E.lv, i * BP_MAXV + q), ln = gE(E.ln, i * BP_MAXV + q);
         const double c = t.x, s = t.y;
         vx = (c * lv.x + (-s) * lv.y) + t.z;
         vy = (s * lv.x + c * lv.y) + t.w;
         const double nx = c * ln.x + (-s) * ln.y;
         const double ny = s * ln.x + c * ln.y;
-        E.wv[i * BP_MAXV + q] = mk2(vx, vy);
-        E.wn[i * BP_MAXV + q] = mk2(nx, ny);
+        gE(E.wv, i * BP_MAXV + q) = mk2(vx, vy);
+        gE(E.wn, i * BP_MAXV + q) = mk2(nx, ny);
     }
     const double l = half_min(valid ? vx : BP_INF);
     const double r = half_max(valid ? vx : -BP_INF);
     const double bo = half_min(valid ? vy : BP_INF);
     const double tp = half_max(valid ? vy : -BP_INF);
-    const double rad = E.prop[i].x;
+    const double rad = gE(E.prop, i).x;
     outbb.x = l - rad; outbb.y = bo - rad; outbb.z = r + rad; outbb.w = tp + rad;
 }
 
@@ -264,7 +269,7 @@ __device__ __forceinline__ void support_queries(const EnvCtx &E, const LdsCtx &L
         for (int t = 0; t < (VL + 7) / 8; t++) {
             const int q = l8 + 8 * t;
             const bool ok = act && (q < nv);
-            const d2 v = E.wv[body * BP_MAXV + (ok ? q : 0)];
+            const d2 v = gE(E.wv, body * BP_MAXV + (ok ? q : 0));
             const double d = vdot(dir, v);
             if (ok && d < best) { best = d; bi = q; }
         }
@@ -311,19 +316,19 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const int sl = L.slot_of[i];
             d2 v = mk2(0.0, 0.0), w2 = mk2(0.0, 0.0), vb = mk2(0.0, 0.0);
             if (sl != 255) { v = L.sv[sl]; w2 = L.sw[sl]; vb = L.sb[sl]; }
-            d2 p = E.pxy[i];
+            d2 p = gE(E.pxy, i);
             if (sl != 255) p = L.sp[sl];
-            const double a = E.ang[i];
-            d2 r = E.rot[i];
-            const double4 ms = E.mass[i];
-            rad = E.prop[i].x;
-            fatb = E.fat[i];
-            L.rf[lane] = (unsigned char)E.nv[i];
+            const double a = gE(E.ang, i);
+            d2 r = gE(E.rot, i);
+            const double4 ms = gE(E.mass, i);
+            rad = gE(E.prop, i).x;
+            fatb = gE(E.fat, i);
+            L.rf[lane] = (unsigned char)gE(E.nv, i);
             p.x = p.x + (v.x + vb.x) * dt;
             p.y = p.y + (v.y + vb.y) * dt;
             const double a2 = a + (w2.x + w2.y) * dt;
             if (a2 != a) { double sn, cs; bp_sincos(a2, sn, cs); r = mk2(cs, sn); }
-            E.pxy[i] = p; E.ang[i] = a2; E.rot[i] = r;
+            gE(E.pxy, i) = p; gE(E.ang, i) = a2; gE(E.rot, i) = r;
             if (i == 0) { L.ag[0] = mk2(a2, 0.0); L.ag[1] = r; }
             if (sl != 255) { L.sb[sl] = mk2(0.0, 0.0); L.sw[sl].y = 0.0; L.sp[sl] = p; }   // w itself is unchanged: only the bias half is cleared (8-byte store)
             double4 t;
@@ -349,13 +354,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (q < (int)L.rf[kk]) {
                     const d2 t0_ = L.tf[2 * kk], t1_ = L.tf[2 * kk + 1];
                     const double c = t0_.x, s = t0_.y;
-                    const d2 lv = E.lv[i * BP_MAXV + q], ln = E.ln[i * BP_MAXV + q];
+                    const d2 lv = gE(E.lv, i * BP_MAXV + q), ln = gE(E.ln, i * BP_MAXV + q);
                     const double vx = (c * lv.x + (-s) * lv.y) + t1_.x;
                     const double vy = (s * lv.x + c * lv.y) + t1_.y;
                     const double nx = c * ln.x + (-s) * ln.y;
                     const double ny = s * ln.x + c * ln.y;
-                    E.wv[i * BP_MAXV + q] = mk2(vx, vy);
-                    E.wn[i * BP_MAXV + q] = mk2(nx, ny);
+                    gE(E.wv, i * BP_MAXV + q) = mk2(vx, vy);
+                    gE(E.wn, i * BP_MAXV + q) = mk2(nx, ny);
                     const unsigned long long kx = f64_key(vx), ky = f64_key(vy);
                     atomicMin(&bbk[kk * 4 + 0], kx); atomicMax(&bbk[kk * 4 + 1], kx);
                     atomicMin(&bbk[kk * 4 + 2], ky); atomicMax(&bbk[kk * 4 + 3], ky);
@@ -370,7 +375,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             double4 nbb;
             nbb.x = key_f64(bbk[lane * 4 + 0]) - rad; nbb.y = key_f64(bbk[lane * 4 + 2]) - rad;
             nbb.z = key_f64(bbk[lane * 4 + 1]) + rad; nbb.w = key_f64(bbk[lane * 4 + 3]) + rad;
-            E.bb[i] = nbb;
+            gE(E.bb, i) = nbb;
             leftfat = !(nbb.x >= fatb.x && nbb.y >= fatb.y && nbb.z <= fatb.z && nbb.w <= fatb.w);
         }
         PROF_ACC(0)
@@ -394,7 +399,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         kmax = 0;
         for (int k0 = 0; k0 < S.nmv; k0 += 64) {
             const int k = k0 + lane;
-            const int cnt = (k < S.nmv) ? (int)E.adjn[L.mv[k]] : 0;
+            const int cnt = (k < S.nmv) ? (int)gE(E.adjn, L.mv[k]) : 0;
             int m = 0;
             for (int bit = 16; bit >= 1; bit >>= 1) { if (ballot(cnt >= (m | bit))) m |= bit; }
             kmax = max(kmax, m);
@@ -426,14 +431,14 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const bool inlist = k < S.nmv;
             i = inlist ? (int)L.mv[k] : 0;
             const int sc = min(s, BP_KADJ - 1);
-            const int adjn_i = E.adjn[i];
-            j = E.adj[i * BP_KADJ + sc] < E.nb ? (int)E.adj[i * BP_KADJ + sc] : 0;
-            hw = E.hint[i * BP_KADJ + sc];
+            const int adjn_i = gE(E.adjn, i);
+            j = gE(E.adj, i * BP_KADJ + sc) < E.nb ? (int)gE(E.adj, i * BP_KADJ + sc) : 0;
+            hw = gE(E.hint, i * BP_KADJ + sc);
             valid = inlist && (s < adjn_i);
             if (valid && L.mvs[j] == now && j < i) valid = false; // pair is evaluated from j's list
-            const int ki = E.kind[i], kj = E.kind[j];
-            const double mi = E.mass[i].x, mj = E.mass[j].x;
-            nA_h = E.nv[min(i, j)]; nB_h = E.nv[max(i, j)];
+            const int ki = gE(E.kind, i), kj = gE(E.kind, j);
+            const double mi = gE(E.mass, i).x, mj = gE(E.mass, j).x;
+            nA_h = gE(E.nv, min(i, j)); nB_h = gE(E.nv, max(i, j));
             flagonly = false; // two infinite-mass shapes: evaluated only for the (1,3) robot x wall handler, never solved
             if (valid) {
                 if (kind_group(ki) != 0 && kind_group(ki) == kind_group(kj)) valid = false; // shapes of one body
@@ -453,9 +458,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         }
         const int sc = min(s, BP_KADJ - 1);
         const int sa = min(i, j), sb = max(i, j);
-        const double4 bbi = E.bb[i];
-        const double4 bbj = E.bb[j];
-        const double radA = E.prop[sa].x, radB = E.prop[sb].x;
+        const double4 bbi = gE(E.bb, i);
+        const double4 bbj = gE(E.bb, j);
+        const double radA = gE(E.prop, sa).x, radB = gE(E.prop, sb).x;
         const double rsum = radA + radB;
         // the cached planes (hint word) of both sides travel with this round trip too, and so do the cached support vertex of each with its two
         // cyclic neighbours: plane and vertex indices only need to be valid addresses here
@@ -464,10 +469,10 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         const int jA0 = HW_VERT_A(hw) < BP_MAXV ? HW_VERT_A(hw) : 0, jB0 = HW_VERT_B(hw) < BP_MAXV ? HW_VERT_B(hw) : 0;
         const int jAm = (jA0 == 0) ? max(min(cnB, BP_MAXV) - 1, 0) : jA0 - 1, jAp = (jA0 + 1 >= cnB) ? 0 : jA0 + 1;   // on B
         const int jBm = (jB0 == 0) ? max(min(cnA, BP_MAXV) - 1, 0) : jB0 - 1, jBp = (jB0 + 1 >= cnA) ? 0 : jB0 + 1;   // on A
-        const d2 fnA = E.wn[sa * BP_MAXV + hA], fpA = E.wv[sa * BP_MAXV + hA];
-        const d2 fnB = E.wn[sb * BP_MAXV + hB], fpB = E.wv[sb * BP_MAXV + hB];
-        const d2 vAm = E.wv[sb * BP_MAXV + jAm], vA0 = E.wv[sb * BP_MAXV + jA0], vAp = E.wv[sb * BP_MAXV + jAp];
-        const d2 vBm = E.wv[sa * BP_MAXV + jBm], vB0 = E.wv[sa * BP_MAXV + jB0], vBp = E.wv[sa * BP_MAXV + jBp];
+        const d2 fnA = gE(E.wn, sa * BP_MAXV + hA), fpA = gE(E.wv, sa * BP_MAXV + hA);
+        const d2 fnB = gE(E.wn, sb * BP_MAXV + hB), fpB = gE(E.wv, sb * BP_MAXV + hB);
+        const d2 vAm = gE(E.wv, sb * BP_MAXV + jAm), vA0 = gE(E.wv, sb * BP_MAXV + jA0), vAp = gE(E.wv, sb * BP_MAXV + jAp);
+        const d2 vBm = gE(E.wv, sa * BP_MAXV + jBm), vB0 = gE(E.wv, sa * BP_MAXV + jB0), vBp = gE(E.wv, sa * BP_MAXV + jBp);
         if (valid) valid = bb_overlap(bbi, bbj);
         PROF_ACC(27)
         PROF_CNT(24, 1)
@@ -514,7 +519,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             valid = false;
             if (hw & HW_BOTH) {
                 const unsigned long long nh = (hw & ~(HW_BOTH | HW_PRIM_B)) | ((sepAc > rsum) ? 0ull : HW_PRIM_B);
-                E.hint[i * BP_KADJ + s] = nh;
+                gE(E.hint, i * BP_KADJ + s) = nh;
                 if (base == 0) L.cc_hw[lane] = nh;
             }
         }
@@ -568,8 +573,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                     round_addr(pa0, pb0, qb0, np0, nqv0, hX0, ev0, jc0, jm0, jp0);
                     round_addr(pa1, pb1, qb1, np1, nqv1, hX1, ev1, jc1, jm1, jp1);
                     const int fc0 = (f < np0) ? f : 0, fc1 = (f < np1) ? f : 0;
-                    const d2 fn0 = E.wn[pb0 * BP_MAXV + fc0], fp0 = E.wv[pb0 * BP_MAXV + fc0], vb0 = E.wv[qb0 * BP_MAXV + jc0], vm0 = E.wv[qb0 * BP_MAXV + jm0], vp0 = E.wv[qb0 * BP_MAXV + jp0];
-                    const d2 fn1 = E.wn[pb1 * BP_MAXV + fc1], fp1 = E.wv[pb1 * BP_MAXV + fc1], vb1 = E.wv[qb1 * BP_MAXV + jc1], vm1 = E.wv[qb1 * BP_MAXV + jm1], vp1 = E.wv[qb1 * BP_MAXV + jp1];
+                    const d2 fn0 = gE(E.wn, pb0 * BP_MAXV + fc0), fp0 = gE(E.wv, pb0 * BP_MAXV + fc0), vb0 = gE(E.wv, qb0 * BP_MAXV + jc0), vm0 = gE(E.wv, qb0 * BP_MAXV + jm0), vp0 = gE(E.wv, qb0 * BP_MAXV + jp0);
+                    const d2 fn1 = gE(E.wn, pb1 * BP_MAXV + fc1), fp1 = gE(E.wv, pb1 * BP_MAXV + fc1), vb1 = gE(E.wv, qb1 * BP_MAXV + jc1), vm1 = gE(E.wv, qb1 * BP_MAXV + jm1), vp1 = gE(E.wv, qb1 * BP_MAXV + jp1);
                     {
                         const double th = side ? thr0.y : thr0.x;
                         const bool pv = (f < np0) && !(ev0 && f == hX0);
@@ -665,8 +670,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 const double th = side ? thr.y : thr.x;
                 const bool pv = (f < np) && !(evX && f == hX);
                 const int fc = (f < np) ? f : 0;
-                const d2 fn = E.wn[pbody * BP_MAXV + fc], fp = E.wv[pbody * BP_MAXV + fc];
-                const d2 vb = E.wv[qbody * BP_MAXV + jc], vm = E.wv[qbody * BP_MAXV + jm], vp = E.wv[qbody * BP_MAXV + jp];
+                const d2 fn = gE(E.wn, pbody * BP_MAXV + fc), fp = gE(E.wv, pbody * BP_MAXV + fc);
+                const d2 vb = gE(E.wv, qbody * BP_MAXV + jc), vm = gE(E.wv, qbody * BP_MAXV + jm), vp = gE(E.wv, qbody * BP_MAXV + jp);
                 const double c = vdot(fn, fp);
                 const double bound = (fmin(vdot(fn, vb), fmin(vdot(fn, vm), vdot(fn, vp))) - c) + 0.0;
                 const bool surv = pv && (!evX || bound >= th);
@@ -693,7 +698,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         int i1A = 0, i1B = 0;              // support vertices of the contact (PolySupportPointIndex)
         bool needA = false, needB = false; // ... that a support query has to find
         const int nA = nA_l, nB = nB_l;
-        const d2 *Av = E.wv + sa * BP_MAXV, *An = E.wn + sa * BP_MAXV, *Bv = E.wv + sb * BP_MAXV, *Bn = E.wn + sb * BP_MAXV;
+        const d2 *Av = E.wv + sa * BP_MAXV, *Bv = E.wv + sb * BP_MAXV;   // (for the rare tie_partner scan; everything else goes through gE)
+        const int oA = sa * BP_MAXV, oB = sb * BP_MAXV;
         if (valid) {
             const double sA = key_f64(L.res_smA[myr]), sB = key_f64(L.res_smB[myr]);
             iA = (int)L.res_iA[myr]; iB = (int)L.res_iB[myr]; jA = (int)L.res_jA[myr]; jB = (int)L.res_jB[myr];
@@ -702,13 +708,13 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             touching = true;
             // every vertex / normal the three cases below can need is fetched up front: one round trip instead of a dependent chain
             const int iA0 = (iA == 0) ? nA - 1 : iA - 1, iB0 = (iB == 0) ? nB - 1 : iB - 1;
-            const d2 nAi = An[iA], nBi = Bn[iB];
-            const d2 aA = Av[iA0], bA = Av[iA], qA = Bv[jA];
-            const d2 aB = Bv[iB0], bB = Bv[iB], qB = Av[jB];
+            const d2 nAi = gE(E.wn, oA + iA), nBi = gE(E.wn, oB + iB);
+            const d2 aA = gE(E.wv, oA + iA0), bA = gE(E.wv, oA + iA), qA = gE(E.wv, oB + jA);
+            const d2 aB = gE(E.wv, oB + iB0), bB = gE(E.wv, oB + iB), qB = gE(E.wv, oA + jB);
             // the outer neighbours of the two winning edges: they certify the support vertex of the shape that owns the normal (below)
             const int iA0m = (iA0 == 0) ? nA - 1 : iA0 - 1, iAp = (iA + 1 >= nA) ? 0 : iA + 1;
             const int iB0m = (iB0 == 0) ? nB - 1 : iB0 - 1, iBp = (iB + 1 >= nB) ? 0 : iB + 1;
-            const d2 oA0 = Av[iA0m], oA1 = Av[iAp], oB0 = Bv[iB0m], oB1 = Bv[iBp];
+            const d2 oA0 = gE(E.wv, oA + iA0m), oA1 = gE(E.wv, oA + iAp), oB0 = gE(E.wv, oB + iB0m), oB1 = gE(E.wv, oB + iBp);
             if (smax > rsum) touching = false;
             else if (smax <= 0.0) { n = useA ? nAi : vneg(nBi); src = useA ? 0 : 1; }
             else {
@@ -775,7 +781,7 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const unsigned long long nh = (unsigned long long)((unsigned)iA | ((unsigned)iB << 5) | ((unsigned)jA << 10) | ((unsigned)jB << 15) |
                                                                ((unsigned)nA << 20) | ((unsigned)nB << 25)) |
                                           HW_HAS_A | HW_HAS_B | (useA ? 0ull : HW_PRIM_B) | ((smax > rsum) ? 0ull : HW_BOTH);
-            E.hint[i * BP_KADJ + s] = nh;
+            gE(E.hint, i * BP_KADJ + s) = nh;
             if (base == 0) L.cc_hw[lane] = nh;
         }
         PROF_ACC(31)
@@ -805,8 +811,8 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             {   // both candidate edges of each shape are fetched together, then selected
                 const int a0 = (i1A == 0) ? nA - 1 : i1A - 1, a2 = (i1A + 1 == nA) ? 0 : i1A + 1;
                 const int b0 = (i1B == 0) ? nB - 1 : i1B - 1, b2 = (i1B + 1 == nB) ? 0 : i1B + 1;
-                const d2 nA1 = An[i1A], nA2 = An[a2], vA0 = Av[a0], vA1 = Av[i1A], vA2 = Av[a2];
-                const d2 nB1 = Bn[i1B], nB2 = Bn[b2], vB0 = Bv[b0], vB1 = Bv[i1B], vB2 = Bv[b2];
+                const d2 nA1 = gE(E.wn, oA + i1A), nA2 = gE(E.wn, oA + a2), vA0 = gE(E.wv, oA + a0), vA1 = gE(E.wv, oA + i1A), vA2 = gE(E.wv, oA + a2);
+                const d2 nB1 = gE(E.wn, oB + i1B), nB2 = gE(E.wn, oB + b2), vB0 = gE(E.wv, oB + b0), vB1 = gE(E.wv, oB + i1B), vB2 = gE(E.wv, oB + b2);
                 const bool fa = vdot(n, nA1) > vdot(n, nA2);
                 e1a = fa ? vA0 : vA1; e1ia = fa ? a0 : i1A; e1b = fa ? vA1 : vA2; e1ib = fa ? i1A : a2;
                 const bool fb = vdot(nn, nB1) > vdot(nn, nB2);
@@ -839,15 +845,15 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
         if (KIND == BP_ENV_BOX) {
             // (1,3) robot x boundary and (2,3) box x boundary pre_solve: remember normal and contact 0 (r1, r2 relative to the
             // bodies' positions at collision time); they run after the collision phase in ascending key order
-            const bool ev = valid && M.count > 0 && (flagonly || (kind_ctype(E.kind[sa]) == 2 && kind_ctype(E.kind[sb]) == 3));
+            const bool ev = valid && M.count > 0 && (flagonly || (kind_ctype(gE(E.kind, sa)) == 2 && kind_ctype(gE(E.kind, sb)) == 3));
             const unsigned long long em = ballot(ev);
             if (em) {
                 const int pos = S.nev + popc_below(em, lane);
                 if (ev && pos < BP_EVCAP) {
                     L.ev_key[pos] = ((unsigned)sa << 16) | (unsigned)sb;
                     L.ev_d[pos * 3 + 0] = M.n;
-                    L.ev_d[pos * 3 + 1] = vsub(M.p1_0, E.pxy[sa]);
-                    L.ev_d[pos * 3 + 2] = vsub(M.p2_0, E.pxy[sb]);
+                    L.ev_d[pos * 3 + 1] = vsub(M.p1_0, gE(E.pxy, sa));
+                    L.ev_d[pos * 3 + 2] = vsub(M.p2_0, gE(E.pxy, sb));
                 }
                 S.nev += __popcll(em);
                 if (S.nev > BP_EVCAP) { S.nev = BP_EVCAP; S.err |= BP_ERR_ARB_OVERFLOW; }
@@ -899,9 +905,9 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
                 if (BP_UNLIKELY2(fresh)) { // masses and material products of a pair stay with its arbiter
                     A.state = ARB_FIRST; A.count = 0; A.h0 = A.h1 = 0; A.jn0 = A.jt0 = A.jn1 = A.jt1 = 0.0;
                     const int usa = (int)(A.key >> 16), usb = (int)(A.key & 0xFFFFu);
-                    const double4 m1 = E.mass[usa], m2 = E.mass[usb];
+                    const double4 m1 = gE(E.mass, usa), m2 = gE(E.mass, usb);
                     A.ma = m1.x; A.ia = m1.y; A.mb = m2.x; A.ib = m2.y;
-                    const double4 q1 = E.prop[usa], q2 = E.prop[usb];
+                    const double4 q1 = gE(E.prop, usa), q2 = gE(E.prop, usb);
                     A.e = q1.y * q2.y; A.u = q1.z * q2.z;
                 }
                 double njn0 = 0.0, njt0 = 0.0, njn1 = 0.0, njt1 = 0.0;
@@ -959,17 +965,17 @@ __device__ __forceinline__ void substep(const DevParams &P, const EnvCtx &E, con
             const double f = 2 * (v.x * n.x + v.y * n.y);
             const d2 refl = mk2(v.x - n.x * f, v.y - n.y * f);
             const d2 nv = mk2(refl.x * 0.5, refl.y * 0.5);
-            const d2 pa = E.pxy[a], pb = E.pxy[b];
+            const d2 pa = gE(E.pxy, a), pb = gE(E.pxy, b);
             const double depth = vdot(vsub(vadd(pb, r2), vadd(pa, r1)), n);
             const d2 pn = mk2(pa.x + n.x * depth, pa.y + n.y * depth);
             const bool robot = a < P.nkin;
             if (robot) S.robot_hit = depth < 0;
             __syncthreads(); // all lanes have read pa before it is overwritten
             if (robot) {
-                if (lane < P.nkin) { E.pxy[lane] = pn; L.sp[lane] = pn; L.sv[lane] = nv; }
+                if (lane < P.nkin) { gE(E.pxy, lane) = pn; L.sp[lane] = pn; L.sv[lane] = nv; }
                 if (pn.x != pa.x || pn.y != pa.y) S.evmask |= 1ull;
             } else {
-                if (lane == 0) { E.pxy[a] = pn; if (sl != 255) { L.sv[sl] = nv; L.sp[sl] = pn; } }
+                if (lane == 0) { gE(E.pxy, a) = pn; if (sl != 255) { L.sv[sl] = nv; L.sp[sl] = pn; } }
                 if (pn.x != pa.x || pn.y != pa.y) S.evmask |= 1ull << a;
             }
             __syncthreads();
