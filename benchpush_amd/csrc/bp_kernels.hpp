@@ -310,6 +310,9 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
     const int env = CHUNKED ? c_env : (mode == MODE_RESET) ? (tmpl ? P.num_envs + (int)blockIdx.x : (int)blockIdx.x)
                                          : (D.order != nullptr ? D.order[blockIdx.x + boff] : (int)blockIdx.x + boff);
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#ifdef BP_SCHED_TRACE
+    const unsigned long long _tt_a = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = lane_id();
 #if 1
     // heaviest-first dispatch: the first workgroups carry the envs that set the launch time -> issue priority over their SIMD mates
@@ -443,6 +446,10 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         load_state_b<KIND>(P, D, E, L, A, S, env);
     }
 
+#ifdef BP_SCHED_TRACE   // where a task's time goes: resume (everything before the first sub-step), the first sub-step after a resume, parking -- summed into D.prof[1..6]
+    const unsigned long long _tt_b = __builtin_amdgcn_s_memrealtime();
+    unsigned long long _tt_c = 0ull;
+#endif
     const unsigned stamp_start = S.stamp;
     const unsigned costp_resume = S.costp;
     const int nsub = (mode == MODE_RESET) ? P.settle_steps : P.steps;
@@ -501,6 +508,9 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         // agent rules: a ship-ice handle gets the yaw + boundary rules, a maze handle the boundary rule alone -- also when a generic KIND 0 kernel
         // serves it (k_physics_step_damp, k_physics_step with hulls above 8 vertices); the scheduled ship kernel is only ever launched for ship-ice handles
         substep<KIND, DAMP>(P, E, L, A, S, P.dt_sub, (mode != MODE_STEP) ? 0 : (KIND == BP_ENV_SHIP_ICE && (CHUNKED || P.env_kind == BP_ENV_SHIP_ICE)) ? 1 : 2);
+#ifdef BP_SCHED_TRACE
+        if (it == it_first) _tt_c = __builtin_amdgcn_s_memrealtime();
+#endif
         if (BP_UNLIKELY2(S.quiescent && !BP_TRACE_ON(D))) {
             // Nothing moves and no arbiter can produce an impulse: every remaining sub-step leaves all positions,
             // velocities and impulses untouched.  Apply their only effects in closed form: the stamp advances, active
@@ -531,6 +541,9 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         }
     }
 
+#ifdef BP_SCHED_TRACE
+    const unsigned long long _tt_d = __builtin_amdgcn_s_memrealtime();
+#endif
     if (CHUNKED && !step_done) {
         // ---- end of a chunk: park the env exactly as at a step boundary; the step-local flags and the shapes that have moved so far go along
         unsigned char *mvd_ = D.sq_moved + (size_t)env * nbcap;
@@ -562,6 +575,15 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
             if (lane == 0) L.prof[23] = __builtin_amdgcn_s_memtime() - _t_kernel0;
             lds_sync();
             if (lane < BP_PROFN) D.prof[(size_t)env * BP_PROFN + lane] += L.prof[lane];
+        }
+#endif
+#ifdef BP_SCHED_TRACE
+        __syncthreads();
+        if (lane == 0 && D.prof != nullptr) {
+            const unsigned long long _tt_e = __builtin_amdgcn_s_memrealtime();
+            atomicAdd(&D.prof[3], _tt_e - _tt_d); atomicAdd(&D.prof[7], 1ull);                                   // parks: time from the last sub-step to the end of the stores
+            if (c_sub > 0) { atomicAdd(&D.prof[1], _tt_b - _tt_a); atomicAdd(&D.prof[2], _tt_c - _tt_b); atomicAdd(&D.prof[4], 1ull); }   // resumes: load, first sub-step
+            atomicAdd(&D.prof[5], (unsigned long long)(c_it_parked - it_first)); atomicAdd(&D.prof[6], _tt_d - _tt_b);   // sub-steps of the run and their time
         }
 #endif
         return false;

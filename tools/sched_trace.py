@@ -40,6 +40,9 @@ for t in range(STEPS):
         pre = (rec[:, 3] >> np.uint64(32)).astype(np.int64) / 100.0          # microseconds between the workgroup's start and the task's start (queue pop, waiting)
         hwid = ((rec[:, 3] >> np.uint64(16)) & np.uint64(0xFFFF)).astype(np.int64)
         idle = (rec[:, 3] & np.uint64(0xFFFF)).astype(int)
+        if int(p[7]) > 0 and int(p[4]) > 0:      # sums over the tasks that ended with a park (100 MHz ticks): [1] resume = everything before the first sub-step, [2] the first sub-step after a resume, [3] park, [6] / [5] mean sub-step
+            print("   parked tasks %d: park %.1f us each; resumed ones %d: resume %.1f us, first sub-step after it %.1f us; mean sub-step of those runs %.1f us" % (
+                int(p[7]), p[3] / 100.0 / int(p[7]), int(p[4]), p[1] / 100.0 / int(p[4]), p[2] / 100.0 / int(p[4]), p[6] / 100.0 / max(int(p[5]), 1)))
         T0 = t0.min(); t0 = (t0 - T0) / 100.0; t1 = (t1 - T0) / 100.0          # microseconds since the first task started
         end = t1.max()
         busy = (t1 - t0).sum()
