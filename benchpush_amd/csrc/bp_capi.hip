@@ -102,6 +102,16 @@ static int mvcap_for(int nbcap) { return nbcap > 192 ? nbcap : 192; }
 #endif
 static size_t lds_bytes_for(int nbcap, bool box) { return bp_lds_map(nbcap, mvcap_for(nbcap), box, BP_PROF_HOST).total; }
 
+// The chunk boundaries at which a running env may yield (bit k: after k chunks).  A launch without pairing takes no turns during the first 40 % of the step: the
+// even finish needs fine turns only towards the end, and every turn costs ~76 us of slot-time -- +1.6 % env-steps/s at 4096 envs, +1.8 % maze, +0.8 %
+// at 50 % concentration; pairing launches (-2 % at 5120 envs) keep every boundary.  BP_SCHED_YMASK=<mask> overrides.
+static unsigned sched_yield_mask(bool solo_launch, int steps, int chunk)
+{
+    if (const char *ev = getenv("BP_SCHED_YMASK")) return (unsigned)strtoul(ev, nullptr, 0);
+    if (!solo_launch || chunk <= 0) return 0xFFFFFFFFu;
+    const int first = (2 * steps + 5 * chunk - 1) / (5 * chunk);   // ceil(0.4 * steps / chunk)
+    return first >= 32 ? 0u : (0xFFFFFFFFu << first);
+}
 // Resident wavefronts for a scheduled launch without pairing (k_physics_step_schedl*): one workgroup per wave slot of the device, BP_SCHED_PERSIST=0 goes back to
 // one workgroup per task from the hardware dispatcher, BP_SCHED_PERSIST=n > 1 launches n workgroups per slot (the surplus waits for the end and leaves)
 static int sched_persist_setup(bp_handle *h)
@@ -373,6 +383,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->P.sq_floor = std::max(0, getenv("BP_SCHED_FLOOR") ? atoi(getenv("BP_SCHED_FLOOR")) : 150);
             // pace-based issue priorities (physics_body: pace_prio), per cent of the reference cost for priority 3: +1.5 ... +2.4 % at 4096 envs, flat from 100 to 130
             h->P.sq_dynprio = getenv("BP_SCHED_DYNPRIO") ? atoi(getenv("BP_SCHED_DYNPRIO")) : 115;
+            h->P.sq_ymask = 0xFFFFFFFFu;   // (set below, once it is known whether the launch pairs)
             h->P.sq_cls = getenv("BP_SCHED_CLS") ? atoi(getenv("BP_SCHED_CLS")) : 0;
             h->P.sq_parts = std::min(8, std::max(1, getenv("BP_SCHED_PARTS") ? atoi(getenv("BP_SCHED_PARTS")) : 1));
             h->P.sq_part = 0;
@@ -430,6 +441,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             // (pairing launches have a resident kernel of their own, k_physics_step_schedr: the kernel that holds both step bodies INLINE lost 4 % at 8192 envs as a
             // resident loop -- 266 spilled VGPRs against 203)
+            h->P.sq_ymask = sched_yield_mask(h->P.pair_mode != 2, h->P.steps, h->P.sq_chunk);
             if (h->P.pair_mode != 2 && h->P.sq_parts == 1) { int rc2 = sched_persist_setup(h); if (rc2) return rc2; }
             if (h->P.pair_mode == 2) {
                 HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
@@ -454,6 +466,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch; h->P.sq_cap = h->num_envs;
             h->P.sq_dynprio = getenv("BP_SCHED_DYNPRIO") ? atoi(getenv("BP_SCHED_DYNPRIO")) : 115;   // pace priorities as for ship-ice: +1.6 % at 4096 envs
+            h->P.sq_ymask = sched_yield_mask(true, h->P.steps, h->P.sq_chunk);
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
             if ((rc = dalloc(h, &d_items, (size_t)SQ_NX * SQ_MAXLEV * h->P.sq_cap))) return rc;
             if ((rc = dalloc(h, &d_ctr, (size_t)SQ_NX * (SQ_MAXLEV + 2) * 2))) return rc;

@@ -34,6 +34,7 @@ struct DevParams {
     int obs_h, obs_w, grid_h, grid_w;
     int sq_chunk, sq_levels, sq_cap;           // scheduler: sub-steps per chunk, chunks per step, queue capacity per (XCD, level)
     int sq_cls;                                // issue-priority classes of the dispatch order: 0 = quarter / quarter / half -> 3 / 1 / 0, 1 = 1/16, 3/16, 1/4, 1/2 -> 3 / 2 / 1 / 0
+    unsigned sq_ymask;                         // chunk boundaries (bit k: after k chunks) at which a running env may yield; all ones = every boundary
     int sq_dynprio;                            // > 0: issue priority re-set at every chunk boundary from the env's projected step length (per cent of *sq_thr for priority 3)
     int sq_parts, sq_part;                     // the scheduled launch as sq_parts kernels on as many streams; this kernel's index
     int sq_floor;                              // longest-remaining-first: lower bound of the estimated cost per sub-step left (wave cycles >> 8)

@@ -483,15 +483,17 @@ __device__ __forceinline__ bool physics_body(const DevParams &P, const DevPtrs &
         if (CHUNKED) {
             if (to_boundary == 0) { // chunk boundary: yield to an env that is further behind, otherwise carry on without a context switch
                 int yield = 0, key = it / P.sq_chunk;
+                // (P.sq_ymask: the chunk boundaries at which an env may yield, bit k = after k chunks -- an even finish needs fine turns only towards the end of the step)
                 if (lane == 0 && !c_noyield) {
-                    if (P.sq_lrpt) {
+                    if (!((P.sq_ymask >> key) & 1u)) yield = 0;
+                    else if (P.sq_lrpt) {
                         const unsigned long long el = (unsigned long long)carry_units + ((__builtin_amdgcn_s_memtime() - t_begin) >> 8);
                         // (no env is taken for lighter than P.sq_floor per sub-step left: an env's pace so far says little about a cluster it has yet to run into)
                         const unsigned long long rem = max(el * (unsigned)(nsub - it) / (unsigned)max(it, 1), (unsigned long long)P.sq_floor * (unsigned)(nsub - it));
                         key = sq_lrpt_key(P, rem);
                         yield = sq_someone_heavier(P, D, c_x, key, rem) ? 1 : 0;
                     } else yield = sq_someone_behind(P, D, c_x, key, c_hold) ? 1 : 0;
-                    if (P.sq_debug && c_env == 1 && it == P.sq_chunk) yield = 1;
+                    if (P.sq_debug && c_env == 1 && it == P.sq_chunk) yield = 1;   // (fault-injection hook of the diagnostic twin: env 1 parks at its first boundary whatever the mask says)
                 }
                 if (__builtin_amdgcn_readfirstlane(yield)) { step_done = false; *c_lev_out = __builtin_amdgcn_readfirstlane(key); c_it_parked = it; break; }
                 if (P.sq_dynprio) pace_prio((unsigned long long)carry_units + ((__builtin_amdgcn_s_memtime() - t_begin) >> 8), it);
