@@ -814,7 +814,7 @@ __device__ __forceinline__ int sched_paired_block(const DevParams &P, const DevP
         int it_half = 0, score_half = 0, heavy_half = 0;
         auto behind = [&](const int level) -> bool {
             int y = 0;
-            if (lane == 0) y = sq_someone_behind(P, D, x, level) ? 1 : 0;
+            if (lane == 0) y = (((P.sq_ymask >> level) & 1u) && sq_someone_behind(P, D, x, level)) ? 1 : 0;   // (P.sq_ymask: see physics_body)
             return __builtin_amdgcn_readfirstlane(y) != 0;
         };
         const int st_half = pair_task<true>(P, D, actions, reward, terminated, truncated, info, pe0, pe1, Q, it_half, score_half, heavy_half, behind);
