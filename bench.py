@@ -498,8 +498,8 @@ def main():
                   "physics_ms": sp_ms2, "one_gpu_ms_per_step": tmax / K * 1e3, "speedup_vs_one_gpu": tmax / dtS, "efficiency": tmax / dtS / world,
                   "how": "a second handle of E / world = %d envs per rank (global env ids rank * %d ..., same trials and action stream), same W + K steps, "
                          "barrier + synchronize on both sides, max over ranks; T1 = this run's weak region (E envs on every GPU)" % (Es, Es),
-                  "expectation": "below ~3300 envs per GPU a launch lasts as long as its heaviest env's own chain (profiles/r04_final/launch_vs_envs.txt: "
-                                 "12.5 ms at 1024 envs, 13.3 at 2048, 16.0 at 4096), so fixed E = 4096 over N GPUs gains at most ~1.3 x"}
+                  "expectation": "below ~3300 envs per GPU a launch lasts as long as its heaviest env's own chain (profiles/r05_final/launch_vs_envs.txt: "
+                                 "12.5 ms at 1024 envs, 13.4 at 2048, 15.2 at 4096), so fixed E = 4096 over N GPUs gains at most ~1.2 x"}
         env_s.close()
 
     pairing = None
