@@ -30,6 +30,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# dmabuf IPC is what RCCL needs on this pool (without it: hipIpcGetMemHandle: invalid argument).  Set before anything touches the GPU, so that a rank started
+# by an external torchrun / torch.distributed.run gets it as well as the ranks spawn_ranks() starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -81,8 +84,8 @@ def cpu_baseline(env, trials):
     orc.bench(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail, pk, min(nenv, 4), 1, cores)  # warm the library
     n, sec = orc.bench(env.params, cfg.ship.vertices, cfg.ship.head, cfg.ship.tail, pk, nenv, steps, cores)
     return {"value": n / sec, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "%d envs x %d env.step() (30%% ship-ice trials, 400 sub-steps x 10 iterations + raster each), OpenMP on %d "
-                      "threads, step loop only (resets untimed), %.2f s wall = %.0f core-seconds" % (nenv, steps, cores, sec, sec * cores)}
+            "sample": "%d envs x %d env.step() (%.0f%% ship-ice trials, 400 sub-steps x 10 iterations + raster each), OpenMP on %d "
+                      "threads, step loop only (resets untimed), %.2f s wall = %.0f core-seconds" % (nenv, steps, float(cfg.concentration) * 100, cores, sec, sec * cores)}
 
 
 def cpu_baseline_single_thread(env):
@@ -247,6 +250,11 @@ def plumbing_only(args, rank, world):
         allr, allc = gather_episode_block(rows, cnt, dist)
         summarize_episode_block(allr, allc)
         ag = time_allgather(rows, cnt, dist, lambda: None)
+        # the per-rank block of the measured N > 1 line (a straggler rank shows in ms_per_step_by_rank): here every rank reports its all-gather median
+        mine = torch.tensor([ag["median_ms"], 0.0], dtype=torch.float64)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per_rank = [float(t_[0].item()) for t_ in allt]
         dist.barrier()
     if rank == 0:
         line = {"metric": "plumbing only: rank launch + rendezvous + episode-block all-gather", "value": None, "n_gpus": joined,
@@ -254,6 +262,9 @@ def plumbing_only(args, rank, world):
         if world > 1:   # the keys the measured N > 1 line carries (no environment here: the strong-scaling block names its split only)
             line["allgather_ms"] = ag["median_ms"]
             line["allgather"] = ag
+            line["ranks"] = {"ms_per_step_min": None, "ms_per_step_max": None, "ms_per_step_by_rank": [None] * world, "physics_ms_by_rank": [None] * world,
+                             "slowest_rank": None, "allgather_median_ms_by_rank": per_rank, "note": "plumbing only: no environment was stepped"}
+            line["env"] = {"HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
             line["strong_scaling"] = {"total_envs": args.envs_per_gpu, "envs_per_gpu": args.envs_per_gpu // world, "value": None, "ms_per_step": None,
                                       "speedup_vs_one_gpu": None, "efficiency": None, "note": "plumbing only: no environment was stepped"}
         print(json.dumps(line))
@@ -399,15 +410,25 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     phys_ms, rast_ms, nlaunch = env.kernel_time_ms()
+    cost_stats = env.cost_stats() if (args.env in ("ship-ice", "maze") and hasattr(env, "cost_stats") and hasattr(env.L, "bp_get_cost_stats")) else None
     env.enable_timing(False)
     _check_errors(env)
     # clock the chip held over the timed region: shader-clock counter against the 100 MHz reference, both stamped on the device after every step
     clk1 = env.clock_stamps() if clk0 is not None else None
     # both stamps of the pair come from ONE XCD (the shader-clock counters of different XCDs are not synchronised): the XCD with the longest span
-    clock_hz, clock_xcd = env.clock_hz_between(clk0, clk1) if clk1 is not None else (None, None)
+    clock_hz, clock_xcd, clock_span_s = env.clock_hz_between(clk0, clk1, with_span=True) if clk1 is not None else (None, None, None)
+    clock_xcds = env.clock_per_xcd(clk0, clk1) if (clk1 is not None and hasattr(env, "clock_per_xcd")) else None
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=coll_device)
+    rank_ms = None
     if dist is not None:
+        # every rank's own wall time of the timed region (a straggler rank shows here; `value` uses the maximum)
+        mine = torch.tensor([dt / K * 1e3, phys_ms], dtype=torch.float64, device=coll_device)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        per = [float(t_[0].item()) for t_ in allt]
+        rank_ms = {"ms_per_step_min": min(per), "ms_per_step_max": max(per), "ms_per_step_by_rank": per,
+                   "physics_ms_by_rank": [float(t_[1].item()) for t_ in allt], "slowest_rank": int(np.argmax(per))}
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     tmax = float(tmax.item())
     # episode metrics cross GPUs once, after the timed region (RCCL all-gather over xGMI): per-rank counters and, for ship-ice, the
@@ -524,6 +545,12 @@ def main():
             "clock_mhz": (clock_hz / 1e6) if clock_hz else None,
             "clock_source": ("s_memtime / s_memrealtime stamps of XCD %d around the timed launches" % clock_xcd) if clock_hz else
                             "no stamp pair from one XCD: issue.frac uses the nominal 2.1 GHz",
+            "clock_span_ms": (clock_span_s * 1e3) if clock_span_s else None,
+            "clock_per_xcd": clock_xcds,
+            "clock_note": "shader-clock counter (s_memtime) over the 100 MHz reference counter (s_memrealtime) between the newest stamp before the timed region "
+                          "and the newest after it, on one XCD; the span is printed because a reading over a few launches is noisier than one over the whole "
+                          "region.  The guide's 2 400 MHz is the spec'd peak engine clock; this kernel draws little power (27 % of the lanes, no MFMA), and readings "
+                          "of 2.37-2.62 GHz have been seen on different boxes of the pool -- the counter ratio is what the chip ran at, not a nominal value",
             "kernel": (("k_physics_step_sched" + (("r" if resident > 0 else "p") if pairing and pairing.get("mode") == 2 else "l" if resident > 0 else "") + ("_maze" if args.env == "maze" else ""))
                        if sched_chunk > 0 else ("k_physics_step_maze" if args.env == "maze" else "k_physics_step")),
             "pairing": pairing,
@@ -549,6 +576,24 @@ def main():
                                                    "THIS kernel's time; nothing achieves it (SURVEY 8d asks for both accountings)"},
         }
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
+        if cost_stats is not None and len(cost_stats) and phys_ms > 0:
+            # the two lower bounds of a launch, from this run's own per-env cycle counts (bp_get_cost_stats) and this run's own clock
+            ck_ = clock_hz if clock_hz else 2.4e9
+            slots_ = int(env.L.bp_sched_resident(env.h)) if hasattr(env.L, "bp_sched_resident") else 0
+            slots_ = slots_ if slots_ > 0 else 2048
+            cs = cost_stats.astype(np.float64)
+            work_ms = float(np.mean(cs[:, 0])) / slots_ / ck_ * 1e3
+            chain_ms = float(np.mean(cs[:, 1])) / ck_ * 1e3
+            roof["ceiling"] = {
+                "heaviest_chain_ms": chain_ms, "work_over_slots_ms": work_ms,
+                "launch_over_chain": phys_ms / chain_ms if chain_ms > 0 else None, "launch_over_work": phys_ms / work_ms if work_ms > 0 else None,
+                "wave_slots": slots_, "launches": int(len(cost_stats)), "clock_used_mhz": ck_ / 1e6,
+                "heaviest_chain_ms_max": float(np.max(cs[:, 1])) / ck_ * 1e3,
+                "mean_env_busy_ms": float(np.mean(cs[:, 0])) / E / ck_ * 1e3,
+                "what": "per timed launch, from the wave cycles every env's step took (its tasks summed, queue waits excluded; k_cost_stats after each launch): "
+                        "work_over_slots = sum over the envs / wave slots of the device -- the launch if the slots were perfectly packed; heaviest_chain = the "
+                        "largest of them -- the busy time of the heaviest env as it ran (beside a second wave on its SIMD; alone it is ~1.2 x shorter, DESIGN.md 4s). "
+                        "Means over the timed launches, converted with the clock measured in this run; launch_over_* = physics_ms over each bound"}
         if pmc and phys_ms > 0:
             per = pmc.get("per_launch", {})
             insts = sum(per.get(k, 0.0) for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"))
@@ -599,6 +644,12 @@ def main():
             "substeps_per_s": value * env.params["steps"],
             "roofline": roof,
         }
+        if steady is not None:   # both accountings first-class: `value` = fresh episodes (steps W..W+K of a reset batch), `steady_state_value` = envs spread over all episode phases
+            out["steady_state_value"] = steady["value"]
+            out["value_note"] = ("value: the K timed steps right after reset + W warm-up steps (the contract's region); steady_state_value: the same batch after its envs were spread "
+                                 "uniformly over the phases of an episode -- what a long-running job sees.  Quote the steady-state number for sustained throughput")
+        if rank_ms is not None:
+            out["ranks"] = rank_ms
         if allgather is not None:
             out["allgather_ms"] = allgather["median_ms"]
             out["allgather"] = allgather
@@ -611,12 +662,13 @@ def main():
         if args.env in ("box", "area"):
             if hasattr(env, "stragglers") and hasattr(env.L, "bp_bd_get_stragglers"):
                 resumed, limited = env.stragglers()
+                bd_budget = int(env.L.bp_bd_budget(env.h)) if hasattr(env.L, "bp_bd_budget") else int(os.environ.get("BP_BD_BUDGET", "3000"))   # what the handle uses
                 out["straggler_env_steps"] = {"ran_into_STEP_LIMIT": limited, "finished_by_the_second_pass": resumed, "env_steps_total": E * (K + W),
-                                              "budget_sim_steps": int(os.environ.get("BP_BD_BUDGET", "3000")),
+                                              "budget_sim_steps": bd_budget,
                                               "what": "cumulative over warm-up and timed steps: env steps whose execute_robot_path / step_simulation_until_still loop hit the "
                                                       "reference's STEP_LIMIT (10 000 sim steps: single wavefronts that set the launch time), and env steps that ran past the "
                                                       "sim-step budget of the first pass and were finished by the second one beside the other envs' finish / map / observation kernels"}
-            if int(os.environ.get("BP_BD_BUDGET", "3000")) > 0:   # two-pass step: both groups' observation kernels run inside the physics window (other streams)
+            if (int(env.L.bp_bd_budget(env.h)) if hasattr(env.L, "bp_bd_budget") else int(os.environ.get("BP_BD_BUDGET", "3000"))) > 0:   # two-pass step: both groups' observation kernels run inside the physics window (other streams)
                 out["roofline"]["raster_kernel"].update(ms=None, achieved=None, frac=None,
                                                         note="two-pass step (DESIGN.md 4c): k_bd_observe runs once per group on two streams inside physics_ms; "
                                                              "3.8-3.9 ms for 4 096 envs in the kernel trace (profiles/r05_box/)")

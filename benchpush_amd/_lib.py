@@ -25,7 +25,8 @@ EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp
            "bp_obs_width", "bp_get_num_bodies", "bp_check_errors", "bp_kernel_time_ms", "bp_enable_timing", "bp_get_step_cycles", "bp_set_step_cost_hint", "bp_sched_chunk", "bp_sched_resident", "bp_sched_warnings", "bp_get_clock_stamps", "bp_last_error",
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
            "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2", "bp_debug_scramble_hints",
-           "bp_copy_rows_masked", "bp_pair_mode", "bp_get_pair_stats", "bp_bd_get_stragglers"]
+           "bp_copy_rows_masked", "bp_pair_mode", "bp_get_pair_stats", "bp_bd_get_stragglers",
+           "bp_device_shared", "bp_launch_policy_query", "bp_bd_budget", "bp_get_cost_stats"]
 
 
 class BpCostmapConfig(C.Structure):
@@ -138,6 +139,13 @@ def load():
     L.bp_bd_get_stragglers.argtypes = [vp, vp]
     L.bp_sched_chunk.restype = C.c_int32
     L.bp_sched_resident.restype = C.c_int32
+    if hasattr(L, "bp_device_shared"):    # ABI 11 (tools/ab_libs.sh loads older builds for same-box comparisons)
+        L.bp_device_shared.argtypes = [vp]
+        L.bp_device_shared.restype = C.c_int32
+        L.bp_bd_budget.argtypes = [vp]
+        L.bp_bd_budget.restype = C.c_int32
+        L.bp_launch_policy_query.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
+        L.bp_get_cost_stats.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
     if hasattr(L, "bp_get_clock_stamps"):
         L.bp_get_clock_stamps.argtypes = [vp, vp]
     if hasattr(L, "bp_sched_warnings"):   # absent from libraries of ABI 6 (tools/ab_bench.sh loads older builds for same-box comparisons)

@@ -6,11 +6,19 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
+#include <fcntl.h>
+#include <sys/file.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include "bp_host_bd.hpp"
 #include "bp_boxdelivery.hpp"
+#include "bp_policy.hpp"
 
 struct bp_handle {
     bp_config cfg;
@@ -30,6 +38,11 @@ struct bp_handle {
     int sched_persist = 0;          // > 0: the scheduled launch is k_physics_step_schedl with this many resident workgroups (BP_SCHED_PERSIST)
     void *pd_buf = nullptr;         // its launch constants in device memory (DevParams, DevPtrs)
     int sched_chunk = 0;            // > 0: k_physics_step_sched (preemptive scheduler, chunks of this many sub-steps) is the step kernel; BP_SCHED=0 turns it off
+    std::string dev_lock_key;       // non-empty: this handle holds a share of the per-device residency lock (resident_* below)
+    bool resident_auto = false;     // resident launches fall back to dispatcher-driven ones while another PROCESS uses the device (checked every few launches)
+    bool device_shared = false;     // result of the last check
+    unsigned launches = 0;
+    int num_cus = 0;                // multiProcessorCount of the handle's device
     hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel; ship-ice: the solo kernel of a pairing launch
     std::vector<hipStream_t> st_parts;   // ship-ice: the scheduled launch split over several hardware queues (BP_SCHED_PARTS)
     std::vector<hipEvent_t> ev_parts;
@@ -40,6 +53,7 @@ struct bp_handle {
     DevPtrs D;
     std::vector<void *> allocs;
     size_t lds_bytes = 0, obs_lds_bytes = 0;
+    size_t sched_lds = 0;           // dynamic LDS of the scheduler kernels: lds_bytes, or two half-wave images in pairing launches if that is more
     std::string err;
     std::vector<double> goal_raw; // maze: un-normalised wavefront map (info['goal_dt'])
     // box-delivery
@@ -54,7 +68,10 @@ struct bp_handle {
     bool timing = false;
     std::vector<hipEvent_t> ev; // triples: start, mid, stop
     size_t ev_used = 0;
+    unsigned long long *cost_ring = nullptr;   // [BP_COST_RING][2] per-launch (sum, max) of the envs' step cycles while timing is on (k_cost_stats)
+    int cost_n = 0;
 };
+#define BP_COST_RING 1024
 
 static int fail(bp_handle *h, int code, const std::string &msg)
 {
@@ -112,16 +129,80 @@ static unsigned sched_yield_mask(bool solo_launch, int steps, int chunk)
     const int first = (2 * steps + 5 * chunk - 1) / (5 * chunk);   // ceil(0.4 * steps / chunk)
     return first >= 32 ? 0u : (0xFFFFFFFFu << first);
 }
+// ---- is this process alone on its device? --------------------------------------------------------------------------------------------------------
+// A resident kernel holds every wave slot until its launch is over: two PROCESSES that share one GPU can then only alternate by saving and restoring
+// 2 048 wavefronts (80 ms per launch measured in a two-rank rehearsal on one device).  One rank per GPU -- the deployment this library is
+// built for -- never sees that, but nothing used to detect the other case.  Every handle with resident launches now holds a SHARED advisory lock on a
+// per-device file (keyed by the PCI bus id, so that HIP_VISIBLE_DEVICES renumbering does not matter), one descriptor per process and device; "alone" =
+// the lock can be converted to EXCLUSIVE without waiting.  Checked at load and every 64 launches (one flock call); while it fails the handle launches the
+// dispatcher-driven kernels (bit-identical results, BP_SCHED_PERSIST=0 behaviour) and goes back to resident ones when the other process has left.
+// BP_SCHED_PERSIST / BP_PAIR_RESIDENT set explicitly switch the detection off.  Best effort: processes that do not share a /tmp are not seen.
+struct ResidentLock { int fd = -1; int refs = 0; };
+static std::mutex g_res_mu;
+static std::map<std::string, ResidentLock> g_res_locks;
+
+static void resident_acquire(bp_handle *h)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus), h->device) != hipSuccess) return;
+    for (char *c = bus; *c; c++) if (*c == ':' || *c == '/' || *c == '.') *c = '_';
+    const char *dir = getenv("BP_LOCK_DIR");
+    const std::string key = std::string(dir ? dir : "/tmp") + "/benchpush_amd.resident." + bus + ".lock";
+    std::lock_guard<std::mutex> g(g_res_mu);
+    ResidentLock &L = g_res_locks[key];
+    if (L.fd < 0) {
+        const mode_t um = umask(0);
+        L.fd = open(key.c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+        umask(um);
+        if (L.fd < 0) { g_res_locks.erase(key); return; }   // no lock file: assume the device is ours
+        (void)flock(L.fd, LOCK_SH);
+    }
+    L.refs++;
+    h->dev_lock_key = key;
+}
+static void resident_release(bp_handle *h)
+{
+    if (h->dev_lock_key.empty()) return;
+    std::lock_guard<std::mutex> g(g_res_mu);
+    auto it = g_res_locks.find(h->dev_lock_key);
+    if (it != g_res_locks.end() && --it->second.refs <= 0) { close(it->second.fd); g_res_locks.erase(it); }
+    h->dev_lock_key.clear();
+}
+// true: some other process holds a share of this device's lock
+static bool resident_device_shared(bp_handle *h)
+{
+    if (h->dev_lock_key.empty()) return false;
+    std::lock_guard<std::mutex> g(g_res_mu);
+    auto it = g_res_locks.find(h->dev_lock_key);
+    if (it == g_res_locks.end()) return false;
+    if (flock(it->second.fd, LOCK_EX | LOCK_NB) == 0) { (void)flock(it->second.fd, LOCK_SH); return false; }
+    (void)flock(it->second.fd, LOCK_SH);   // a failed conversion may have dropped the shared lock: take it again
+    return true;
+}
+static int device_cus(bp_handle *h)
+{
+    if (h->num_cus <= 0) {
+        hipDeviceProp_t prop;
+        HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
+        h->num_cus = prop.multiProcessorCount;
+    }
+    return BP_OK;
+}
 // Resident wavefronts for a scheduled launch without pairing (k_physics_step_schedl*): one workgroup per wave slot of the device, BP_SCHED_PERSIST=0 goes back to
 // one workgroup per task from the hardware dispatcher, BP_SCHED_PERSIST=n > 1 launches n workgroups per slot (the surplus waits for the end and leaves)
 static int sched_persist_setup(bp_handle *h)
 {
-    hipDeviceProp_t prop;
-    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-    const int slots = prop.multiProcessorCount * 8;   // 4 SIMDs x 2 wavefronts of 256 VGPRs
+    int rc = device_cus(h);
+    if (rc) return rc;
+    const int slots = h->num_cus * 8;   // 4 SIMDs x 2 wavefronts of 256 VGPRs
     const int pers = getenv("BP_SCHED_PERSIST") ? atoi(getenv("BP_SCHED_PERSIST")) : 1;
     h->sched_persist = pers > 0 ? std::min(h->num_envs, slots * pers) : 0;
     if (h->sched_persist && !h->pd_buf) HIPCHK(h, hipMalloc(&h->pd_buf, sizeof(DevParams) + sizeof(DevPtrs)));
+    if (h->sched_persist && !getenv("BP_SCHED_PERSIST")) {
+        h->resident_auto = true;
+        resident_acquire(h);
+        h->device_shared = resident_device_shared(h);
+    }
     return BP_OK;
 }
 extern "C" {
@@ -200,6 +281,7 @@ int bp_destroy(bp_handle *h)
     if (!h) return BP_EINVAL;
     DevGuard _dg(h->device);
     if (h->st_aux) { hipStreamSynchronize(h->st_aux); hipStreamDestroy(h->st_aux); }
+    resident_release(h);
     if (h->pd_buf) hipFree(h->pd_buf);
     if (h->st_aux2) { hipStreamSynchronize(h->st_aux2); hipStreamDestroy(h->st_aux2); }
     for (hipStream_t s_ : h->st_parts) { hipStreamSynchronize(s_); hipStreamDestroy(s_); }
@@ -363,7 +445,11 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         // the light envs saves a tenth of the wave-instructions and moves the launch by 0 ... +2.5 % at 4 096 envs (profiles/r05_pair/), -2 % at 2 048 --
         // and the kernel that holds both step bodies runs the solo body 6 % slower -- so those handles keep the lean one-env-per-wavefront scheduler kernel.
         // BP_PAIR=0 / 1 / 2 overrides.
-        if (can_pair && h->num_envs >= 5120) h->pair_mode = 2;
+        if ((rc = device_cus(h))) return rc;
+        // regime boundaries in rounds of the device's wave slots, not in envs (bp_policy.hpp): pairing from 2.5 rounds, loose limits from 3.5, no scheduler
+        // without pairing above 4 -- 5 120 / 7 168 / 8 192 envs on the 256 CUs they were measured on
+        const BpLaunchPolicy pol = bp_launch_policy(h->num_envs, h->num_cus, can_pair, false);
+        h->pair_mode = pol.pair_mode;
         if (const char *evp = getenv("BP_PAIR")) h->pair_mode = can_pair ? atoi(evp) : 0;
         if (h->pair_mode == 1) {
             h->P.pair_mode = 1;
@@ -371,7 +457,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_pair, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * PL_HALF)));
         }
         // (with paired first tasks the scheduler is what lets an env leave its pair, so it stays on at every batch size: chunks of 100 sub-steps above 8192 envs)
-        int ch = (h->num_envs <= 8192) ? 40 : (h->pair_mode == 2 ? 100 : 0);
+        int ch = pol.chunk ? pol.chunk : (h->pair_mode == 2 ? 100 : 0);
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
@@ -424,7 +510,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 // step starts alone.  From ~7 000 envs the launch is throughput: every env starts in a pair and leaves it at 20 active arbiters or 40 work units per
                 // sub-step (same-box sweeps in profiles/r05_pair/ and profiles/r05_sched/pairing_limits_by_batch.txt; on the resident kernel, fresh / steady state:
                 // 6144 envs tight 294 k / 306 k against 294 k / 285 k, 7168 envs 300 k / 308 k against 314 k / 310 k, 8192 envs 303 k / 313 k against 323 k / 324 k).
-                const bool tight = h->num_envs < 7168;
+                const bool tight = pol.pair_mode == 2 ? pol.tight != 0 : 2LL * h->num_envs < (long long)BP_POLICY_LOOSE_FROM_HALF_ROUNDS * pol.wave_slots;   // (BP_PAIR=2 forced below the default regime)
                 h->P.pair_solo = std::min(h->num_envs, std::max(0, envint("BP_PAIR_SOLO", tight ? h->num_envs / 8 : 0)));
                 h->P.pp_max_keys = std::min(30, envint("BP_PP_KEYS", 26));
                 h->P.pp_max_slots = std::min(PP_NSLOT - 4, envint("BP_PP_SLOTS", 34));
@@ -434,23 +520,23 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
                 h->P.pp_rate = envint("BP_PP_RATE", tight ? 70 : 200);
                 h->P.pp_snake = envint("BP_PP_SNAKE", 0);
                 h->P.pp_heavy_only = envint("BP_PP_HEAVY_ONLY", 0);
-                h->lds_bytes = std::max(h->lds_bytes, (size_t)(2 * PL_HALF));
             }
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
-            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+            // (the per-env kernels k_physics_step / k_physics_reset keep lds_bytes, for which their attribute was set above)
+            h->sched_lds = h->pair_mode == 2 ? std::max(h->lds_bytes, (size_t)(2 * PL_HALF)) : h->lds_bytes;
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->sched_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->sched_lds));
+            HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->sched_lds));
             // (pairing launches have a resident kernel of their own, k_physics_step_schedr: the kernel that holds both step bodies INLINE lost 4 % at 8192 envs as a
             // resident loop -- 266 spilled VGPRs against 203)
             h->P.sq_ymask = sched_yield_mask(h->P.pair_mode != 2, h->P.steps, h->P.sq_chunk);
             if (h->P.pair_mode != 2 && h->P.sq_parts == 1) { int rc2 = sched_persist_setup(h); if (rc2) return rc2; }
             if (h->P.pair_mode == 2) {
-                HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+                HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedr, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->sched_lds));
                 const int pr = getenv("BP_PAIR_RESIDENT") ? atoi(getenv("BP_PAIR_RESIDENT")) : 1;   // 0: the dispatcher-driven pair of kernels
                 if (pr > 0) {
-                    hipDeviceProp_t prop;
-                    HIPCHK(h, hipGetDeviceProperties(&prop, h->device));
-                    h->pair_resident = std::min(h->num_envs, prop.multiProcessorCount * 8 * pr);
+                    h->pair_resident = std::min(h->num_envs, pol.wave_slots * pr);
                     if (!h->pd_buf) HIPCHK(h, hipMalloc(&h->pd_buf, sizeof(DevParams) + sizeof(DevPtrs)));
+                    if (!getenv("BP_PAIR_RESIDENT")) { h->resident_auto = true; resident_acquire(h); h->device_shared = resident_device_shared(h); }
                 }
             }
         }
@@ -460,7 +546,8 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
     h->maze8 = (h->P.env_kind == BP_ENV_MAZE);
     for (int v : h_nv) if (v > 8) h->maze8 = false;
     if (h->maze8) {
-        int ch = (h->num_envs <= 8192) ? 40 : 0;
+        if ((rc = device_cus(h))) return rc;
+        int ch = bp_launch_policy(h->num_envs, h->num_cus, false, true).chunk;
         if (const char *ev = getenv("BP_SCHED")) ch = atoi(ev);
         if (ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) { // preemptive scheduler, as for ship-ice
             h->sched_chunk = ch;
@@ -491,6 +578,7 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
 #ifdef BP_DEBUG_PATHS
             if (const char *ev2 = getenv("BP_SCHED_DEBUG_DROP")) h->P.sq_debug = atoi(ev2);
 #endif
+            h->sched_lds = h->lds_bytes;
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_sched_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             HIPCHK(h, hipFuncSetAttribute((const void *)k_physics_step_schedl_maze, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
             if ((rc = sched_persist_setup(h))) return rc;
@@ -801,25 +889,28 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
             // preemptive scheduler: one workgroup per (env, chunk) task (most leave at once: only parked envs need a second workgroup)
             hipLaunchKernelGGL(k_sched_init, dim3(16), dim3(1024), 0, st, h->P, h->D);
             HIPCHK(h, hipGetLastError());
-            if (h->sched_persist) {
+            // resident launches only while this process has the device to itself (see resident_device_shared)
+            if (h->resident_auto && (++h->launches & 63u) == 0) h->device_shared = resident_device_shared(h);
+            const bool resident_ok = !(h->resident_auto && h->device_shared);
+            if (h->sched_persist && resident_ok) {
                 // resident wavefronts: one workgroup per wave slot for the whole launch; the launch constants go through device memory (see sched_resident)
                 DevParams *Pg = (DevParams *)h->pd_buf;
                 DevPtrs *Dg = (DevPtrs *)((char *)h->pd_buf + sizeof(DevParams));
                 hipLaunchKernelGGL(k_store_params, dim3(1), dim3(64), 0, st, h->P, h->D, Pg, Dg);
                 HIPCHK(h, hipGetLastError());
                 if (h->maze8)
-                    hipLaunchKernelGGL(k_physics_step_schedl_maze, dim3(h->sched_persist), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
+                    hipLaunchKernelGGL(k_physics_step_schedl_maze, dim3(h->sched_persist), dim3(64), h->sched_lds, st, Pg, Dg, actions, reward, term, trunc, info);
                 else
-                    hipLaunchKernelGGL(k_physics_step_schedl, dim3(h->sched_persist), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
-            } else if (h->pair_resident > 0 && h->P.pair_mode == 2) {
+                    hipLaunchKernelGGL(k_physics_step_schedl, dim3(h->sched_persist), dim3(64), h->sched_lds, st, Pg, Dg, actions, reward, term, trunc, info);
+            } else if (h->pair_resident > 0 && h->P.pair_mode == 2 && resident_ok) {
                 // a pairing launch on resident wavefronts: one kernel, the two step bodies as functions of their own (k_physics_step_schedr)
                 DevParams *Pg = (DevParams *)h->pd_buf;
                 DevPtrs *Dg = (DevPtrs *)((char *)h->pd_buf + sizeof(DevParams));
                 hipLaunchKernelGGL(k_store_params, dim3(1), dim3(64), 0, st, h->P, h->D, Pg, Dg);
                 HIPCHK(h, hipGetLastError());
-                hipLaunchKernelGGL(k_physics_step_schedr, dim3(h->pair_resident), dim3(64), h->lds_bytes, st, Pg, Dg, actions, reward, term, trunc, info);
+                hipLaunchKernelGGL(k_physics_step_schedr, dim3(h->pair_resident), dim3(64), h->sched_lds, st, Pg, Dg, actions, reward, term, trunc, info);
             } else if (h->maze8)
-                hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+                hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->sched_lds, st, h->P, h->D, actions, reward, term, trunc, info);
             else if (h->P.pair_mode == 2) {
                 // (BP_PAIR_RESIDENT=0) a pairing launch as two kernels side by side: the envs that start alone on the lean solo code (second stream), everything else -- paired
                 // first tasks, the workgroups that serve the queues -- in the kernel that holds both step bodies
@@ -831,11 +922,11 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 if (h->P.pair_solo > 0) {
                     HIPCHK(h, hipEventRecord(h->ev_fork, st));
                     HIPCHK(h, hipStreamWaitEvent(h->st_aux, h->ev_fork, 0));
-                    hipLaunchKernelGGL(k_physics_step_sched, dim3(h->P.pair_solo), dim3(64), h->lds_bytes, h->st_aux, h->P, h->D, actions, reward, term, trunc, info);
+                    hipLaunchKernelGGL(k_physics_step_sched, dim3(h->P.pair_solo), dim3(64), h->sched_lds, h->st_aux, h->P, h->D, actions, reward, term, trunc, info);
                     HIPCHK(h, hipGetLastError());
                     HIPCHK(h, hipEventRecord(h->ev_join, h->st_aux));
                 }
-                hipLaunchKernelGGL(k_physics_step_schedp, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+                hipLaunchKernelGGL(k_physics_step_schedp, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->sched_lds, st, h->P, h->D, actions, reward, term, trunc, info);
                 HIPCHK(h, hipGetLastError());
                 if (h->P.pair_solo > 0) HIPCHK(h, hipStreamWaitEvent(st, h->ev_join, 0));
             } else if (h->P.sq_parts > 1) {
@@ -852,13 +943,13 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                     hipStream_t sk = (k == 0) ? st : h->st_parts[k - 1];
                     if (k > 0) HIPCHK(h, hipStreamWaitEvent(sk, h->ev_parts[7], 0));
                     const int grid = (h->num_envs * h->P.sq_levels + np - 1) / np;
-                    hipLaunchKernelGGL(k_physics_step_sched, dim3(grid), dim3(64), h->lds_bytes, sk, Pk, h->D, actions, reward, term, trunc, info);
+                    hipLaunchKernelGGL(k_physics_step_sched, dim3(grid), dim3(64), h->sched_lds, sk, Pk, h->D, actions, reward, term, trunc, info);
                     HIPCHK(h, hipGetLastError());
                     if (k > 0) { HIPCHK(h, hipEventRecord(h->ev_parts[k - 1], sk)); }
                 }
                 for (int k = 1; k < np; k++) HIPCHK(h, hipStreamWaitEvent(st, h->ev_parts[k - 1], 0));
             } else
-                hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->lds_bytes, st, h->P, h->D, actions, reward, term, trunc, info);
+                hipLaunchKernelGGL(k_physics_step_sched, dim3(h->num_envs * h->P.sq_levels), dim3(64), h->sched_lds, st, h->P, h->D, actions, reward, term, trunc, info);
             HIPCHK(h, hipGetLastError());
             // completion launch: workgroup b finishes the b-th env that the scheduled launch left unfinished (scheduler watchdog); normally all leave at once
 #ifdef BP_DEBUG_PATHS
@@ -872,9 +963,9 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                 DevParams PC = h->P;
                 PC.sq_mode = 1;
                 if (h->maze8)
-                    hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
+                    hipLaunchKernelGGL(k_physics_step_sched_maze, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->sched_lds, st, PC, h->D, actions, reward, term, trunc, info);
                 else
-                    hipLaunchKernelGGL(k_physics_step_sched, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->lds_bytes, st, PC, h->D, actions, reward, term, trunc, info);
+                    hipLaunchKernelGGL(k_physics_step_sched, dim3(std::min(h->num_envs, SQ_RESCUE)), dim3(64), h->sched_lds, st, PC, h->D, actions, reward, term, trunc, info);
             }
         }
         else if (mode == MODE_STEP && h->damp)
@@ -892,6 +983,11 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
         else
             hipLaunchKernelGGL(k_reset_copy, dim3(h->num_envs), dim3(256), 0, st, h->P, h->D, mask, info);
         HIPCHK(h, hipGetLastError());
+        if (mode == MODE_STEP && h->timing && h->cost_ring && h->cost_n < BP_COST_RING) {
+            hipLaunchKernelGGL(k_cost_stats, dim3(1), dim3(1024), 0, st, (const unsigned *)h->D.e_cost, h->num_envs, h->cost_ring, h->cost_n);
+            HIPCHK(h, hipGetLastError());
+            h->cost_n++;
+        }
         if (h->P.env_kind == BP_ENV_SHIP_ICE || h->P.env_kind == BP_ENV_MAZE) {
             hipLaunchKernelGGL(k_episode_metrics, dim3((h->num_envs + 255) / 256), dim3(256), 0, st, h->P, h->D, mode == MODE_STEP ? 0 : 1, mask);
             HIPCHK(h, hipGetLastError());
@@ -1492,7 +1588,21 @@ int bp_get_step_cycles(bp_handle *h, uint32_t *out_host)
 }
 
 int32_t bp_sched_chunk(bp_handle *h) { return h ? h->sched_chunk : 0; }
-int32_t bp_sched_resident(bp_handle *h) { return (h && h->sched_chunk > 0) ? (h->P.pair_mode == 2 ? h->pair_resident : h->sched_persist) : 0; }
+int32_t bp_sched_resident(bp_handle *h)
+{
+    if (!h || h->sched_chunk <= 0 || (h->resident_auto && h->device_shared)) return 0;
+    return h->P.pair_mode == 2 ? h->pair_resident : h->sched_persist;
+}
+int32_t bp_device_shared(bp_handle *h) { return (h && h->resident_auto && h->device_shared) ? 1 : 0; }
+int32_t bp_bd_budget(bp_handle *h) { return h ? h->bd_budget : 0; }
+int bp_launch_policy_query(int32_t num_envs, int32_t num_compute_units, int32_t can_pair, int32_t is_maze, int32_t *out8_host)
+{
+    if (!out8_host || num_envs <= 0 || num_compute_units <= 0) return BP_EINVAL;
+    const BpLaunchPolicy p = bp_launch_policy(num_envs, num_compute_units, can_pair != 0, is_maze != 0);
+    out8_host[0] = p.wave_slots; out8_host[1] = p.pair_mode; out8_host[2] = p.tight; out8_host[3] = p.pair_solo; out8_host[4] = p.chunk;
+    out8_host[5] = p.pp_max_act; out8_host[6] = p.pp_max_work; out8_host[7] = p.pp_rate;
+    return BP_OK;
+}
 
 int bp_get_clock_stamps(bp_handle *h, uint64_t *out16_host)
 {
@@ -1559,6 +1669,22 @@ int bp_enable_timing(bp_handle *h, int32_t on)
     if (!h) return BP_EINVAL;
     h->timing = on != 0;
     h->ev_used = 0;
+    if (on && h->loaded && h->P.env_kind != BP_ENV_BOX) {   // per-launch cost statistics ride along (bp_get_cost_stats)
+        BP_DEVICE(h);
+        if (!h->cost_ring) { int rc = dalloc(h, &h->cost_ring, (size_t)BP_COST_RING * 2); if (rc) return rc; }
+        h->cost_n = 0;
+    }
+    return BP_OK;
+}
+
+int bp_get_cost_stats(bp_handle *h, uint64_t *out_host, int32_t max_launches, int32_t *launches)
+{
+    if (!h || !launches || (max_launches > 0 && !out_host)) return BP_EINVAL;
+    BP_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    const int n = std::min(h->cost_n, std::max(0, (int)max_launches));
+    if (n > 0) HIPCHK(h, hipMemcpy(out_host, h->cost_ring, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    *launches = n;
     return BP_OK;
 }
 

@@ -206,7 +206,7 @@ __device__ __forceinline__ void store_state(const DevParams &P, const DevPtrs &D
 // ---- queues of the preemptive step scheduler (k_physics_step_sched below) -----------------------------------------------------------------
 // D.sq_ctr: per XCD x SQ_MAXLEV + 2 rows of two ints: rows 0 .. SQ_MAXLEV-1 = (head, tail) of the queue of envs that have completed that many
 // chunks; row SQ_MAXLEV of XCD x = (envs waiting in any of x's queues, -); XCD 0 additionally keeps the launch-wide counters in row SQ_MAXLEV + 1 =
-// (envs finished, first chunks started).  D.sq_items: [8][SQ_MAXLEV][sq_cap] env | priority class << 24, -1 = claimed but not yet written.
+// (envs finished, first chunks started).  D.sq_items: [16][SQ_MAXLEV][sq_cap] rings of env | priority class << 24, -1 = empty (claimed but not yet written, or taken).
 __device__ __forceinline__ int sq_xcc_id()
 {
 #if defined(__gfx942__) || defined(__gfx950__)
@@ -234,9 +234,13 @@ __device__ __forceinline__ int sq_pop_level(const DevParams &P, const DevPtrs &D
     while (h < sq_ld(ctr + 1)) {
         const int got = atomicCAS(ctr, h, h + 1);
         if (got == h) {
-            const int *slot = D.sq_items + ((size_t)xk * SQ_MAXLEV + l) * P.sq_cap + h;
+            // rows are rings of P.sq_cap entries: an env waits in at most one row at a time, so a row never holds more than num_envs = sq_cap live
+            // entries however often the same env is queued at the same level (pairing: a mate that leaves at an arbitrary sub-step, a pair declined
+            // at load, a paired wave that yields mid-chunk; longest-remaining-first keys repeat too).  The popper TAKES the entry (exchange with -1),
+            // the pusher waits for an empty one: entries of a row are interchangeable, so two poppers that meet on one slot a lap apart are harmless.
+            int *slot = D.sq_items + ((size_t)xk * SQ_MAXLEV + l) * P.sq_cap + (int)((unsigned)h % (unsigned)P.sq_cap);
             int e;
-            while ((e = sq_ld(slot)) < 0) __builtin_amdgcn_s_sleep(1); // the pusher has taken the index, the id is on its way
+            while ((e = atomicExch(slot, -1)) < 0) __builtin_amdgcn_s_sleep(1); // the pusher has taken the index, the id is on its way
             atomicSub(sq_waiting(D, xk), 1);
             return e;
         }
@@ -259,7 +263,12 @@ __device__ __forceinline__ int sq_pop(const DevParams &P, const DevPtrs &D, cons
 __device__ __forceinline__ void sq_push(const DevParams &P, const DevPtrs &D, const int xk, const int lev, const int item)
 {
     const int idx = atomicAdd(sq_row(D, xk, lev) + 1, 1);
-    __hip_atomic_store(D.sq_items + ((size_t)xk * SQ_MAXLEV + lev) * P.sq_cap + idx, item, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int *slot = D.sq_items + ((size_t)xk * SQ_MAXLEV + lev) * P.sq_cap + (int)((unsigned)idx % (unsigned)P.sq_cap);
+    // ring entry of a lap ago: empty unless its popper has claimed the index and not yet taken the id (see sq_pop_level) -- bounded wait, never past the row
+    for (int spin = 0; atomicCAS(slot, -1, item) != -1; spin++) {
+        if (spin > (1 << 22)) { atomicOr(&D.e_err[0], BP_ERR_SCHED_TIMEOUT); return; }   // cannot happen by the invariant above; never write anywhere else
+        __builtin_amdgcn_s_sleep(1);
+    }
     atomicAdd(sq_waiting(D, xk), 1);
 }
 // lane 0: is some env behind one that has completed `lev` chunks?  Envs whose first chunk has not been dispatched yet are behind everybody.
@@ -1245,6 +1254,24 @@ __global__ __launch_bounds__(1024) void k_make_order(const unsigned *__restrict_
     }
 }
 
+
+// Per-launch cost statistics for bench.py's two ceilings (bp_get_cost_stats; launched only while kernel timing is on): ring[slot] = (sum over the
+// envs of the wave cycles >> 8 their step took, the largest of them).  The sum over the device's wave slots bounds the launch from below when
+// the slots are perfectly packed, the maximum is the busy time of the heaviest env -- both in this run's own clock.
+__global__ __launch_bounds__(1024) void k_cost_stats(const unsigned *__restrict__ cost, int n, unsigned long long *__restrict__ ring, int slot)
+{
+    __shared__ unsigned long long ssum;
+    __shared__ unsigned smax;
+    if (threadIdx.x == 0) { ssum = 0ull; smax = 0u; }
+    __syncthreads();
+    unsigned long long s = 0ull;
+    unsigned mx = 0u;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const unsigned c = cost[i]; s += c; mx = max(mx, c); }
+    atomicAdd(&ssum, s);
+    atomicMax(&smax, mx);
+    __syncthreads();
+    if (threadIdx.x == 0) { ring[2 * slot] = ssum; ring[2 * slot + 1] = smax; }
+}
 
 // reset() from the settled per-trial template (ship_ice_env.py:223-249 is a pure function of the trial when
 // random_start is off): copy the template state of trial (global_env_id + episode) % T into the env.

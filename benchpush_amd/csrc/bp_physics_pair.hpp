@@ -1484,7 +1484,8 @@ __device__ BP_PAIR_TASK_INLINE int pair_task(const DevParams &P, const DevPtrs &
     if (W.hl == 0) {
         const d2 sp = gA(D.pxy, W.eo);
         const double sa = gA(D.ang, W.eo);
-        // solo-equivalent cost of the env for the next step's dispatch order: the wave's cycles until this half finished
+        // cost of the env for the next step's dispatch order: the wave's cycles of this task up to here -- written after the pair loop, so a half that finished
+        // first is charged its mate's remaining sub-steps too (an over-estimate that only moves it forward in the heaviest-first order) -- plus its earlier tasks'
         gA(D.e_cost, env) = (unsigned)((__builtin_amdgcn_s_memtime() - t_begin) >> 8) + (resumed ? gA(D.sq_carry, (size_t)env * 4 + 3) : 0u);
         const double total_work = gA(D.e_total_work, env) + work;
         gA(D.e_total_work, env) = total_work;

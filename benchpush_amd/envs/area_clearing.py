@@ -85,6 +85,8 @@ class AreaClearingEnv(Env):
         super().__init__()
         self._b = BatchedAreaClearingEnv(1, cfg=cfg, trials=trials, device=device, num_trials=num_trials)
         self.cfg = self._b.cfg
+        from ..obs_log import refuse_render_log_obs
+        refuse_render_log_obs(self.cfg, "area-clearing-v0")
         lay = env_layout(self.cfg)
         self.boundary_vertices, self.outer_boundary_vertices = lay.boundary, lay.outer_boundary
         self.walls = lay.walls if "walls" in lay else []

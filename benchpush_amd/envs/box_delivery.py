@@ -133,6 +133,8 @@ class BoxDeliveryEnv(Env):
         super().__init__()
         self._b = BatchedBoxDeliveryEnv(1, cfg=cfg, trials=trials, device=device, num_trials=num_trials)
         self.cfg = self._b.cfg
+        from ..obs_log import refuse_render_log_obs
+        refuse_render_log_obs(self.cfg, "box-delivery-v0")
         self.num_boxes = self._b.nbox
         lp = self._b.obs_shape[0]
         if self.cfg.agent.action_type == "velocity":     # box_delivery_env.py:157-162

@@ -175,7 +175,20 @@ class MazeNAMO(Env):
         info = {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)), "total_work": self.total_work[0],
                 "collision reward": float(it[5]), "scaled collision reward": float(it[6]), "dist increment reward": float(it[7]),
                 "trial_success": bool(it[8]), "obs": obstacles}
+        if self.cfg.log_obs:
+            self.log_observation()
         return self._observation(obstacles, it), reward, terminated, False, info
+
+    def log_observation(self):
+        """`cfg.log_obs` (maze_NAMO_env.py:482-483, 539-595): <cfg.output_dir>/t<episode_idx>/<t>_footprint, _movable_obs, _fixed_obs, _local_distance_map (the four
+        observation channels) and _distance_map (the global goal-distance map: wavefront distances over their maximum, walls and unreached cells 1.0)."""
+        from ..obs_log import dump_channels
+        o = self._b.obs[0].cpu().numpy()               # [footprint, boxes, walls, distance] (occupancy_map.py:142-202)
+        g = np.asarray(self._goal_dt, np.float64)
+        gn = g / g.max() if g.max() > 0 else g.copy()
+        gn[g == 0] = 1.0
+        return dump_channels(self.cfg.output_dir, self.episode_idx, self.t,
+                             {"footprint": o[0], "movable_obs": o[1], "fixed_obs": o[2], "distance_map": gn, "local_distance_map": o[3]})
 
     def update_path(self, new_path, scatter=False):
         self.path = new_path

@@ -271,6 +271,24 @@ class BatchedShipIceEnv(_BatchedBase):
         hz = (int(c1[best, 0]) - int(c0[best, 0])) / span * 1e8
         return (hz, best, span / 1e8) if with_span else (hz, best)
 
+    @staticmethod
+    def clock_per_xcd(c0, c1):
+        """Every XCD that was stamped before both readings: [{xcd, mhz, span_ms}] -- what `clock_hz_between` chose from (a short span reads noisier)."""
+        out = []
+        for x in range(8):
+            if c0[x, 1] == 0 or c1[x, 1] <= c0[x, 1]:
+                continue
+            span = int(c1[x, 1]) - int(c0[x, 1])
+            out.append({"xcd": x, "mhz": (int(c1[x, 0]) - int(c0[x, 0])) / span * 1e2, "span_ms": span / 1e5})
+        return out
+
+    def cost_stats(self, max_launches=1024):
+        """(sum, max) over the envs of the wave cycles each bp_step launch took since `enable_timing(True)`: uint64 [launches, 2], in shader cycles."""
+        out = np.zeros((max_launches, 2), np.uint64)
+        n = C.c_int32()
+        _lib.check(self.L, self.h, self.L.bp_get_cost_stats(self.h, out.ctypes.data_as(C.c_void_p), int(max_launches), C.byref(n)), "bp_get_cost_stats")
+        return out[: n.value] << np.uint64(8)
+
     def sched_warnings(self):
         """(watchdog events, envs finished by the completion launch) of the step scheduler since load: (0, 0) unless a scheduler fault occurred."""
         out = np.zeros(2, np.int32)
@@ -395,7 +413,21 @@ class ShipIceEnv(Env):
         info = {"state": (round(float(it[0]), 2), round(float(it[1]), 2), round(float(it[2]), 2)),
                 "total_work": self.total_work[0], "collision reward": float(it[5]), "scaled collision reward": float(it[6]),
                 "dist reward": float(it[7]), "trial_success": bool(it[8]), "obs": obstacles}
+        if self.cfg.log_obs:
+            self.log_observation()
         return self._observation(obstacles), reward, terminated, False, info
+
+    def log_observation(self):
+        """`cfg.log_obs` (ship_ice_env.py:352-353, 412-479): one PNG per observation channel under <cfg.output_dir>/t<episode_idx>/, named like the reference's
+        files -- egocentric: <t>_con (occupancy), _orientation, _edt, _footprint; planner mode: <t>_con (5x5 block-mean occupancy), _footprint (obs_log.py)."""
+        from ..obs_log import dump_channels
+        if self.cfg.egocentric_obs:
+            o = self._b.obs[0].cpu().numpy()           # channels [footprint, goal-line distance, orientation, occupancy] (ship_ice_env.py:392)
+            ch = {"con": o[3], "orientation": o[2], "edt": o[1], "footprint": o[0]}
+        else:
+            o = self._b.observe_global()[0].cpu().numpy()   # [occupancy, footprint] (ship_ice_env.py:405)
+            ch = {"con": o[0], "footprint": o[1]}
+        return dump_channels(self.cfg.output_dir, self.episode_idx, self.t, ch)
 
     def update_path(self, new_path):
         self.path = new_path

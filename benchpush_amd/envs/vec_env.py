@@ -12,8 +12,12 @@ What the adapter costs per step is what bounds a learner behind it, so it is bui
   done mask goes to the masked reset as a device tensor, the observations of the envs about to be reset are saved on the device by
   ``bp_copy_rows_masked`` (cost proportional to the rows that finished), the step counters are updated with tensor ops, and capacity flags are polled
   every ``check_every`` steps instead of on every batch with a finished episode.
-* ``to_numpy=True`` (SB3 itself): one non-blocking device-to-host copy per output into pre-allocated PINNED host buffers and ONE synchronisation per step;
-  the arrays returned are views of those buffers (valid until the next ``step_wait``, as with SB3's own ``DummyVecEnv`` buffers).
+* ``to_numpy=True`` (SB3 itself): one non-blocking device-to-host copy per output into pre-allocated PINNED host buffers and ONE synchronisation per step.
+  SB3's ``DummyVecEnv`` hands out a deep copy of its observation buffer, and its learners rely on that: ``collect_rollouts`` calls ``env.step()`` first and only
+  then stores ``self._last_obs`` -- the batch returned by the PREVIOUS step -- in the rollout / replay buffer.  A batch must therefore stay intact while the next
+  step is taken: the observation batch rotates through ``obs_buffers`` (default 2) pinned buffers, so the array returned by step t is rewritten by step
+  t + ``obs_buffers``, not before (``obs_buffers=0`` returns a fresh copy each step: no lifetime rule at all, one more host pass over the batch).  Rewards,
+  dones and the info block are small and always returned as copies.
 * ``infos`` is a lazy sequence in both modes: ``infos[i]`` builds env i's dict on first access from one host copy of the info block; only ``len``,
   indexing and iteration are offered, which is all SB3 uses.  4096 dicts are no longer built per step.
 """
@@ -38,7 +42,11 @@ class LazyInfos(collections.abc.Sequence):
 
     ``infos[i]`` holds the env's info scalars under the adapter's ``info_keys`` and, for an env whose episode ended in this step,
     ``'terminal_observation'`` (numpy, or a device tensor with ``to_numpy=False``) and ``'TimeLimit.truncated'``.  The first access copies the
-    [E, K] info block (and the done / truncation masks) to the host once; nothing is copied if nobody looks."""
+    [E, K] info block (and the done / truncation masks) to the host once; nothing is copied if nobody looks.
+
+    Lifetime: the info / done / truncation arrays handed to the constructor are private snapshots of the step (never rewritten).  The terminal observations
+    live in one of the adapter's two rotating device buffers: ``infos[i]`` must be read (materialised) before the step after the next one rewrites that
+    buffer -- SB3 reads them right after ``step_wait`` -- and in numpy mode the dict then holds its own host copy."""
 
     def __init__(self, keys, info, done, trunc, term_obs, to_numpy):
         self._keys, self._info, self._done, self._trunc, self._term_obs, self._to_numpy = keys, info, done, trunc, term_obs, to_numpy
@@ -79,7 +87,7 @@ class LazyInfos(collections.abc.Sequence):
 
 
 class BatchedVecEnv(_Base):
-    def __init__(self, batched_env, info_keys, max_episode_steps=None, to_numpy=True, action_shape=(), check_every=64):
+    def __init__(self, batched_env, info_keys, max_episode_steps=None, to_numpy=True, action_shape=(), check_every=64, obs_buffers=2):
         self.env = batched_env
         self.num_envs = batched_env.num_envs
         self.observation_space = spaces.Box(low=0, high=255, shape=batched_env.obs_shape, dtype=np.uint8)
@@ -93,7 +101,11 @@ class BatchedVecEnv(_Base):
         self._steps = torch.zeros(self.num_envs, dtype=torch.int64, device=dv)
         self._actions = None
         self._nstep = 0
-        self._term_obs = torch.zeros((self.num_envs,) + tuple(batched_env.obs_shape), dtype=torch.uint8, device=dv)   # rows of finished envs, saved before the reset
+        # rows of finished envs, saved before the reset; two buffers in rotation so that the infos of step t survive step t + 1
+        self._term_obs_ring = [torch.zeros((self.num_envs,) + tuple(batched_env.obs_shape), dtype=torch.uint8, device=dv) for _ in range(2)]
+        self._term_obs = self._term_obs_ring[0]
+        self.obs_buffers = int(obs_buffers)
+        self._obs_turn = 0
         self._host = None          # pinned host buffers of the to_numpy path, allocated on first use
         if _Base is not object:
             _Base.__init__(self, self.num_envs, self.observation_space, self.action_space)
@@ -103,9 +115,20 @@ class BatchedVecEnv(_Base):
         if self._host is None:
             E, e = self.num_envs, self.env
             pin = lambda shape, dt: torch.empty(shape, dtype=dt, pin_memory=True)   # noqa: E731
-            self._host = {"obs": pin((E,) + tuple(e.obs_shape), torch.uint8), "rew": pin((E,), torch.float64), "done": pin((E,), torch.bool),
+            self._host = {"obs": [pin((E,) + tuple(e.obs_shape), torch.uint8) for _ in range(max(1, self.obs_buffers))],
+                          "rew": pin((E,), torch.float64), "done": pin((E,), torch.bool),
                           "trunc": pin((E,), torch.bool), "info": pin(tuple(e.info.shape), torch.float64)}
         return self._host
+
+    def _next_obs_buffer(self):
+        """The pinned observation buffer of this step: the one whose batch was handed out longest ago."""
+        ring = self._host_buffers()["obs"]
+        buf = ring[self._obs_turn % len(ring)]
+        self._obs_turn += 1
+        return buf
+
+    def _obs_out(self, buf):
+        return buf.numpy().copy() if self.obs_buffers <= 0 else buf.numpy()
 
     def _save_terminal_rows(self, done_u8, obs):
         from .. import _lib
@@ -120,10 +143,10 @@ class BatchedVecEnv(_Base):
         self._steps.zero_()
         if not self.to_numpy:
             return obs
-        hb = self._host_buffers()
-        hb["obs"].copy_(obs, non_blocking=True)
+        buf = self._next_obs_buffer()
+        buf.copy_(obs, non_blocking=True)
         torch.cuda.current_stream(self.env.device).synchronize()
-        return hb["obs"].numpy()
+        return self._obs_out(buf)
 
     def step_async(self, actions):
         a = torch.as_tensor(np.asarray(actions, dtype=np.float32).reshape(self.num_envs, self._adim)) if not torch.is_tensor(actions) else actions
@@ -141,6 +164,7 @@ class BatchedVecEnv(_Base):
         done_u8 = done.to(torch.uint8)
         rew_out = rew.clone()                                           # the env's buffers are rewritten by the next step
         info_out = info.clone()
+        self._term_obs = self._term_obs_ring[self._nstep & 1]
         self._save_terminal_rows(done_u8, obs)                          # terminal observations, before the auto-reset overwrites those rows
         obs, _ = env.reset(done_u8)                                     # masked reset, device mask: a batch with no finished env launches two empty kernels
         self._steps.mul_((~done).to(torch.int64))
@@ -152,12 +176,15 @@ class BatchedVecEnv(_Base):
         if not self.to_numpy:
             return obs, rew_out, done, LazyInfos(self.info_keys, info_out, done, trunc_b, self._term_obs, False)
         hb = self._host_buffers()
-        hb["obs"].copy_(obs, non_blocking=True); hb["rew"].copy_(rew_out, non_blocking=True); hb["done"].copy_(done, non_blocking=True)
+        obuf = self._next_obs_buffer()
+        obuf.copy_(obs, non_blocking=True); hb["rew"].copy_(rew_out, non_blocking=True); hb["done"].copy_(done, non_blocking=True)
         hb["trunc"].copy_(trunc_b, non_blocking=True); hb["info"].copy_(info_out, non_blocking=True)
         torch.cuda.current_stream(env.device).synchronize()             # the one synchronisation of the step
-        # rewards and dones are small: returned as copies (SB3's DummyVecEnv copies its buffers too); the observation batch is a view of the pinned buffer
-        return (hb["obs"].numpy(), hb["rew"].numpy().copy(), hb["done"].numpy().copy(),
-                LazyInfos(self.info_keys, hb["info"].numpy(), hb["done"].numpy(), hb["trunc"].numpy(), self._term_obs, True))
+        # rewards, dones and the info block are small: returned as copies (SB3's DummyVecEnv copies its buffers too); the observation batch is a view of
+        # the pinned buffer of this turn, which the NEXT step does not touch (see the module docstring)
+        done_h = hb["done"].numpy().copy()
+        return (self._obs_out(obuf), hb["rew"].numpy().copy(), done_h,
+                LazyInfos(self.info_keys, hb["info"].numpy().copy(), done_h, hb["trunc"].numpy().copy(), self._term_obs, True))
 
     def step(self, actions):
         self.step_async(actions)

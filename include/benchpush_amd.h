@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define BP_ABI_VERSION 10
+#define BP_ABI_VERSION 11
 #define BP_MAXV 20          /* max hull vertices per shape (generate_polygon draws 10-20, polygon.py:53,72) */
 #define BP_MAX_SHIP_VERTS 32
 #define BP_OBS_C 4
@@ -231,6 +231,11 @@ int bp_check_errors(bp_handle *h, int32_t *out_host);
  * measured with HIP events on the launch stream (synchronises). */
 int bp_kernel_time_ms(bp_handle *h, double *physics_ms, double *raster_ms, int32_t *launches);
 int bp_enable_timing(bp_handle *h, int32_t on);
+/* Per-launch cost statistics of the bp_step calls since bp_enable_timing(h, 1) (ship-ice and maze handles, at most 1024 launches): out_host[k][0] = sum
+ * over the envs of the shader cycles >> 8 their wavefronts spent in launch k, out_host[k][1] = the largest of them.  With the clock of the run they give
+ * the two lower bounds of a launch -- all work packed into the device's wave slots, and the busy time of the heaviest env (bench.py roofline.ceiling).
+ * Host uint64 [max_launches][2]; *launches = rows written (synchronises).  ABI 11. */
+int bp_get_cost_stats(bp_handle *h, uint64_t *out_host, int32_t max_launches, int32_t *launches);
 /* shader cycles >> 8 each env's wavefront spent in the last bp_step (the dispatch-order hint): host uint32 [E] (synchronises) */
 int bp_get_step_cycles(bp_handle *h, uint32_t *out_host);
 /* sub-steps per chunk of the preemptive step scheduler (k_physics_step_sched: envs are parked at chunk boundaries while another one is further
@@ -240,9 +245,18 @@ int32_t bp_sched_chunk(bp_handle *h);
 /* Resident wavefronts of the step scheduler (k_physics_step_schedl: one workgroup per wave slot of the device takes task after task itself instead of one
  * workgroup per task from the hardware dispatcher; results are identical): the number of resident workgroups of a scheduled launch, 0 = one workgroup per
  * task.  Default: 8 x the device's compute units for scheduled launches (k_physics_step_schedr in pairing launches); environment variables BP_SCHED_PERSIST=0 /
- * BP_PAIR_RESIDENT=0 turn it off.  (ABI 10) */
+ * BP_PAIR_RESIDENT=0 turn it off.  (ABI 10)  A resident kernel holds every wave slot for the whole launch, which suits one process per GPU only: unless one of
+ * the two variables is set, the handle checks every 64 launches whether another PROCESS has a resident handle on the same device (advisory lock on
+ * $BP_LOCK_DIR|/tmp/benchpush_amd.resident.<pci bus id>.lock) and launches the dispatcher-driven kernels while that is so; the value returned is that of the
+ * launches being issued now (0 while the device is shared).  bp_device_shared: 1 while the last check saw another process.  (ABI 11) */
 int32_t bp_sched_resident(bp_handle *h);
-/* Two environments per wavefront (ship-ice handles with space.damping == 0 and at most 272 body slots; lanes 0..31 one env, lanes 32..63 another, results
+int32_t bp_device_shared(bp_handle *h);
+/* The load-time launch policy as a pure function (no GPU, no handle): regime boundaries are rounds of the device's wave slots (8 per compute unit), not env
+ * counts -- pairing from 2.5 rounds, loose pairing limits from 3.5, no scheduler without pairing above 4 (5 120 / 7 168 / 8 192 envs on the 256 CUs of an
+ * MI355X).  out8_host = wave slots, pair mode (0 / 2), tight limits (0 / 1), envs that start alone, sub-steps per scheduler chunk (0 = no scheduler), and
+ * the three leave limits (active arbiters, work units per sub-step, work rate).  (ABI 11) */
+int bp_launch_policy_query(int32_t num_envs, int32_t num_compute_units, int32_t can_pair, int32_t is_maze, int32_t *out8_host);
+/* Two environments per wavefront (ship-ice handles with space.damping == 0 and at most 448 body slots (PP_NBCAP); lanes 0..31 one env, lanes 32..63 another, results
  * identical): 0 = off, 1 = fixed pairs of the dispatch order for the whole step (test kernel), 2 = inside the step scheduler: the heaviest envs of the
  * dispatch order start alone, the others in pairs, and an env that outgrows the half-wave capacities or turns heavy is parked at a sub-step boundary and
  * resumed in a wavefront of its own.  Environment variable BP_PAIR=<mode> selects it at load time.  ABI 9. */
@@ -332,8 +346,9 @@ int bp_bd_get_maps(bp_handle *h, int32_t trial, int32_t *dims, uint8_t *cspace, 
 /* Two-pass step of box-delivery / area-clearing handles (ABI 9): out2_host[0] = env steps whose sim-step loop ran past the budget of the first pass and was
  * finished by the second one (beside the finish / map / observation kernels of all other envs), out2_host[1] = env steps whose execute_robot_path or
  * step_simulation_until_still loop ran into STEP_LIMIT (box_delivery_env.py:62,891-1023) -- cumulative since load (host uint32 [2], synchronises).
- * BP_BD_BUDGET=<sim steps> sets the budget of the first pass at load time (default 3000; 0 = one pass). */
+ * BP_BD_BUDGET=<sim steps> sets the budget of the first pass at load time (default 3000; 0 = one pass); bp_bd_budget returns the value the handle uses (ABI 11). */
 int bp_bd_get_stragglers(bp_handle *h, uint32_t *out2_host);
+int32_t bp_bd_budget(bp_handle *h);
 /* tests: per-env box bookkeeping, host buffers: alive uint8 [E][24], waypoints double [E][64][3], nwp int32 [E] (synchronises) */
 int bp_bd_get_state(bp_handle *h, uint8_t *alive, double *waypoints, int32_t *nwp);
 

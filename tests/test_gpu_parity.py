@@ -5,6 +5,7 @@ info scalars are compared with ==, contact counters and termination flags exactl
 """
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -600,6 +601,77 @@ def test_vec_env_device_mode_matches_numpy_mode_and_keeps_terminal_observations(
         rsteps[rdone] = 0
     assert ndone >= 8
     vd.close(); vn.close(); raw.close()
+
+
+def test_vec_env_previous_observation_survives_the_next_step():
+    """SB3's collect_rollouts takes `new_obs = env.step()` first and stores `self._last_obs` -- the batch of the PREVIOUS step -- afterwards
+    (DummyVecEnv deep-copies its buffer).  The numpy adapter must therefore never rewrite the batch of step t during step t + 1; infos kept for one
+    more step must not change either (ADVICE r5, high + low)."""
+    from benchpush_amd.envs.ship_ice import default_trials
+    from benchpush_amd.envs.vec_env import make_ship_ice_vec_env
+    trials = default_trials(0.1, 3, base_seed=2)
+    for bufs in (2, 0, 3):
+        venv = make_ship_ice_vec_env(6, cfg={"concentration": 0.1}, trials=trials)
+        venv.obs_buffers = bufs
+        venv.max_episode_steps = 5
+        last = venv.reset()
+        keep = last.copy()
+        prev_infos = prev_snapshot = None
+        for t in range(14):
+            a = np.zeros(6, np.float32)
+            a[0] = 1.0
+            obs, rew, done, infos = venv.step(a)
+            assert np.array_equal(last, keep), "the previous step's observation batch was rewritten by this step"
+            assert not np.shares_memory(obs, last)
+            if prev_infos is not None:                                    # the infos of step t - 1, read again after step t
+                now = [(prev_infos[e]["x"], prev_infos[e]["y"], prev_infos[e].get("TimeLimit.truncated")) for e in range(6)]
+                assert now == prev_snapshot[0]
+                for e, to in prev_snapshot[1].items():
+                    assert np.array_equal(prev_infos[e]["terminal_observation"], to)
+            snap = [(infos[e]["x"], infos[e]["y"], infos[e].get("TimeLimit.truncated")) for e in range(6)]
+            prev_infos, prev_snapshot = infos, (snap, {e: infos[e]["terminal_observation"].copy() for e in range(6) if done[e]})
+            rew0, done0 = rew.copy(), done.copy()
+            last, keep = obs, obs.copy()
+        obs, rew, done, infos = venv.step(np.zeros(6, np.float32))
+        assert np.array_equal(rew0, rew0.copy()) and rew is not rew0 and not np.shares_memory(done, done0)
+        venv.close()
+
+
+def test_log_obs_dumps_the_observation_channels(tmp_path):
+    """cfg.log_obs on the single-env adapters: the files the reference's log_observation writes (names, directory per episode, vertical flip) hold the
+    channels of the observation step() returned."""
+    import benchpush_amd
+    from benchpush_amd.envs.ship_ice import default_trials
+    from benchpush_amd.obs_log import read_gray_png
+    trials = default_trials(0.1, 2, base_seed=2)
+    out = str(tmp_path / "logs")
+    env = benchpush_amd.make("ship-ice-v0", cfg={"concentration": 0.1, "log_obs": True, "output_dir": out}, trials=trials).unwrapped
+    env.reset()
+    obs, _, _, _, _ = env.step(0.3)
+    obs2, _, _, _, _ = env.step(-0.2)
+    for t, o in ((1, obs), (2, obs2)):
+        for name, c in (("footprint", 0), ("edt", 1), ("orientation", 2), ("con", 3)):
+            assert np.array_equal(read_gray_png(os.path.join(out, "t0", "%d_%s.png" % (t, name))), o[c][::-1])
+    env.reset()
+    env.step(0.0)
+    assert os.path.exists(os.path.join(out, "t1", "1_con.png")) and not os.path.exists(os.path.join(out, "t1", "2_con.png"))
+    env.close()
+    genv = benchpush_amd.make("ship-ice-v0", cfg={"concentration": 0.1, "log_obs": True, "output_dir": out + "_g", "egocentric_obs": False}, trials=trials).unwrapped
+    genv.reset()
+    gobs, _, _, _, _ = genv.step(0.1)
+    assert np.array_equal(read_gray_png(os.path.join(out + "_g", "t0", "1_con.png")), gobs[0][::-1])
+    assert np.array_equal(read_gray_png(os.path.join(out + "_g", "t0", "1_footprint.png")), gobs[1][::-1])
+    genv.close()
+    menv = benchpush_amd.make("maze-NAMO-v0", cfg={"log_obs": True, "output_dir": out + "_m"}).unwrapped
+    menv.reset()
+    mobs, _, _, _, _ = menv.step(0.2)
+    for name, c in (("footprint", 0), ("movable_obs", 1), ("fixed_obs", 2), ("local_distance_map", 3)):
+        assert np.array_equal(read_gray_png(os.path.join(out + "_m", "t0", "1_%s.png" % name)), mobs[c][::-1])
+    g = read_gray_png(os.path.join(out + "_m", "t0", "1_distance_map.png"))
+    assert g.shape == menv._goal_dt.shape and g.max() == 255
+    menv.close()
+    with pytest.raises(NotImplementedError):
+        benchpush_amd.make("box-delivery-v0", cfg={"render": {"log_obs": True}})
 
 
 def test_global_planner_observation_matches_oracle():

@@ -21,8 +21,46 @@ def test_cabi_library_exports_every_declared_symbol():
     assert {"bp_create", "bp_step", "bp_reset", "bp_load_scenarios", "bp_get_world_polys"} <= declared
     for name in declared:
         assert hasattr(L, name), name
-    assert L.bp_abi_version() == 10
+    assert L.bp_abi_version() == 11
     assert set(_lib.EXPORTS) <= declared | {"bp_debug_trace"}
+
+
+def _policy(L, envs, cus, can_pair=1, maze=0):
+    out = (C.c_int32 * 8)()
+    assert L.bp_launch_policy_query(envs, cus, can_pair, maze, out) == 0
+    return dict(zip(("slots", "pair_mode", "tight", "pair_solo", "chunk", "act", "work", "rate"), list(out)))
+
+
+def test_launch_policy_is_stated_in_rounds_of_the_wave_slots():
+    """the regime boundaries of a ship-ice / maze handle (pairing, tight limits, scheduler chunk) are multiples of the device's
+    wave slots (8 per CU), not the env counts they were tuned at.  256 CUs (MI355X SPX) must give exactly the measured thresholds 5120 / 7168 / 8192;
+    304 CUs (MI300X) and 32 CUs (one CPX partition) the same boundaries in rounds."""
+    from benchpush_amd import _lib
+    L = _lib.load()
+    # 256 CUs: the thresholds the defaults were measured at
+    assert _policy(L, 4096, 256) == dict(slots=2048, pair_mode=0, tight=0, pair_solo=0, chunk=40, act=20, work=40, rate=200)
+    assert _policy(L, 5119, 256)["pair_mode"] == 0 and _policy(L, 5120, 256)["pair_mode"] == 2
+    p = _policy(L, 6144, 256)
+    assert p["tight"] == 1 and p["pair_solo"] == 768 and (p["act"], p["work"], p["rate"]) == (16, 9, 70) and p["chunk"] == 40
+    assert _policy(L, 7167, 256)["tight"] == 1 and _policy(L, 7168, 256)["tight"] == 0 and _policy(L, 7168, 256)["pair_solo"] == 0
+    assert _policy(L, 8192, 256)["chunk"] == 40 and _policy(L, 8193, 256)["chunk"] == 100 and _policy(L, 16384, 256)["chunk"] == 100
+    assert _policy(L, 16384, 256, can_pair=0) == dict(slots=2048, pair_mode=0, tight=0, pair_solo=0, chunk=0, act=20, work=40, rate=200)
+    # maze handles never pair; scheduler up to four rounds
+    assert _policy(L, 8192, 256, maze=1)["chunk"] == 40 and _policy(L, 8193, 256, maze=1)["chunk"] == 0 and _policy(L, 8193, 256, maze=1)["pair_mode"] == 0
+    # other CU counts: the same boundaries in rounds (2.5 / 3.5 / 4 rounds of 8 x CUs)
+    for cus in (304, 32, 64, 228):
+        slots = 8 * cus
+        assert _policy(L, 1, cus)["slots"] == slots
+        e_pair, e_loose, e_sched = (5 * slots + 1) // 2, (7 * slots + 1) // 2, 4 * slots
+        assert _policy(L, e_pair - 1, cus)["pair_mode"] == 0 and _policy(L, e_pair, cus)["pair_mode"] == 2 and _policy(L, e_pair, cus)["tight"] == 1
+        assert _policy(L, e_loose - 1, cus)["tight"] == 1 and _policy(L, e_loose, cus)["tight"] == 0
+        assert _policy(L, e_sched, cus, can_pair=0)["chunk"] == 40 and _policy(L, e_sched + 1, cus, can_pair=0)["chunk"] == 0
+        assert _policy(L, e_sched + 1, cus)["chunk"] == 100
+    # a CPX partition (32 CUs = 256 slots) with the headline batch is deep in the throughput regime; a 304-CU device is not yet pairing at 6000
+    assert _policy(L, 4096, 32)["pair_mode"] == 2 and _policy(L, 4096, 32)["tight"] == 0 and _policy(L, 4096, 32)["chunk"] == 100
+    assert _policy(L, 6000, 304)["pair_mode"] == 0 and _policy(L, 6080, 304)["pair_mode"] == 2
+    out = (C.c_int32 * 8)()
+    assert L.bp_launch_policy_query(0, 256, 1, 0, out) == -1 and L.bp_launch_policy_query(16, 0, 1, 0, out) == -1 and L.bp_launch_policy_query(16, 8, 1, 0, None) == -1
 
 
 def test_header_is_plain_c_and_cxx():
@@ -223,6 +261,21 @@ def test_bench_gpus_2_really_starts_two_ranks():
     assert d["allgather_ms"] > 0 and d["allgather"]["reps"] == 20 and d["allgather"]["payload_bytes_per_rank"] == 4096 * 7 * 8
     assert d["strong_scaling"]["total_envs"] == 4096 and d["strong_scaling"]["envs_per_gpu"] == 2048
     assert {"value", "ms_per_step", "speedup_vs_one_gpu", "efficiency"} <= set(d["strong_scaling"])
+    # per-rank times (straggler visibility) in every N > 1 line, and the dmabuf IPC setting in the ranks' environment whoever launched them
+    assert {"ms_per_step_min", "ms_per_step_max", "ms_per_step_by_rank", "physics_ms_by_rank", "slowest_rank"} <= set(d["ranks"])
+    assert len(d["ranks"]["ms_per_step_by_rank"]) == 2 and len(d["ranks"]["allgather_median_ms_by_rank"]) == 2
+    assert d["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_sets_the_ipc_mode_under_an_external_launcher():
+    """A rank started by somebody else's torchrun (WORLD_SIZE already set, HSA_ENABLE_IPC_MODE_LEGACY absent) must still get dmabuf IPC: bench.py sets it at
+    import, before anything can touch the GPU."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    env.pop("HSA_ENABLE_IPC_MODE_LEGACY", None)
+    code = "import os, runpy, sys; sys.argv = ['bench.py', '--plumbing-only']; runpy.run_path(%r, run_name='bench_import'); print('IPC=' + os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % os.path.join(ROOT, "bench.py")
+    p = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert "IPC=0" in p.stdout.decode()
 
 
 def test_bench_refuses_more_ranks_than_gpus():
@@ -253,3 +306,28 @@ def test_dispatcher_model_reproduces_the_measured_launch_times():
         assert abs(rule - measured) < 0.03, (heavy_every, rule)
         assert abs(m.greedy(ds, 2048) - measured) > 1.0                                   # any free slot: far too fast
         assert abs(max(m.greedy(ds[x::32], 64) for x in range(32)) - measured) > 0.5      # static engines without the in-order wait
+
+
+def test_log_obs_png_codec_and_render_log_obs_refusal(tmp_path):
+    """cfg.log_obs: the dump writes <output_dir>/t<episode>/<t>_<name>.png per channel, flipped vertically like the reference's
+    np.flip(axis=0) (ship_ice_env.py:412-479); box-delivery / area-clearing log from render(), which is out of scope -> refused, not ignored."""
+    from benchpush_amd.config import default_cfg, merge_user_cfg
+    from benchpush_amd.obs_log import dump_channels, read_gray_png, refuse_render_log_obs, write_gray_png
+    rng = np.random.default_rng(0)
+    a = rng.integers(0, 256, (37, 53), dtype=np.uint8)
+    f = rng.random((20, 11))
+    write_gray_png(str(tmp_path / "a.png"), a)
+    assert np.array_equal(read_gray_png(str(tmp_path / "a.png")), a)
+    paths = dump_channels(str(tmp_path / "logs"), 3, 17, {"con": a, "edt": f})
+    assert [os.path.relpath(p, str(tmp_path)) for p in paths] == ["logs/t3/17_con.png", "logs/t3/17_edt.png"]
+    assert np.array_equal(read_gray_png(paths[0]), a[::-1])
+    assert np.array_equal(read_gray_png(paths[1]), (f[::-1] * 255).astype(np.uint8))
+    with pytest.raises(ValueError):
+        dump_channels("", 0, 0, {"con": a})
+    for name in ("box_delivery", "area_clearing"):
+        cfg = default_cfg(name)
+        refuse_render_log_obs(cfg, name)                                       # shipped default: log_obs false
+        with pytest.raises(NotImplementedError):
+            refuse_render_log_obs(merge_user_cfg(default_cfg(name), {"render": {"log_obs": True}}), name)
+    for name in ("ship_ice", "maze_namo"):
+        assert default_cfg(name).log_obs is False
