@@ -194,7 +194,7 @@ static int sched_persist_setup(bp_handle *h)
 {
     int rc = device_cus(h);
     if (rc) return rc;
-    const int slots = h->num_cus * 8;   // 4 SIMDs x 2 wavefronts of 256 VGPRs
+    const int slots = h->num_cus * 4 * (h->P.env_kind == BP_ENV_SHIP_ICE ? BP_SCHED_WAVES : 2);   // 4 SIMDs x 2 wavefronts of 256 VGPRs (x 3 in the occupancy experiment)
     const int pers = getenv("BP_SCHED_PERSIST") ? atoi(getenv("BP_SCHED_PERSIST")) : 1;
     h->sched_persist = pers > 0 ? std::min(h->num_envs, slots * pers) : 0;
     if (h->sched_persist && !h->pd_buf) HIPCHK(h, hipMalloc(&h->pd_buf, sizeof(DevParams) + sizeof(DevPtrs)));

@@ -1039,7 +1039,10 @@ __device__ __forceinline__ void sched_resident(const DevParams *Pg, const DevPtr
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(64, 2) void k_physics_step_schedl(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
+#ifndef BP_SCHED_WAVES
+#define BP_SCHED_WAVES 2   // wavefronts per SIMD the scheduled ship-ice kernels are compiled for (3: the occupancy experiment, tools/build_variant.sh w3)
+#endif
+__global__ __launch_bounds__(64, BP_SCHED_WAVES) void k_physics_step_schedl(const DevParams *Pg, const DevPtrs *Dg, const double *__restrict__ actions,
                                                              double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                              unsigned char *__restrict__ truncated, double *__restrict__ info)
 {
@@ -1150,9 +1153,6 @@ __global__ void k_store_params(const DevParams P, const DevPtrs D, DevParams *Pg
     for (unsigned i = threadIdx.x; i < sizeof(DevParams) / 4; i += blockDim.x) ((unsigned *)Pg)[i] = sp[i];
     for (unsigned i = threadIdx.x; i < sizeof(DevPtrs) / 4; i += blockDim.x) ((unsigned *)Dg)[i] = sd[i];
 }
-#ifndef BP_SCHED_WAVES
-#define BP_SCHED_WAVES 2
-#endif
 __global__ __launch_bounds__(64, BP_SCHED_WAVES) void k_physics_step_sched(const DevParams P, const DevPtrs D, const double *__restrict__ actions,
                                                            double *__restrict__ reward, unsigned char *__restrict__ terminated,
                                                            unsigned char *__restrict__ truncated, double *__restrict__ info)
