@@ -663,7 +663,8 @@ def main():
             if hasattr(env, "stragglers") and hasattr(env.L, "bp_bd_get_stragglers"):
                 resumed, limited = env.stragglers()
                 bd_budget = int(env.L.bp_bd_budget(env.h)) if hasattr(env.L, "bp_bd_budget") else int(os.environ.get("BP_BD_BUDGET", "3000"))   # what the handle uses
-                out["straggler_env_steps"] = {"ran_into_STEP_LIMIT": limited, "finished_by_the_second_pass": resumed, "env_steps_total": E * (K + W),
+                skips = env.cycle_skips() if hasattr(env.L, "bp_bd_get_cycle_skips") else (None, None)
+                out["straggler_env_steps"] = {"ran_into_STEP_LIMIT": limited, "recurrences_found_in_execute_robot_path": skips[0], "sim_steps_skipped_by_them": skips[1], "finished_by_the_second_pass": resumed, "env_steps_total": E * (K + W),
                                               "budget_sim_steps": bd_budget,
                                               "what": "cumulative over warm-up and timed steps: env steps whose execute_robot_path / step_simulation_until_still loop hit the "
                                                       "reference's STEP_LIMIT (10 000 sim steps: single wavefronts that set the launch time), and env steps that ran past the "
@@ -673,7 +674,11 @@ def main():
                                                         note="two-pass step (DESIGN.md 4c): k_bd_observe runs once per group on two streams inside physics_ms; "
                                                              "3.8-3.9 ms for 4 096 envs in the kernel trace (profiles/r05_box/)")
             out["roofline"]["kernel"] = "k_bd_physics (+ k_bd_plan / k_bd_finish / k_bd_robot_map / k_bd_observe in physics_ms)"
-            out["roofline"]["note"] = "persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c)"
+            out["roofline"]["note"] = ("persistent per-env wavefront over ~1000 sim steps; latency-bound like k_physics_step (DESIGN.md 4c).  A launch lasts as long as its slowest env: "
+                                       "an env step whose step_simulation_until_still loop runs the reference's full 10 001 sim steps (box_delivery_env.py:990-1023; boxes that keep "
+                                       "jittering against a wall, 8-9e8 wave cycles = 350-400 ms for ONE wavefront, no exact shortcut: the states never recur) sets 4 of 13 launches of "
+                                       "this workload and two thirds of its time -- that is the reference's own loop, not kernel overhead.  The other kind -- execute_robot_path into "
+                                       "STEP_LIMIT with a robot that pushes against a wall -- recurs bit for bit and is skipped exactly (straggler_env_steps.sim_steps_skipped_by_them)")
             out["substeps_per_s"] = None
         if world == 1 and not args.no_cpu_baseline and args.env == "ship-ice":
             out["cpu_baseline"] = cpu_baseline(env, trials)

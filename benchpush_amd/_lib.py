@@ -26,7 +26,7 @@ EXPORTS = ["bp_abi_version", "bp_create", "bp_destroy", "bp_load_scenarios", "bp
            "bp_bd_create", "bp_bd_load", "bp_bd_sizeof_config", "bp_bd_get_maps", "bp_bd_get_state",
            "bp_get_episode_metrics", "bp_get_episode_history", "bp_start_uniform", "bp_debug_round2", "bp_debug_scramble_hints",
            "bp_copy_rows_masked", "bp_pair_mode", "bp_get_pair_stats", "bp_bd_get_stragglers",
-           "bp_device_shared", "bp_launch_policy_query", "bp_bd_budget", "bp_get_cost_stats"]
+           "bp_device_shared", "bp_launch_policy_query", "bp_bd_budget", "bp_get_cost_stats", "bp_bd_get_cycle_skips"]
 
 
 class BpCostmapConfig(C.Structure):
@@ -146,6 +146,8 @@ def load():
         L.bp_bd_budget.restype = C.c_int32
         L.bp_launch_policy_query.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp]
         L.bp_get_cost_stats.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+    if hasattr(L, "bp_bd_get_cycle_skips"):
+        L.bp_bd_get_cycle_skips.argtypes = [vp, vp]
     if hasattr(L, "bp_get_clock_stamps"):
         L.bp_get_clock_stamps.argtypes = [vp, vp]
     if hasattr(L, "bp_sched_warnings"):   # absent from libraries of ABI 6 (tools/ab_bench.sh loads older builds for same-box comparisons)

@@ -38,6 +38,8 @@ struct BdParams {
     // The envs that finish in pass 0 -- all but the handful that run into the reference's 10 001-step loops -- go through the finish / robot-map / observe
     // kernels while pass 1 is still running on another stream; `sel_want` tells a tail kernel which of the two groups it serves (-1: every env).
     int budget, pass, sel_want;
+    int resume_sel;                     // second pass: 0 = every unfinished env, 1 = those that stopped inside execute_robot_path, 2 = the others (until-still loop)
+    int cycle_skip;                     // > 0: the second pass of the two-pass step looks for exact recurrences of the robot's state in execute_robot_path once a path has run this many sim steps, and skips whole periods (bd_physics_body<DAMP, CYC>; BP_BD_CYCLE=0 turns it off)
 };
 struct BdPtrs {
     // per map (trial -> map index): window rasters
@@ -65,7 +67,7 @@ struct BdPtrs {
     unsigned char *unfin;           // [E] 1 = the env's sim-step loop hit the budget of pass 0 (its loop state is in rs_i / rs_d) -- written by pass 0 for every env
     int *rs_i;                      // [E][16] phase, wi, path0, done_turning, dp_valid, sp_one, sim_steps, kcount, have_prev, still_done, total_sub, robot_hit, cycles >> 8
     double *rs_d;                   // [E][4 + 2 * 64] the controller's doubles (L.ctl) and the until-still loop's previous positions (one d2 per lane)
-    unsigned *straggler;            // [2] cumulative: envs resumed by pass 1, envs whose loops ran into STEP_LIMIT
+    unsigned *straggler;            // [4] cumulative: envs resumed by pass 1, envs whose loops ran into STEP_LIMIT, recurrences found in execute_robot_path, sim steps they skipped
     float *dist;                    // [E][SH*SW] spfa scratch
     float *rmap;                    // [E][SH*SW] spfa map from the robot (observation channel 2)
     const d2 *goals;                // [ngoal] area-clearing goal points
@@ -557,16 +559,69 @@ __device__ __forceinline__ d2 bd_local_to_world(const EnvCtx &E, int i, int q)
     return mk2((r.x * lv.x + (-r.y) * lv.y) + tx, (r.y * lv.x + r.x * lv.y) + ty);
 }
 
+// ---- exact recurrences of execute_robot_path (bd_physics_body) -------------------------------------------------------------------------------------------
+// The robot's state -- per kinematic part: position, angle, (cos, sin), velocity, (w, w_bias), bias velocity, velocity slot; once: the controller's doubles and
+// the packed loop / sub-step words handed in -- is compared with the snapshot (store == 0: returns 1 if every value is bit for bit the snapshot's) or written
+// to it (store != 0).  Only the kernel of the second pass of the two-pass step holds this code (bd_physics_body<DAMP, CYC = true>, k_bd_physics_resume): with it
+// inline the sim step of k_bd_physics spilled 53 VGPRs instead of 11 and ran 5 % slower for every env, as a non-inlined function 41.
+__device__ __forceinline__ int bd_cycle_visit(unsigned long long *snap, const d2 *sp, const d2 *sv, const d2 *sw, const d2 *sb, const unsigned char *slot_of,
+                                                        const double *ctl, const d2 *rot, const double *ang, const int nkin, const int store,
+                                                        const unsigned long long w5, const unsigned long long w6, const unsigned long long w7, const unsigned long long w8,
+                                                        const unsigned long long w9, const double ke, const double imp, const double curr_dt)
+{
+    const int lane = lane_id();
+    bool same = true;
+    lds_sync();
+    if (lane <= nkin) {
+        unsigned long long *row = snap + lane * BP_SNAP_COLS;
+        auto item = [&](const int k, const unsigned long long v) { if (store) row[k] = v; else same = same && (row[k] == v); };
+        auto itemd = [&](const int k, const double v) { item(k, __builtin_bit_cast(unsigned long long, v)); };
+        if (lane < nkin) {          // part `lane` of the kinematic robot (bodies [0, nkin) hold the velocity slots [0, nkin))
+            const d2 p_ = sp[lane]; itemd(0, p_.x); itemd(1, p_.y);
+            itemd(2, ang[lane]);
+            const d2 r_ = rot[lane]; itemd(3, r_.x); itemd(4, r_.y);
+            const d2 v_ = sv[lane]; itemd(5, v_.x); itemd(6, v_.y);
+            const d2 w_ = sw[lane]; itemd(7, w_.x); itemd(8, w_.y);
+            const d2 b_ = sb[lane]; itemd(9, b_.x); itemd(10, b_.y);
+            item(11, (unsigned long long)slot_of[lane]);
+        } else {                    // the controller and whatever else of the sub-step state a sim step can read or change
+            itemd(0, ctl[0]); itemd(1, ctl[1]); itemd(2, ctl[3]); itemd(3, ke); itemd(4, imp);
+            item(5, w5); item(6, w6); item(7, w7); item(8, w8); item(9, w9);
+            itemd(10, curr_dt);
+        }
+    }
+    lds_sync();
+    return (ballot(!same) == 0ull) ? 1 : 0;
+}
+// the counters of `skip` skipped iterations that live in LDS / HBM: the "moved in the sub-step that just ended" stamps of the robot's parts, the advanced
+// path length (TargetCourse.advance of every skipped iteration, added one by one so that it rounds like the loop's own additions) and the statistics
+__device__ __forceinline__ void bd_cycle_skip(unsigned *mvs, double *ctl, const int nkin, const unsigned stamp, const int skip, const double target_speed,
+                                                        const double ctrl_dt, unsigned *stats)
+{
+    const int lane = lane_id();
+    lds_sync();
+    if (lane < nkin) mvs[lane] = stamp;
+    if (lane == 0) {
+        double al = ctl[2];
+        for (int k = 0; k < skip; k++) al = al + target_speed * ctrl_dt;
+        ctl[2] = al;
+        if (stats != nullptr) { atomicAdd(&stats[2], 1u); atomicAdd(&stats[3], (unsigned)skip); }
+    }
+    lds_sync();
+}
 #ifndef BP_BD_WAVES
 #define BP_BD_WAVES 2
 #endif
 // DAMP: space.damping != 0 (box_delivery_env.py:204, area_clearing.py: `space.damping = cfg.sim.damping`; no shipped config) -> substep<BP_ENV_BOX, true>
-template <bool DAMP>
+template <bool DAMP, bool CYC = false>
 __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtrs &D, const BdParams &B, const BdPtrs &Q)
 {
     const int env = (D.order != nullptr) ? D.order[blockIdx.x] : (int)blockIdx.x;
     const bool resume = B.pass == 1;
     if (resume && Q.unfin[env] == 0) return;       // pass 1 serves only the envs that pass 0 left unfinished
+    // ... in two launches: the envs that ran out of budget inside execute_robot_path (saved phase 0 = PH_PATH) go to the kernel that holds the recurrence test,
+    // the ones inside step_simulation_until_still -- the reference's own 10 001-step loops, which never recur -- stay on the lean kernel
+    if (resume && B.resume_sel != 0 && ((Q.rs_i[(size_t)env * 16] == 0) != (B.resume_sel == 1))) return;
     const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
     const int lane = lane_id();
     LdsCtx L;
@@ -618,6 +673,19 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
     const int first_static = B.first_box + B.nbox;
     const int nstat = E.nb - first_static;
     bool first_after_resume = false, hit_limit = false;   // hit_limit: one of the two loops ran into STEP_LIMIT in this env step (statistics only)
+    // Exact recurrence of execute_robot_path (kind-(i) stragglers: a robot that pushes against a wall until STEP_LIMIT, box_delivery_env.py:891-988).  While
+    // only the robot moves and no arbiter exists, the next sim step is a function of the robot's parts (pose, velocities), the controller's loop variables
+    // and nothing else -- boxes lie still and touch nothing, walls never move, cached planes / neighbour lists / the candidate cache only steer how the
+    // same results are reached.  If that state is bit for bit the one of p sim steps ago, the loop is periodic from here on, and whole periods can be
+    // skipped: only counters advance (sim steps, stamps, the advanced path length `al`, which is re-added step by step so that it rounds as the loop's
+    // own additions do, and which decides nothing once the set point has switched).  Brent's scheme finds any period with one snapshot (a power-of-two
+    // sim step ago, L.snap) and one comparison per sim step; the robots of the traces in profiles/r03_box/straggler_period.txt sit at a fixed point
+    // (p = 1) within a few hundred sim steps.  The last iteration of the loop always runs for real: it is the one that leaves.
+    // Where: in the second pass of the two-pass step only (CYC, k_bd_physics_resume).  The comparison costs ~3 % of a sim step and, inline in the one kernel
+    // every env runs, 42 more spilled VGPRs (-5 % for everybody); the envs that need it are exactly those that run out of the first pass's budget.
+    int cyc_pow = 1, cyc_lam = 0;
+    bool cyc_have = false;
+    unsigned cyc_costp = 0u;
     unsigned cycles_before = 0u;
     if (resume) {
         // the loop state of pass 0 (the bodies, arbiters and velocities came back through load_state, as after a park of the step scheduler)
@@ -819,6 +887,39 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
                 if (!leave) { sim_steps++; if (sim_steps > B.step_limit) { leave = true; hit_limit = true; } }
             }
             if (leave) { phase = after_move; sim_steps = 0; kcount = 0; }
+            else if (CYC && B.cycle_skip > 0 && sim_steps >= B.cycle_skip && !BP_TRACE_ON(D) && P.nkin < BP_SNAP_ROWS) {
+                // (CYC: the kernel of the second pass, which only the envs that ran out of the first pass's sim-step budget reach -- the 99th percentile of a
+                //  whole env step is ~1 100 sim steps, the budget 3 000)
+                const bool quiet = S.nmv == P.nkin && ballot(A.key != ARB_FREE_KEY) == 0ull && sp_one && dp_valid;
+                if (!quiet) { cyc_have = false; cyc_pow = 1; cyc_lam = 0; }
+                else {
+                    const unsigned long long w5 = (unsigned long long)(done_turning ? 1u : 0u) | ((unsigned long long)(unsigned)S.robot_hit << 1) | ((unsigned long long)(unsigned)S.wall_flag << 2) |
+                                                  ((unsigned long long)(unsigned)wi << 8) | ((unsigned long long)(unsigned)path0 << 20) | ((unsigned long long)(unsigned)S.nslots << 32) |
+                                                  ((unsigned long long)(unsigned)S.nlevels << 44);
+                    const unsigned long long w7 = (unsigned long long)S.n_post | ((unsigned long long)S.n_contact << 32);
+                    const unsigned long long w8 = (unsigned long long)S.n_first | ((unsigned long long)(unsigned)S.err << 32);
+                    const unsigned long long w9 = (unsigned long long)(unsigned)S.yaw_violated | ((unsigned long long)(unsigned)S.boundary_violated << 1) | ((unsigned long long)(unsigned)S.quiescent << 2);
+                    const int hit = cyc_have ? bd_cycle_visit(L.snap, L.sp, L.sv, L.sw, L.sb, L.slot_of, L.ctl, E.rot, E.ang, P.nkin, 0, w5, S.prev_amask, w7, w8, w9, S.total_ke, S.total_imp, S.curr_dt) : 0;
+                    const int iters_left = B.step_limit + 1 - sim_steps;      // iterations of the loop still to come; the last one leaves
+                    if (hit) {
+                        const int period = cyc_lam;
+                        const int skip = ((iters_left - 1) / period) * period;
+                        if (skip > 0) {
+                            sim_steps += skip; total_sub += (unsigned)skip; S.stamp += (unsigned)skip;
+                            S.costp += (unsigned)skip * ((S.costp - cyc_costp) / (unsigned)period);   // work proxy (dispatch heuristics only)
+                            bd_cycle_skip(L.mvs, L.ctl, P.nkin, S.stamp, skip, B.target_speed, B.ctrl_dt, Q.straggler);
+                        }
+                        cyc_have = false; cyc_pow = 1; cyc_lam = 0;
+                    } else {
+                        if (!cyc_have || cyc_lam == cyc_pow) {   // Brent: the snapshot moves to this sim step, the search window doubles
+                            bd_cycle_visit(L.snap, L.sp, L.sv, L.sw, L.sb, L.slot_of, L.ctl, E.rot, E.ang, P.nkin, 1, w5, S.prev_amask, w7, w8, w9, S.total_ke, S.total_imp, S.curr_dt);
+                            if (cyc_have) cyc_pow *= 2;
+                            cyc_have = true; cyc_lam = 0; cyc_costp = S.costp;
+                        }
+                        cyc_lam++;
+                    }
+                }
+            }
         } else if (phase == PH_VEL) {
             kcount++;
             if (S.robot_hit || kcount >= P.steps) {
@@ -878,6 +979,11 @@ __device__ __forceinline__ void bd_physics_body(const DevParams &P, const DevPtr
 __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
 {
     bd_physics_body<false>(P, D, B, Q);
+}
+// the second pass of the two-pass step: the same body with the recurrence test of execute_robot_path compiled in
+__global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics_resume(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
+{
+    bd_physics_body<false, true>(P, D, B, Q);
 }
 __global__ __launch_bounds__(64, BP_BD_WAVES) void k_bd_physics_damp(const DevParams P, const DevPtrs D, const BdParams B, const BdPtrs Q)
 {

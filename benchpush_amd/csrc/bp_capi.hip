@@ -48,6 +48,8 @@ struct bp_handle {
     std::vector<hipEvent_t> ev_parts;
     hipStream_t st_aux2 = nullptr;  // box-delivery / area-clearing: pass 1 of the two-pass step (the envs that ran out of pass 0's sim-step budget) and its tail kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
+    hipStream_t st_aux3 = nullptr;  // ... pass 1's kernel with the recurrence test of execute_robot_path, beside the lean one
+    hipEvent_t ev_join3 = nullptr;
     int bd_budget = 0;              // sim steps of pass 0 of the two-pass step, 0 = one pass (BP_BD_BUDGET)
     DevParams P;
     DevPtrs D;
@@ -284,6 +286,8 @@ int bp_destroy(bp_handle *h)
     resident_release(h);
     if (h->pd_buf) hipFree(h->pd_buf);
     if (h->st_aux2) { hipStreamSynchronize(h->st_aux2); hipStreamDestroy(h->st_aux2); }
+    if (h->st_aux3) { hipStreamSynchronize(h->st_aux3); hipStreamDestroy(h->st_aux3); }
+    if (h->ev_join3) hipEventDestroy(h->ev_join3);
     for (hipStream_t s_ : h->st_parts) { hipStreamSynchronize(s_); hipStreamDestroy(s_); }
     for (hipEvent_t e_ : h->ev_parts) hipEventDestroy(e_);
     if (h->ev_join2) hipEventDestroy(h->ev_join2);
@@ -803,6 +807,8 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
                     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
                     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+                    HIPCHK(h, hipStreamCreateWithFlags(&h->st_aux3, hipStreamNonBlocking));
+                    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
                 }
                 auto finish = [&](const BdParams &Bx, hipStream_t s_) {
                     if (h->B.task == 1) hipLaunchKernelGGL(k_ac_finish, dim3(E), dim3(64), h->bd_lds, s_, h->P, h->D, Bx, h->Q, 0, 0, reward, term, trunc, info);
@@ -823,7 +829,20 @@ static int launch(bp_handle *h, int mode, const double *actions, const unsigned 
                     // group 1 (unfinished): third stream
                     HIPCHK(h, hipStreamWaitEvent(h->st_aux2, h->ev_fork, 0));
                     if (h->damp) hipLaunchKernelGGL(k_bd_physics_damp, dim3(E), dim3(64), h->lds_bytes, h->st_aux2, h->P, h->D, B1, h->Q);
-                    else hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, h->st_aux2, h->P, h->D, B1, h->Q);
+                    else if (h->B.cycle_skip > 0) {
+                        // the envs that stopped inside execute_robot_path: the kernel with the recurrence test (a robot pushing against a wall is over after a
+                        // handful of sim steps there); then the others -- the reference's own until-still loops -- on the lean kernel
+                        // (side by side on two streams: an env that pushes boxes through a long path is neither)
+                        BdParams B1p = B1, B1s = B1;
+                        B1p.resume_sel = 1; B1s.resume_sel = 2;
+                        HIPCHK(h, hipStreamWaitEvent(h->st_aux3, h->ev_fork, 0));
+                        hipLaunchKernelGGL(k_bd_physics_resume, dim3(E), dim3(64), h->lds_bytes, h->st_aux3, h->P, h->D, B1p, h->Q);
+                        HIPCHK(h, hipGetLastError());
+                        HIPCHK(h, hipEventRecord(h->ev_join3, h->st_aux3));
+                        hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, h->st_aux2, h->P, h->D, B1s, h->Q);
+                        HIPCHK(h, hipGetLastError());
+                        HIPCHK(h, hipStreamWaitEvent(h->st_aux2, h->ev_join3, 0));
+                    } else hipLaunchKernelGGL(k_bd_physics, dim3(E), dim3(64), h->lds_bytes, h->st_aux2, h->P, h->D, B1, h->Q);
                     HIPCHK(h, hipGetLastError());
                     hipLaunchKernelGGL(k_bd_robot_map, dim3(E), dim3(BDR_THREADS), h->bd_rmap_lds, h->st_aux2, h->P, h->D, Bs1, h->Q, 0);
                     finish(Bs1, h->st_aux2);
@@ -1411,7 +1430,11 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     const BdMaps &M0 = h->bd_maps[0];
     B.H = M0.H; B.W = M0.W; B.SH = M0.SH; B.SW = M0.SW; B.si0 = M0.si0; B.sj0 = M0.sj0;
     B.nbox = nbox; B.nrecept = 1; B.out_r = M0.out_r;
-    B.budget = 0; B.pass = 0; B.sel_want = -1;
+    B.budget = 0; B.pass = 0; B.sel_want = -1; B.resume_sel = 0;
+    // execute_robot_path skips whole periods once the robot's state recurs exactly (a robot that pushes against a wall until STEP_LIMIT); BP_BD_CYCLE=0: every sim step is run
+    // (in the second pass of the two-pass step, whose envs are already beyond the first pass's budget: from the first sim step of the pass on; BP_BD_CYCLE=<n>: only
+    //  once a path has run n sim steps)
+    B.cycle_skip = getenv("BP_BD_CYCLE") ? std::max(0, atoi(getenv("BP_BD_CYCLE"))) : 1;
     // two-pass step: sim steps every env gets in pass 0 (the mean env needs ~750, the 99th percentile ~3 000; the reference's loops stop at 10 001); BP_BD_BUDGET=0: one pass
     h->bd_budget = getenv("BP_BD_BUDGET") ? atoi(getenv("BP_BD_BUDGET")) : 3000;
     const int NW = B.SH * B.SW, words = (NW + 31) / 32, nm = (int)h->bd_maps.size();
@@ -1476,7 +1499,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if ((rc = dalloc(h, &Q.unfin, E))) return rc;
     if ((rc = dalloc(h, &Q.rs_i, E * 16))) return rc;
     if ((rc = dalloc(h, &Q.rs_d, E * 132))) return rc;
-    if ((rc = dalloc(h, &Q.straggler, (size_t)2))) return rc;
+    if ((rc = dalloc(h, &Q.straggler, (size_t)4))) return rc;
     if ((rc = dalloc(h, &Q.dist, E * NW))) return rc;
     if ((rc = dalloc(h, &Q.rmap, E * NW))) return rc;
     if ((rc = dalloc(h, &Q.cleared, E * BD_MAXBOX))) return rc;
@@ -1491,6 +1514,7 @@ int bp_bd_load(bp_handle *h, int32_t T, int32_t nbox, const double *starts, cons
     if (h->bd_lds > 160 * 1024 || h->bd_obs_lds > 160 * 1024) return fail(h, BP_EINVAL, "map window too large for LDS");
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_settle, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
+    HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics_resume, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_physics_damp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     HIPCHK(h, hipFuncSetAttribute((const void *)k_bd_settle_damp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bytes));
     h->damp = h->P.damping_pow != 0.0;   // space.damping != 0: the generic instantiations (substep<BP_ENV_BOX, DAMP = true>)
@@ -1624,6 +1648,15 @@ int bp_bd_get_stragglers(bp_handle *h, uint32_t *out2_host)
     BP_DEVICE(h);
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out2_host, h->Q.straggler, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return BP_OK;
+}
+int bp_bd_get_cycle_skips(bp_handle *h, uint32_t *out2_host)
+{
+    if (!h || !out2_host) return BP_EINVAL;
+    if (!h->loaded || h->P.env_kind != BP_ENV_BOX || h->Q.straggler == nullptr) return fail(h, BP_ESTATE, "not a loaded box-delivery / area-clearing handle");
+    BP_DEVICE(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out2_host, h->Q.straggler + 2, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return BP_OK;
 }
 

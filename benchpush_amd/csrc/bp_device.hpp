@@ -165,12 +165,14 @@ __device__ __forceinline__ double fclampd(double f, double lo, double hi) { retu
 #define BP_NSLOT 96         // velocity slots per env (bodies with a non-zero velocity or an arbiter)
 #endif
 #define BP_PROFN 64         // diagnostic build: phase timers / trip counters per env
+#define BP_SNAP_ROWS 9      // box-delivery recurrence snapshot: one row per kinematic part of the robot (at most 8) + one for the controller
+#define BP_SNAP_COLS 12
 
 // LDS map of the physics kernels (one wavefront = one env), byte offsets from the start of dynamic LDS.  Used by the kernels (carve_lds) and by the
 // host (launch size), so the two cannot drift apart.
 struct LdsMap {
     unsigned sv, sw, sb, sp, ag, tf, q_dir, q_c, r_val, q_meta, q_aux, r_idx, pt_a, pt_thr, cc, cc_hw, res_smA, res_smB, res_iA, res_iB, res_jA, res_jB, mvs, owner, colmask, mvo, sbody, mv,
-        slot_of, rf, ev_d, ev_key, ctl, prof, total;
+        slot_of, rf, ev_d, ev_key, ctl, snap, prof, total;
 };
 __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, const bool box, const bool prof)
 {
@@ -213,6 +215,7 @@ __host__ __device__ inline LdsMap bp_lds_map(const int nbcap, const int mvcap, c
     m.ev_key = p; if (box) p += 4u * BP_EVCAP;
     p = (p + 7u) & ~7u;
     m.ctl = p; if (box) p += 8u * 4;           // box-delivery: wave-uniform doubles of the path controller, kept out of the VGPR file across the sim step
+    m.snap = p; if (box) p += 8u * BP_SNAP_ROWS * BP_SNAP_COLS;   // box-delivery: snapshot of the robot's state for the recurrence test of execute_robot_path
     m.prof = p; if (prof) p += 8u * BP_PROFN;
     m.total = (p + 15u) & ~15u;
     return m;

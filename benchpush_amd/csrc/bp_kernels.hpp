@@ -58,7 +58,8 @@ __device__ __forceinline__ void carve_lds(const DevParams &P, LdsCtx &L)
     L.mv = (unsigned short *)(b + m.mv); L.mvo = (unsigned *)(b + m.mvo); L.sbody = (unsigned short *)(b + m.sbody);
     L.slot_of = (unsigned char *)(b + m.slot_of); L.rf = (unsigned char *)(b + m.rf);
     L.ev_key = nullptr; L.ev_d = nullptr; L.ctl = nullptr;
-    if (KIND == BP_ENV_BOX) { L.ev_d = (d2 *)(b + m.ev_d); L.ev_key = (unsigned *)(b + m.ev_key); L.ctl = (double *)(b + m.ctl); }
+    L.snap = nullptr;
+    if (KIND == BP_ENV_BOX) { L.ev_d = (d2 *)(b + m.ev_d); L.ev_key = (unsigned *)(b + m.ev_key); L.ctl = (double *)(b + m.ctl); L.snap = (unsigned long long *)(b + m.snap); }
 #ifdef BP_PROF
     L.prof = (unsigned long long *)(b + m.prof);
 #endif

@@ -107,6 +107,7 @@ struct LdsCtx {
     unsigned *ev_key;          // [BP_EVCAP] shapeA << 16 | shapeB
     d2 *ev_d;                  // [BP_EVCAP][3] normal, r1, r2 of contact 0
     double *ctl;               // [4] box-delivery path controller: prev_heading_diff, path length, advanced length, robot_distance (k_bd_physics)
+    unsigned long long *snap;  // [BP_SNAP_ROWS][BP_SNAP_COLS] box-delivery: the robot's state at an earlier sim step of execute_robot_path (recurrence test, k_bd_physics)
 #ifdef BP_PROF
     unsigned long long *prof;  // [BP_PROFN] phase cycle counters and trip counts of this run (diagnostic build)
 #endif

@@ -95,6 +95,12 @@ class BatchedBoxDeliveryEnv(BatchedShipIceEnv):
         _lib.check(self.L, self.h, self.L.bp_bd_get_stragglers(self.h, out.ctypes.data_as(C.c_void_p)), "bp_bd_get_stragglers")
         return int(out[0]), int(out[1])
 
+    def cycle_skips(self):
+        """(exact recurrences found in execute_robot_path, sim steps they skipped), cumulative since load (bp_bd_get_cycle_skips)."""
+        out = np.zeros(2, np.uint32)
+        _lib.check(self.L, self.h, self.L.bp_bd_get_cycle_skips(self.h, out.ctypes.data_as(C.c_void_p)), "bp_bd_get_cycle_skips")
+        return int(out[0]), int(out[1])
+
     def maps(self, trial=0):
         dims = np.zeros(6, np.int32)
         p = lambda a: a.ctypes.data_as(C.c_void_p)

@@ -349,6 +349,13 @@ int bp_bd_get_maps(bp_handle *h, int32_t trial, int32_t *dims, uint8_t *cspace, 
  * BP_BD_BUDGET=<sim steps> sets the budget of the first pass at load time (default 3000; 0 = one pass); bp_bd_budget returns the value the handle uses (ABI 11). */
 int bp_bd_get_stragglers(bp_handle *h, uint32_t *out2_host);
 int32_t bp_bd_budget(bp_handle *h);
+/* Exact recurrences of execute_robot_path (box_delivery_env.py:891-988; ABI 11): while only the robot moves and no arbiter exists, a sim step is a function of the
+ * robot's parts and the controller's loop variables; when that state is bit for bit the one of p sim steps ago (a robot that pushes against a wall until
+ * STEP_LIMIT sits at a fixed point, p = 1, within a few hundred sim steps) whole periods are skipped -- results, sim-step counts and info columns are
+ * those of the full loop.  out2_host[0] = recurrences found, out2_host[1] = sim steps they skipped, cumulative since load (host uint32 [2], synchronises).
+ * The test runs in the second pass of the two-pass step (k_bd_physics_resume: the envs that ran out of the first pass's sim-step budget, BP_BD_BUDGET -- the kernel every
+ * env runs stays lean); BP_BD_CYCLE=<n> at load time: only once a path has run n sim steps, 0: every sim step is run. */
+int bp_bd_get_cycle_skips(bp_handle *h, uint32_t *out2_host);
 /* tests: per-env box bookkeeping, host buffers: alive uint8 [E][24], waypoints double [E][64][3], nwp int32 [E] (synchronises) */
 int bp_bd_get_state(bp_handle *h, uint8_t *alive, double *waypoints, int32_t *nwp);
 

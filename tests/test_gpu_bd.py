@@ -388,3 +388,43 @@ def test_full_size_properties_4096_envs():
         env.reset(term | trunc)
     env.check_errors()
     env.close()
+
+
+def test_exact_recurrence_shortcut_of_execute_robot_path(monkeypatch):
+    """A robot that pushes against a wall runs execute_robot_path into STEP_LIMIT (box_delivery_env.py:891-988: 10 001 sim steps, the kind-(i) stragglers that set a
+    launch's time).  Its state recurs bit for bit after a few hundred sim steps; the second pass of the two-pass step (k_bd_physics_resume) then skips whole periods
+    (bp_bd_get_cycle_skips).  The shortcut must change nothing: 2048 envs x 10 steps with it (default budget 3000; and with a budget of 150 sim steps, which sends
+    nearly every env step through the kernel that holds the test) and without it (BP_BD_CYCLE=0) -- bodies, observations, rewards, flags and the info block (incl.
+    the sim-step count of every env step) bit for bit, and the runs must actually contain recurrences."""
+    from benchpush_amd.envs.box_delivery import BatchedBoxDeliveryEnv
+    E, steps = 2048, 10
+
+    def run(cycle, budget):
+        monkeypatch.setenv("BP_BD_CYCLE", cycle)
+        monkeypatch.setenv("BP_BD_BUDGET", budget)
+        env = BatchedBoxDeliveryEnv(E, cfg={"boxes": {"num_boxes_small": 12}}, num_trials=64)
+        env.reset()
+        g = torch.Generator(device="cuda:0")
+        g.manual_seed(1234)
+        out = []
+        for t in range(steps):
+            a = torch.rand(E, generator=g, device="cuda:0", dtype=torch.float64) * 2 - 1
+            obs, rew, term, trunc, info = env.step(a)
+            out.append((env.body_state().clone(), obs.clone(), rew.clone(), term.clone(), trunc.clone(), info.clone()))
+            env.reset(term | trunc)
+        env.check_errors()
+        skips = env.cycle_skips()
+        limited = env.stragglers()[1]
+        env.close()
+        return out, skips, limited
+
+    off, skips_off, lim_off = run("0", "3000")
+    assert skips_off == (0, 0)
+    assert lim_off >= 1, "no env ran into STEP_LIMIT in this run: the test does not cover the shortcut"
+    for cycle, budget in (("1", "3000"), ("1", "150")):
+        on, skips_on, lim_on = run(cycle, budget)
+        assert lim_on == lim_off
+        for t in range(steps):
+            for a, b in zip(on[t], off[t]):
+                assert torch.equal(a, b), ("step", t, cycle, budget)
+        assert skips_on[0] >= 1 and skips_on[1] >= 1000, (skips_on, budget)

@@ -10,11 +10,11 @@ import re
 import sys
 
 # phases of substep() as line ranges of csrc/bp_physics.hpp (update when the file moves; `grep -n "// ---- " csrc/bp_physics.hpp`)
-PH = [(284, 299, '0head'), (300, 373, '1integrate'), (374, 387, '2refresh'), (388, 472, '3candidates'), (473, 522, '4a_cached_planes'),
-      (523, 681, '4a_bound_rounds+search'), (682, 837, '4b_manifold'), (838, 959, '4c_deliver'), (960, 976, '5events+filter'),
-      (977, 1014, '6a_prestep'), (1015, 1042, '6a_warmset'), (1043, 1082, '6a_colour'), (1083, 1108, '6b_velint'), (1109, 1132, '6c_warmstart'),
-      (1133, 1282, '6d_solver'), (1283, 1325, '7post'), (1326, 1380, '7mvlist'), (254, 279, 'support_queries'), (215, 237, 'world_from_pose'),
-      (162, 212, 'refresh_body')]
+PH = [(291, 307, '0head'), (308, 381, '1integrate'), (382, 395, '2refresh'), (396, 480, '3candidates'), (481, 530, '4a_cached_planes'),
+      (531, 689, '4a_bound_rounds+search'), (690, 861, '4b_manifold'), (862, 983, '4c_deliver'), (984, 1000, '5events+filter'),
+      (1001, 1038, '6a_prestep'), (1039, 1066, '6a_warmset'), (1067, 1106, '6a_colour'), (1107, 1132, '6b_velint'), (1133, 1156, '6c_warmstart'),
+      (1157, 1282, '6d_solver'), (1283, 1337, '7post'), (1338, 1404, '7mvlist'), (256, 280, 'support_queries'), (216, 238, 'world_from_pose'),
+      (163, 213, 'refresh_body')]
 
 
 def phase_of(chain):
