@@ -535,8 +535,8 @@ def main():
         nb = int(round(nf_mean)) + (11 if args.env == "maze" else 19 if args.env == "box" else 1)
         a_min, a_stream, a_phys = algorithmic_bytes_per_env_step(nb, nb - 1, maxv=20, obs_bytes=int(np.prod(env.obs_shape)))
         # SQ instruction mix / HBM traffic per launch need hardware counters: taken from the committed rocprofv3 passes of this kernel
-        # (profiles/r05_final/pmc.json -- the newest earlier round's until this round's profile exists --, written by tools/profile_gpu.sh for the build named inside; config c2 only), never measured in this run
-        pmc_dir = next((d for d in ("r05_final", "r04_final") if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc.json"))), "r03_final")
+        # (profiles/r06_final/pmc.json -- the newest earlier round's until this round's profile exists --, written by tools/profile_gpu.sh for the build named inside; config c2 only), never measured in this run
+        pmc_dir = next((d for d in ("r06_final", "r05_final", "r04_final") if os.path.exists(os.path.join(ROOT, "profiles", d, "pmc.json"))), "r03_final")
         pmc = profile_sourced(os.path.join(pmc_dir, "pmc.json")) if (args.env == "ship-ice" and args.config == "c2") else None
         roof = {
             "bound": "issue",
