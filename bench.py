@@ -576,7 +576,11 @@ def main():
                                                    "THIS kernel's time; nothing achieves it (SURVEY 8d asks for both accountings)"},
         }
         roof["frac"] = roof["achieved"] / HBM_PEAK_GBS if roof["achieved"] else None
-        if cost_stats is not None and len(cost_stats) and phys_ms > 0:
+        if pairing is not None and pairing.get("mode"):
+            roof["ceiling"] = None
+            roof["ceiling_note"] = ("pairing launch: an env's recorded cost is the time of the wavefront it shared (its mate's sub-steps included), so the sum over the envs is not "
+                                    "the work of the launch; the two ceilings are printed for launches with one env per wavefront")
+        elif cost_stats is not None and len(cost_stats) and phys_ms > 0:
             # the two lower bounds of a launch, from this run's own per-env cycle counts (bp_get_cost_stats) and this run's own clock
             ck_ = clock_hz if clock_hz else 2.4e9
             slots_ = int(env.L.bp_sched_resident(env.h)) if hasattr(env.L, "bp_sched_resident") else 0
