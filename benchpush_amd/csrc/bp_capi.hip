@@ -44,7 +44,7 @@ struct bp_handle {
     unsigned launches = 0;
     int num_cus = 0;                // multiProcessorCount of the handle's device
     hipStream_t st_aux = nullptr;   // box-delivery / area-clearing: the robot's spfa map runs beside the finish kernel; ship-ice: the solo kernel of a pairing launch
-    std::vector<hipStream_t> st_parts;   // ship-ice: the scheduled launch split over several hardware queues (BP_SCHED_PARTS)
+    std::vector<hipStream_t> st_parts;   // ship-ice: the scheduled launch split over several hardware queues (a measured variant; P.sq_parts is 1 since round 6)
     std::vector<hipEvent_t> ev_parts;
     hipStream_t st_aux2 = nullptr;  // box-delivery / area-clearing: pass 1 of the two-pass step (the envs that ran out of pass 0's sim-step budget) and its tail kernels
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
@@ -466,16 +466,19 @@ static int upload_trials(bp_handle *h, const std::vector<std::vector<bpgeom::Sha
         if (plain && ch > 0 && (h->P.steps + ch - 1) / ch <= SQ_MAXLEV && h->num_envs < (1 << 24)) {
             h->sched_chunk = ch;
             h->P.sq_chunk = ch; h->P.sq_levels = (h->P.steps + ch - 1) / ch;
-            h->P.sq_hold = getenv("BP_SCHED_HOLD") ? atoi(getenv("BP_SCHED_HOLD")) : 0;
-            h->P.sq_lrpt = getenv("BP_SCHED_LRPT") ? atoi(getenv("BP_SCHED_LRPT")) : 0;
-            h->P.sq_bw = std::max(1, getenv("BP_SCHED_BW") ? atoi(getenv("BP_SCHED_BW")) : 9000);     // ~1 ms of a wavefront at 2.4 GHz
-            h->P.sq_hyst = std::max(0, getenv("BP_SCHED_HYST") ? atoi(getenv("BP_SCHED_HYST")) : 1);
-            h->P.sq_floor = std::max(0, getenv("BP_SCHED_FLOOR") ? atoi(getenv("BP_SCHED_FLOOR")) : 150);
+            // Measured-and-lost scheduler variants (longest-remaining-first keys, hold, static class sets, the launch split over hardware queues: tools/experiments/README.md)
+            // are no longer load-time switches (round 6).  Their kernel code paths stay compiled -- taking them out of physics_body / sched_body moved the register allocation
+            // of k_physics_step_schedl and cost 1.0 % at 4096 envs, same box, both alternations (tools/experiments/r06_removed_scheduler_variants.diff) -- and are switched off here.
+            h->P.sq_hold = 0;
+            h->P.sq_lrpt = 0;
+            h->P.sq_bw = 9000;
+            h->P.sq_hyst = 1;
+            h->P.sq_floor = 150;
             // pace-based issue priorities (physics_body: pace_prio), per cent of the reference cost for priority 3: +1.5 ... +2.4 % at 4096 envs, flat from 100 to 130
             h->P.sq_dynprio = getenv("BP_SCHED_DYNPRIO") ? atoi(getenv("BP_SCHED_DYNPRIO")) : 115;
             h->P.sq_ymask = 0xFFFFFFFFu;   // (set below, once it is known whether the launch pairs)
-            h->P.sq_cls = getenv("BP_SCHED_CLS") ? atoi(getenv("BP_SCHED_CLS")) : 0;
-            h->P.sq_parts = std::min(8, std::max(1, getenv("BP_SCHED_PARTS") ? atoi(getenv("BP_SCHED_PARTS")) : 1));
+            h->P.sq_cls = 0;
+            h->P.sq_parts = 1;
             h->P.sq_part = 0;
             h->P.sq_cap = h->num_envs; // an env's home XCD is where its first chunk ran: any share of the envs
             int *d_items, *d_ctr; unsigned *d_carry; unsigned char *d_moved;
