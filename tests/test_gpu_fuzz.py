@@ -18,7 +18,7 @@ from fuzz_scenes import fuzz_params, make_scenes  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-SUBSTEPS, STEPS, PER_RADIUS = 40, 3, 2000
+SUBSTEPS, STEPS, PER_RADIUS = 40, 3, int(os.environ.get("BP_FUZZ_SCENES", "2000"))   # BP_FUZZ_SCENES=<n per radius> for a longer one-off sweep
 
 
 def _oracle_run(params, cfg, scenes, actions):
@@ -90,7 +90,7 @@ def test_differential_fuzz_oracle_vs_solo_vs_paired(monkeypatch, radius):
                 assert rew[e] == orr and bool(term[e]) == ot, (name, "reward / termination", e, t)
                 assert np.array_equal(info[e], oi), (name, "info", e, t)
                 ncontact += int(oi[14])
-    assert ncontact > 100000   # the scenes do collide: ship x floe contact points over all scenes, steps and kernels
+    assert ncontact > 50 * PER_RADIUS   # the scenes do collide: ship x floe contact points over all scenes, steps and kernels
 
 
 def test_fuzz_scenes_cover_the_constructed_families():
