@@ -564,7 +564,9 @@ def main():
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None,
             "binds": "wave issue slots and dependent-instruction latency of one wavefront per env, not HBM and not MFMA: the state stays "
                      "on-chip for the 400 sub-steps; with the preemptive scheduler the launch is within a few per cent of BOTH the chain of its "
-                     "heaviest env and the sum of all chains / 2048 wave slots (DESIGN.md section 4a)",
+                     "heaviest env and the sum of all chains / 2048 wave slots (DESIGN.md section 4a; both are measured in this run: roofline.ceiling).  Of the two the "
+                     "chains bind: exact work reductions that reach only the light envs (two envs per wavefront, skipping the tail of the ~30 % of sub-steps without a "
+                     "warm arbiter) left the launch where it was (DESIGN.md section 4d6)",
             "raster_kernel": {"kernel": {"ship-ice": "k_observe", "maze": "k_observe_maze"}.get(args.env, "k_bd_observe"),
                               "bytes_written_per_env": int(np.prod(env.obs_shape)),
                               "achieved": int(np.prod(env.obs_shape)) * E / (rast_ms * 1e-3) / 1e9 if rast_ms > 0 else None,
